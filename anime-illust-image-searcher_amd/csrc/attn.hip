@@ -1,0 +1,190 @@
+// attn.hip -- fused softmax(Q K^T) V for the ViT blocks (timm Attention inside tagging.py:174).
+//
+// Non-causal, no mask, head_dim 64, a few hundred tokens (784 for ViT-B/16 @448).
+// One workgroup = 4 waves = 128 query rows of one (image, head); a wave owns 32 query rows.
+// Flash-style: K / V^T tiles of 64 keys are staged through LDS (registers -> ds_write, next
+// tile's global loads issued before the current tile's math), scores never leave registers.
+//
+//   S^T = K Q^T      v_mfma_f32_32x32x16_bf16, A = K tile rows (keys), B = Q^T held in registers.
+//                    The accumulator then has the QUERY on the lane (column) and 16 of the 32 keys in
+//                    its registers, so the online softmax is lane-local (one cross-half exchange).
+//   O^T = V^T P^T    the S^T accumulator, converted to bf16, is directly the B operand (no lane
+//                    movement); its k order inside a 16-key step is  16s + 8(j>>2) + 4h + (j&3),
+//                    and the V^T A-fragment is read from LDS in that same order (two ds_read_b64).
+//                    O^T keeps the query on the lane too: rescale and final 1/l are lane-local.
+// V arrives already transposed ([head][d][token]) from the QKV GEMM epilogue.
+// LDS rows are padded (K: 144 B, V^T: 136 B) so the b128 / b64 fragment reads are conflict free.
+// Keys beyond `tokens` (padding up to a multiple of 64) are masked to -inf; padded K / V^T entries
+// are zero (buffers are cleared once and the epilogues never write there).
+#include "vit_internal.h"
+
+namespace hipts {
+namespace {
+
+constexpr int KV = 64;               // keys per tile
+constexpr int KS = 144;              // LDS bytes per K row   (64 d  * 2 B + 16)
+constexpr int VS = 136;              // LDS bytes per V^T row (64 key* 2 B + 8)
+constexpr int K_BYTES = KV * KS;     // 9216
+constexpr int V_BYTES = 64 * VS;     // 8704
+constexpr int STAGE = K_BYTES + V_BYTES;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                   const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
+                                                   int tokens, int tokens_pad, int qblocks) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = (qb * 4 + wave) * 32;
+    int qrow = q0 + r;
+    qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
+
+    // Q^T fragments (B operand): lane (q = r, half h), k-step s: d = 16 s + 8 h .. + 7
+    bf16x8 qf[4];
+    {
+        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+
+    // staging assignment: K tile = 64 rows x 8 chunks of 16 B, V^T tile likewise; 2 chunks each per thread
+    const bf16_t* kbase = k + (size_t)bh * tokens_pad * 64;
+    const bf16_t* vbase = vT + (size_t)bh * 64 * tokens_pad;
+    uint4 kreg[2], vreg[2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, col = c & 7;
+            kreg[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)(kv0 + row) * 64 + col * 8);
+            vreg[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * tokens_pad + kv0 + col * 8);
+        }
+    };
+    auto write_tile = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, col = c & 7;
+            *reinterpret_cast<uint4*>(st + row * KS + col * 16) = kreg[i];
+            uint2* vp = reinterpret_cast<uint2*>(st + K_BYTES + row * VS + col * 16);
+            vp[0] = make_uint2(vreg[i].x, vreg[i].y);
+            vp[1] = make_uint2(vreg[i].z, vreg[i].w);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        o[0][i] = 0.f;
+        o[1][i] = 0.f;
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkv = tokens_pad / KV;
+    load_tile(0);
+    write_tile(smem);
+    __syncthreads();
+
+    for (int t = 0; t < nkv; ++t) {
+        const char* st = smem + (t & 1) * STAGE;
+        const int kv0 = t * KV;
+        if (t + 1 < nkv) load_tile(kv0 + KV);
+
+        // ---- S^T = K Q^T : two groups of 32 keys
+        f32x16 sacc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[g][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
+                sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[g], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (base-2 domain); the query is on the lane
+        float mx = -INFINITY;
+        const bool tail = kv0 + KV > tokens;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sacc[g][i] * LOG2E;
+                if (tail && kv0 + g * 32 + crow(i, h) >= tokens) v = -INFINITY;
+                sacc[g][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float lsum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
+                lsum += p;
+                pf[g][i >> 3][i & 7] = (bf16_t)p;
+            }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o[0][i] *= alpha;
+            o[1][i] *= alpha;
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const char* vrow = st + K_BYTES + (blk * 32 + r) * VS;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int key = g * 32 + 16 * s2 + 4 * h;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + key * 2);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (key + 8) * 2);
+                    bf16x8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][s2], o[blk], 0, 0, 0);
+                }
+        }
+        if (t + 1 < nkv) write_tile(smem + ((t + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: out[(b*tokens + q)][head*64 + d], 4 consecutive d per register group
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + r;
+    if (qi < tokens) {
+        bf16_t* op = out + ((size_t)b * tokens + qi) * (heads * 64) + head * 64;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[blk][4 * g4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) = v;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
+                     int tokens_pad, hipStream_t s) {
+    HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens, "attention: tokens_pad must be a multiple of %d", KV);
+    const int qtiles = (tokens + 31) / 32;
+    const int qblocks = (qtiles + 3) / 4;
+    attn_kernel<<<batch * heads * qblocks, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+}  // namespace hipts

@@ -1,0 +1,91 @@
+// common.h -- shared host-side plumbing of libhip_tagsearch.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/hip_tagsearch.h"
+
+namespace hipts {
+
+std::string& last_error_ref();
+int set_error(int status, const char* fmt, ...);
+
+// Makes `device` current; fails with HIPTS_ERR_NO_DEVICE when there is no such gfx950 device.
+int use_device(int device);
+
+#define HIPTS_HIP(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::hipts::set_error(HIPTS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                                      hipGetErrorString(_e), __FILE__, __LINE__);              \
+    } while (0)
+
+#define HIPTS_TRY(expr)                                                                        \
+    do {                                                                                       \
+        int _s = (expr);                                                                       \
+        if (_s != HIPTS_OK) return _s;                                                         \
+    } while (0)
+
+#define HIPTS_REQUIRE(cond, ...)                                                               \
+    do {                                                                                       \
+        if (!(cond)) return ::hipts::set_error(HIPTS_ERR_INVALID, __VA_ARGS__);                \
+    } while (0)
+
+#define HIPTS_LAUNCH_CHECK()                                                                   \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e != hipSuccess)                                                                  \
+            return ::hipts::set_error(HIPTS_ERR_HIP, "kernel launch failed: %s (%s:%d)",       \
+                                      hipGetErrorString(_e), __FILE__, __LINE__);              \
+    } while (0)
+
+// Device allocation owned by a handle.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_error(HIPTS_ERR_OOM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        }
+        bytes = n;
+        return HIPTS_OK;
+    }
+    // grow-only
+    int reserve(size_t n) { return n <= bytes ? HIPTS_OK : alloc(n); }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline int upload(void* dst, const void* src, size_t bytes, hipStream_t s = nullptr) {
+    if (bytes == 0) return HIPTS_OK;
+    HIPTS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    HIPTS_HIP(hipStreamSynchronize(s));
+    return HIPTS_OK;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace hipts

@@ -1,0 +1,238 @@
+// d2v.hip -- Doc2Vec PV-DBOW inference, one wavefront per document.
+//
+// Replaces gensim Doc2Vec.infer_vector as the reference calls it (genmodel.py:169 for every
+// document, webui.py:106,185 per query tag / per reranked document; model built at
+// genmodel.py:159 with dm=0, vector_size=300, negative=5, hs=0, sample=1e-3).
+// Algorithm restated from gensim 4.3.3 (doc2vec.py::infer_vector, doc2vec_inner.pyx::
+// train_document_dbow / fast_document_dbow_neg, word2vec_inner.pyx: 48-bit LCG, EXP_TABLE,
+// bisect_left over cum_table).  gensim itself is not available: parity is against
+// oracle/csrc/oracle.c, which restates the same algorithm with the same explicit inputs
+// (start vector v0, per-document seed -> per-epoch LCG state via splitmix64).
+//
+// A document is a serial chain of ~epochs*words*(1+negative) dot/axpy steps on one 300-d vector,
+// so the parallelism is across documents: the vector lives in 5 VGPRs per lane (element i on lane
+// i%64), dot products are 5 fused multiply-adds + a 6-step xor butterfly, control flow is
+// wave-uniform.  Bound by dependent-load latency (syn1neg row gather, cum_table search), not by
+// HBM or MFMA.
+#include "common.h"
+
+using namespace hipts;
+
+struct hipts_d2v {
+    int device = 0;
+    int64_t V = 0;
+    int dim = 0, negative = 5;
+    double exp_scale = 83.0;
+    bool has_sample = false;
+    DevBuf syn1neg, cum_table, sample_int, exp_table;
+    DevBuf ws_ptr, ws_words, ws_v0, ws_seeds, ws_out;
+};
+
+namespace {
+
+constexpr int EXP_TABLE_SIZE = 1000;
+constexpr int MAX_EXP = 6;
+constexpr uint64_t LCG_MOD = 281474976710655ULL;   // 2^48 - 1
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// bisect_left(a, x, 0, n): smallest i with a[i] >= x.  64-ary search: each lane probes the last
+// element of its chunk, the ballot tells which chunk holds the answer (3 rounds for n = 10k).
+__device__ __forceinline__ uint32_t bisect_left_wave(const uint32_t* __restrict__ a, uint32_t x, uint32_t n, int lane) {
+    uint32_t lo = 0;
+    while (n > 0) {
+        const uint32_t step = (n + 63) >> 6;
+        uint32_t idx = lo + (uint32_t)(lane + 1) * step - 1;
+        const uint32_t last = lo + n - 1;
+        idx = idx < last ? idx : last;
+        const bool below = a[idx] < x;
+        const uint64_t mask = __ballot(below);
+        const uint32_t c = (uint32_t)__popcll(mask);
+        if (c == 64) return lo + n;
+        const uint32_t nlo = lo + c * step;
+        uint32_t chunk_last = nlo + step - 1;
+        chunk_last = chunk_last < last ? chunk_last : last;
+        lo = nlo;
+        n = chunk_last - nlo;     // a[chunk_last] >= x is known
+    }
+    return lo;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void d2v_infer_kernel(const float* __restrict__ syn1neg, const uint32_t* __restrict__ cum_table,
+                                                        const uint32_t* __restrict__ sample_int, int64_t V, int dim,
+                                                        const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ words,
+                                                        int64_t ndocs, const float* __restrict__ v0,
+                                                        const uint64_t* __restrict__ seeds, int epochs, float alpha0,
+                                                        float min_alpha, int negative, double exp_scale,
+                                                        const float* __restrict__ exp_table_g, float* __restrict__ out) {
+    __shared__ float exp_table[EXP_TABLE_SIZE];
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += 256) exp_table[i] = exp_table_g[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t doc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (doc >= ndocs) return;                       // whole wave exits together
+    float v[EPL], work[EPL], rw[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) v[c] = (lane + 64 * c < dim) ? v0[doc * dim + lane + 64 * c] : 0.0f;
+    const int64_t wb = doc_ptr[doc], we = doc_ptr[doc + 1];
+    const uint64_t seed = seeds[doc];
+    const uint32_t cum_last = cum_table[V - 1];
+    double alpha = (double)alpha0;
+    const double alpha_delta = ((double)alpha0 - (double)min_alpha) / (double)(epochs - 1 > 1 ? epochs - 1 : 1);
+    for (int e = 0; e < epochs; ++e) {
+        uint64_t next_random = uniform64(splitmix64(seed + (uint64_t)e) & LCG_MOD);
+        const float a = (float)alpha;
+        for (int64_t i = wb; i < we; ++i) {
+            const int32_t w = __builtin_amdgcn_readfirstlane(words[i]);
+            if (w < 0 || w >= V) continue;
+            if (sample_int) {
+                const uint64_t r = next_random >> 16;
+                next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                if ((uint64_t)sample_int[w] < r) continue;
+            }
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) work[c] = 0.0f;
+            for (int d = 0; d < negative + 1; ++d) {
+                uint32_t target;
+                float label;
+                if (d == 0) {
+                    target = (uint32_t)w;
+                    label = 1.0f;
+                } else {
+                    const uint32_t x = (uint32_t)(next_random >> 16) % cum_last;
+                    target = __builtin_amdgcn_readfirstlane(bisect_left_wave(cum_table, x, (uint32_t)V, lane));
+                    next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                    if (target == (uint32_t)w) continue;
+                    label = 0.0f;
+                }
+                const float* __restrict__ row = syn1neg + (int64_t)target * dim;
+                float p = 0.0f;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) {
+                    rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
+                    p = fmaf(v[c], rw[c], p);
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) p = p + __shfl_xor(p, m);
+                float f = p;
+                if (f <= -(float)MAX_EXP || f >= (float)MAX_EXP) continue;
+                f = exp_table[(int)((double)(f + (float)MAX_EXP) * exp_scale)];
+                const float g = (label - f) * a;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) work[c] = fmaf(g, rw[c], work[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) v[c] = v[c] + work[c];
+        }
+        alpha -= alpha_delta;
+    }
+#pragma unroll
+    for (int c = 0; c < EPL; ++c)
+        if (lane + 64 * c < dim) out[doc * dim + lane + 64 * c] = v[c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipts_d2v_create(const float* syn1neg, const uint32_t* cum_table, const uint32_t* sample_int, int64_t vocab, int dim,
+                     int negative, double exp_scale, int device, hipts_d2v_t** out) {
+    HIPTS_REQUIRE(syn1neg && cum_table && out && vocab >= 1 && vocab < (1ll << 31), "hipts_d2v_create: bad arguments");
+    HIPTS_REQUIRE(dim >= 1 && dim <= 512, "hipts_d2v_create: dim must be in [1, 512]");
+    HIPTS_REQUIRE(negative >= 0 && negative <= 64, "hipts_d2v_create: negative out of range");
+    HIPTS_REQUIRE(cum_table[vocab - 1] > 0, "hipts_d2v_create: cum_table[-1] must be positive");
+    HIPTS_TRY(use_device(device));
+    auto* h = new hipts_d2v();
+    h->device = device;
+    h->V = vocab;
+    h->dim = dim;
+    h->negative = negative;
+    h->exp_scale = exp_scale;
+    h->has_sample = sample_int != nullptr;
+    // word2vec_inner.pyx: EXP_TABLE[i] = exp((i / 1000 * 2 - 1) * 6); EXP_TABLE[i] /= (EXP_TABLE[i] + 1)   (REAL_t)
+    float table[EXP_TABLE_SIZE];
+    for (int i = 0; i < EXP_TABLE_SIZE; ++i) {
+        const float e = (float)exp((i / (float)EXP_TABLE_SIZE * 2 - 1) * MAX_EXP);
+        table[i] = (float)(e / (e + 1));
+    }
+    int st;
+    if ((st = h->syn1neg.alloc((size_t)vocab * dim * 4)) || (st = h->cum_table.alloc((size_t)vocab * 4)) ||
+        (st = h->exp_table.alloc(sizeof(table))) || (st = upload(h->syn1neg.p, syn1neg, (size_t)vocab * dim * 4)) ||
+        (st = upload(h->cum_table.p, cum_table, (size_t)vocab * 4)) || (st = upload(h->exp_table.p, table, sizeof(table))) ||
+        (sample_int && ((st = h->sample_int.alloc((size_t)vocab * 4)) || (st = upload(h->sample_int.p, sample_int, (size_t)vocab * 4))))) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return HIPTS_OK;
+}
+
+int hipts_d2v_destroy(hipts_d2v_t* h) {
+    if (h) {
+        (void)hipSetDevice(h->device);
+        delete h;
+    }
+    return HIPTS_OK;
+}
+
+int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words, int64_t ndocs, const float* v0,
+                    const uint64_t* seeds, int epochs, float alpha, float min_alpha, float* out, int out_memspace,
+                    void* stream) {
+    HIPTS_REQUIRE(h && doc_ptr && v0 && seeds && out && ndocs >= 1 && epochs >= 1, "hipts_d2v_infer: bad arguments");
+    HIPTS_TRY(use_device(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nw = doc_ptr[ndocs];
+    HIPTS_REQUIRE(doc_ptr[0] == 0 && nw >= 0 && (words || nw == 0), "hipts_d2v_infer: bad CSR");
+    HIPTS_TRY(h->ws_ptr.reserve((size_t)(ndocs + 1) * 8));
+    HIPTS_TRY(h->ws_words.reserve((size_t)nw * 4));
+    HIPTS_TRY(h->ws_v0.reserve((size_t)ndocs * h->dim * 4));
+    HIPTS_TRY(h->ws_seeds.reserve((size_t)ndocs * 8));
+    HIPTS_HIP(hipMemcpyAsync(h->ws_ptr.p, doc_ptr, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s));
+    if (nw) HIPTS_HIP(hipMemcpyAsync(h->ws_words.p, words, (size_t)nw * 4, hipMemcpyHostToDevice, s));
+    HIPTS_HIP(hipMemcpyAsync(h->ws_v0.p, v0, (size_t)ndocs * h->dim * 4, hipMemcpyHostToDevice, s));
+    HIPTS_HIP(hipMemcpyAsync(h->ws_seeds.p, seeds, (size_t)ndocs * 8, hipMemcpyHostToDevice, s));
+    float* out_dev = out;
+    if (out_memspace != HIPTS_DEVICE) {
+        HIPTS_TRY(h->ws_out.reserve((size_t)ndocs * h->dim * 4));
+        out_dev = h->ws_out.as<float>();
+    }
+    const int grid = ceil_div(ndocs, 4);
+    const int epl = (h->dim + 63) / 64;
+#define D2V_LAUNCH(E)                                                                                                   \
+    d2v_infer_kernel<E><<<grid, 256, 0, s>>>(h->syn1neg.as<float>(), h->cum_table.as<uint32_t>(),                       \
+                                             h->has_sample ? h->sample_int.as<uint32_t>() : nullptr, h->V, h->dim,      \
+                                             h->ws_ptr.as<int64_t>(), h->ws_words.as<int32_t>(), ndocs,                 \
+                                             h->ws_v0.as<float>(), h->ws_seeds.as<uint64_t>(), epochs, alpha, min_alpha, \
+                                             h->negative, h->exp_scale, h->exp_table.as<float>(), out_dev)
+    switch (epl) {
+        case 1: D2V_LAUNCH(1); break;
+        case 2: D2V_LAUNCH(2); break;
+        case 3: D2V_LAUNCH(3); break;
+        case 4: D2V_LAUNCH(4); break;
+        case 5: D2V_LAUNCH(5); break;
+        case 6: D2V_LAUNCH(6); break;
+        case 7: D2V_LAUNCH(7); break;
+        default: D2V_LAUNCH(8); break;
+    }
+#undef D2V_LAUNCH
+    HIPTS_LAUNCH_CHECK();
+    if (out_memspace != HIPTS_DEVICE) {
+        HIPTS_HIP(hipMemcpyAsync(out, out_dev, (size_t)ndocs * h->dim * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIPTS_HIP(hipStreamSynchronize(s));   // staging buffers are reused by the next call
+    return HIPTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,731 @@
+// query.hip -- query-scoring path: BM25, dense similarity index, combine, top-k, fused search.
+//
+// Reference behaviour followed (file:line relative to the reference repository):
+//   BM25 statistics      genmodel.py:51-99
+//   BM25 scoring         webui.py:119-172
+//   index[query]         webui.py:205,352   (gensim Similarity / MatrixSimilarity, dense float32)
+//   normalise + combine  webui.py:377-383
+//   ranking              webui.py:191-192   (stable sort by -score: ties keep ascending doc id)
+//
+// All of it is HBM/L2-bound streaming work: coalesced reads, wave reductions,
+// no GEMM reshaping except the index product, which uses the exact-f32 MFMA because its fixed
+// k-ordered fma chain makes the float32 result bit-reproducible (and equal to the CPU oracle).
+// This file is compiled with -ffp-contract=off: every float64 expression below evaluates in
+// numpy's operation order with one rounding per operation.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+using namespace hipts;
+
+// =============================================================================================
+// BM25
+// =============================================================================================
+struct hipts_bm25 {
+    int device = 0;
+    int64_t D = 0, nnz = 0;
+    int32_t V = 0;
+    double avgdl = 0.0;
+    std::vector<int64_t> h_ptr, h_dl, h_df;
+    std::vector<int32_t> h_term, h_tf;
+    std::vector<double> h_idf;
+    DevBuf d_ptr, d_term, d_tf, d_dl, d_idf;   // int64[D+1], int32[nnz], int32[nnz], int32[D], double[V]
+    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final;
+};
+
+namespace {
+
+constexpr double BM25_K1 = 1.5;    // webui.py:126
+constexpr double BM25_B = 0.75;    // webui.py:127
+constexpr double REQUIRE_MAGIC = 1000.0;   // webui.py:60
+
+// One thread per (document, query).  Document-major CSR: the ~20 (term, tf) pairs of a document
+// are contiguous, consecutive threads own consecutive documents, so a wave sweeps one contiguous
+// span of the postings arrays.
+__global__ __launch_bounds__(256) void bm25_score_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ term,
+                                                         const int32_t* __restrict__ tf, const int32_t* __restrict__ dl,
+                                                         const double* __restrict__ idf, int32_t V, double avgdl, int64_t D,
+                                                         const int32_t* __restrict__ q_terms, const double* __restrict__ q_weights,
+                                                         const int32_t* __restrict__ q_ptr, double* __restrict__ out) {
+    const int q = blockIdx.y;
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const int qb = q_ptr[q], qe = q_ptr[q + 1];
+    const int64_t b = ptr[d], e = ptr[d + 1];
+    // webui.py:144  k1 * (1 - b + b * (dl / avgdl))   [(1-b) folds to 0.25 exactly]
+    const double dlv = (double)dl[d];
+    const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv / avgdl));
+    double s = 0.0;
+    bool masked = false;
+    for (int j = qb; j < qe; ++j) {
+        const int32_t t = q_terms[j];
+        const double w = q_weights[j];
+        int32_t tfv = 0;
+        for (int64_t i = b; i < e; ++i)
+            if (term[i] == t) tfv = tf[i];
+        const double idf_t = (t >= 0 && t < V) ? idf[t] : 0.0;   // bm25_idf.get(term_id, 0)   :140
+        const double tfd = (double)tfv;
+        const double denom = tfd + nrm;                          // :144
+        const double numer = tfd * (BM25_K1 + 1.0);              // :145
+        const double sc = idf_t * (numer / denom);               // :146
+        if (w < 0.0) {                                           // :154-160 exclude
+            if (tfv > 0) masked = true;
+        } else if (w > REQUIRE_MAGIC) {                          // :161-168 required
+            s += (w - REQUIRE_MAGIC) * sc;
+            if (tfv == 0) masked = true;
+        } else {                                                 // :169-170
+            s += w * sc;
+        }
+    }
+    out[(int64_t)q * D + d] = masked ? -INFINITY : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row maxima (numpy .max(): NaN-free inputs assumed)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void rowmax_kernel(const T* __restrict__ v, int64_t n, T* __restrict__ out) {
+    const T* row = v + (int64_t)blockIdx.x * n;
+    T m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmax(m, row[i]);
+    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    __shared__ T part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        T x = threadIdx.x < 16 ? part[threadIdx.x] : (T)-INFINITY;
+        for (int o = 8; o >= 1; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+        if (threadIdx.x == 0) out[blockIdx.x] = x;
+    }
+}
+
+// webui.py:377-383 (and :208 with norm flags off):
+//   out = wa * (a / max_a) + (double)((float)wb * (b / max_b))
+__global__ __launch_bounds__(256) void combine_kernel(const double* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                      double wa, float wb, const double* __restrict__ max_a,
+                                                      const float* __restrict__ max_b, double* __restrict__ out) {
+    const int q = blockIdx.y;
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= n) return;
+    double A = a[(int64_t)q * n + d];
+    float B = b[(int64_t)q * n + d];
+    if (max_a) {
+        const double m = max_a[q];
+        if (m > 0.0) A = A / m;
+    }
+    if (max_b) {
+        const float m = max_b[q];
+        if (m > 0.0f) B = B / m;
+    }
+    const float wB = wb * B;                      // python float * float32 array stays float32
+    out[(int64_t)q * n + d] = wa * A + (double)wB;
+}
+
+// =============================================================================================
+// Dense similarity: scores[q][d] = chain_k fma(row[d][k], query[q][k], acc)
+// v_mfma_f32_32x32x2_f32: A = 32 queries x 2 k, B = 2 k x 32 documents, D[query][document].
+// Per wave: a 32-document tile, the whole K; up to 32 queries per pass for the price of one
+// (the kernel is HBM-bound: 32 x 1200 B per 150 MFMAs per wave).
+// =============================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__ index, int64_t D, int K, int64_t ld,
+                                                       const float* __restrict__ q, int nq, float* __restrict__ out,
+                                                       int64_t out_ld) {
+    extern __shared__ __attribute__((aligned(16))) float qT[];   // [K][32]: qT[k*32 + j] = q[j][k]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < K * 32; i += 256) {
+        const int k = i >> 5, j = i & 31;
+        qT[i] = j < nq ? q[(int64_t)j * K + k] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (D + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t doc = tile * 32 + r;
+        const int64_t docc = doc < D ? doc : D - 1;
+        const float* __restrict__ row = index + docc * ld;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 8 <= K; k += 8) {
+            const float4 v0 = *reinterpret_cast<const float4*>(row + k);
+            const float4 v1 = *reinterpret_cast<const float4*>(row + k + 4);
+            const float b0 = h ? v0.y : v0.x, b1 = h ? v0.w : v0.z, b2 = h ? v1.y : v1.x, b3 = h ? v1.w : v1.z;
+            const float* qk = qT + (k + h) * 32 + r;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[0], b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[64], b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[128], b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[192], b3, acc, 0, 0, 0);
+        }
+        for (; k + 2 <= K; k += 2) {   // K % 8 tail (K is even, checked on the host)
+            const float b0 = row[k + h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qT[(k + h) * 32 + r], b0, acc, 0, 0, 0);
+        }
+        // D layout: column = lane & 31 = document, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = query
+        if (doc < D) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int qi = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (qi < nq) out[(int64_t)qi * out_ld + doc] = acc[reg];
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// top-k by (value descending, index ascending): one workgroup per query.
+// MSB-first radix select over an order-preserving u64 image of the float64 value (12-bit digits,
+// LDS histogram), early exit once the survivors fit the LDS candidate buffer, then a bitonic
+// sort of the candidates.  Exact for ties (ordered gather of the lowest indices).
+// =============================================================================================
+constexpr int TOPK_CAP = 2048;
+constexpr int TOPK_MAX_K = 1024;
+
+__device__ __forceinline__ uint64_t order_key(double x) {
+    if (x == 0.0) x = 0.0;   // -0.0 and +0.0 compare equal in the reference's sort
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(uint64_t k) {
+    uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads); returns exclusive prefix, total in *total
+__device__ __forceinline__ int block_excl_scan(int x, int* scratch /*[17]*/, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) {
+            int t = scratch[w];
+            scratch[w] = run;
+            run += t;
+        }
+        scratch[16] = run;
+    }
+    __syncthreads();
+    const int res = scratch[wave] + incl - x;
+    *total = scratch[16];
+    __syncthreads();
+    return res;
+}
+
+__global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
+                                                    int32_t* __restrict__ ids_out, double* __restrict__ vals_out) {
+    __shared__ uint32_t hist[4096];
+    __shared__ uint64_t ckey[TOPK_CAP];
+    __shared__ uint32_t cid[TOPK_CAP];
+    __shared__ int scratch[17];
+    __shared__ int sh_digit, sh_need, sh_bin, sh_cnt;
+    const int tid = threadIdx.x;
+    const double* __restrict__ v = vals + (int64_t)blockIdx.x * n;
+    if ((int64_t)k > n) k = (int)n;
+    uint64_t prefix = 0;
+    int pbits = 0;
+    int need = k;            // how many of the keys matching `prefix` are still wanted
+    bool fits = false;
+    const int shifts[6] = {52, 40, 28, 16, 4, 0};
+    for (int pass = 0; pass < 6 && !fits; ++pass) {
+        const int shift = shifts[pass];
+        const int dbits = pass == 5 ? 4 : 12;
+        for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += 1024) {
+            const uint64_t key = order_key(v[i]);
+            if (pbits == 0 || (key >> (64 - pbits)) == prefix)
+                atomicAdd(&hist[(key >> shift) & ((1u << dbits) - 1)], 1u);
+        }
+        __syncthreads();
+        // walk bins from the top: thread t owns reversed bins 4t..4t+3
+        int own[4], s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            own[j] = (int)hist[4095 - (4 * tid + j)];
+            s += own[j];
+        }
+        int total;
+        int excl = block_excl_scan(s, scratch, &total);
+        if (excl < need && need <= excl + s) {
+            int run = excl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (run < need && need <= run + own[j]) {
+                    sh_digit = 4095 - (4 * tid + j);
+                    sh_need = need - run;
+                    sh_bin = own[j];
+                }
+                run += own[j];
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << dbits) | (uint64_t)(sh_digit & ((1 << dbits) - 1));
+        pbits += dbits;
+        const int above = k - sh_need;          // keys strictly above the chosen bin (all wanted)
+        need = sh_need;
+        fits = above + sh_bin <= TOPK_CAP;
+        __syncthreads();
+    }
+    const uint64_t low = pbits == 64 ? prefix : (prefix << (64 - pbits));
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    if (fits) {
+        for (int64_t i = tid; i < n; i += 1024) {
+            const uint64_t key = order_key(v[i]);
+            if (key >= low) {
+                const int slot = atomicAdd(&sh_cnt, 1);
+                ckey[slot] = key;
+                cid[slot] = (uint32_t)i;
+            }
+        }
+        __syncthreads();
+    } else {
+        // pbits == 64 and more than CAP exact ties at the threshold: everything above it, then the
+        // `need` lowest indices among the ties (ordered compaction).
+        for (int64_t i = tid; i < n; i += 1024) {
+            const uint64_t key = order_key(v[i]);
+            if (key > low) {
+                const int slot = atomicAdd(&sh_cnt, 1);
+                ckey[slot] = key;
+                cid[slot] = (uint32_t)i;
+            }
+        }
+        __syncthreads();
+        int base = sh_cnt, taken = 0;
+        for (int64_t i0 = 0; i0 < n && taken < need; i0 += 1024) {
+            const int64_t i = i0 + tid;
+            const int flag = (i < n && order_key(v[i]) == low) ? 1 : 0;
+            int total;
+            const int excl = block_excl_scan(flag, scratch, &total);
+            if (flag && taken + excl < need) {
+                ckey[base + taken + excl] = low;
+                cid[base + taken + excl] = (uint32_t)i;
+            }
+            taken += total;
+        }
+        __syncthreads();
+        if (tid == 0) sh_cnt = base + (taken < need ? taken : need);
+        __syncthreads();
+    }
+    const int cnt = sh_cnt;
+    int np2 = 64;
+    while (np2 < cnt) np2 <<= 1;
+    for (int i = cnt + tid; i < np2; i += 1024) {
+        ckey[i] = 0;
+        cid[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    // bitonic sort, "greater first": (key desc, id asc)
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (np2 >> 1); t += 1024) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const uint64_t ka = ckey[lo], kb = ckey[hi];
+                const uint32_t ia = cid[lo], ib = cid[hi];
+                const bool a_first = (ka > kb) || (ka == kb && ia < ib);
+                if (a_first != desc) {
+                    ckey[lo] = kb; ckey[hi] = ka;
+                    cid[lo] = ib; cid[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 1024) {
+        ids_out[(int64_t)blockIdx.x * k + i] = (int32_t)cid[i];
+        vals_out[(int64_t)blockIdx.x * k + i] = key_value(ckey[i]);
+    }
+}
+
+// Handle-less entry points (hipts_combine / hipts_topk) keep their small scratch here: one slot
+// per (device, purpose), intentionally never freed (freeing at static-destruction time would
+// race the HIP runtime's own teardown).  Callers are single-threaded per device by contract.
+DevBuf& scratch_buf(int device, int which) {
+    static DevBuf* bufs = new DevBuf[64 * 2];
+    return bufs[(device & 63) * 2 + which];
+}
+
+int copy_out(void* dst, const void* src_dev, size_t bytes, int memspace, hipStream_t s) {
+    if (!dst || bytes == 0) return HIPTS_OK;
+    if (memspace == HIPTS_DEVICE) {
+        if (dst != src_dev) HIPTS_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPTS_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        HIPTS_HIP(hipStreamSynchronize(s));
+    }
+    return HIPTS_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// Dense index handle
+// =============================================================================================
+struct hipts_index {
+    int device = 0;
+    int dim = 0;
+    int64_t len = 0, cap = 0;
+    DevBuf rows;      // float [cap][dim]
+    DevBuf ws_q, ws_out;
+};
+
+namespace {
+
+int launch_sim(const float* index, int64_t D, int K, const float* q_dev, int nq, float* out_dev, int64_t out_ld,
+               hipStream_t s) {
+    const size_t lds = (size_t)K * 32 * sizeof(float);
+    HIPTS_REQUIRE(lds <= 160 * 1024, "index dim %d too large for the query tile in LDS", K);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t ntiles = (D + 31) / 32;
+    int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * 4);
+    if (grid < 1) grid = 1;
+    for (int q0 = 0; q0 < nq; q0 += 32) {
+        const int n = std::min(32, nq - q0);
+        sim_mfma_kernel<<<grid, 256, lds, s>>>(index, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
+        HIPTS_LAUNCH_CHECK();
+    }
+    return HIPTS_OK;
+}
+
+int launch_bm25(hipts_bm25* h, const int32_t* qt_dev, const double* qw_dev, const int32_t* qp_dev, int nq, double* out_dev,
+                hipStream_t s) {
+    dim3 grid(ceil_div(h->D, 256), nq);
+    bm25_score_kernel<<<grid, 256, 0, s>>>(h->d_ptr.as<int64_t>(), h->d_term.as<int32_t>(), h->d_tf.as<int32_t>(),
+                                           h->d_dl.as<int32_t>(), h->d_idf.as<double>(), h->V, h->avgdl, h->D, qt_dev, qw_dev,
+                                           qp_dev, out_dev);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+// stage the CSR query description in the handle's workspace; returns device pointers
+int stage_queries(hipts_bm25* h, const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr, int nq,
+                  const int32_t** qt, const double** qw, const int32_t** qp, hipStream_t s) {
+    const int nt = q_ptr[nq];
+    HIPTS_REQUIRE(q_ptr[0] == 0 && nt >= 0, "q_ptr must start at 0 and be non-decreasing");
+    const size_t off_w = ((size_t)nt * 4 + 15) / 16 * 16;
+    const size_t off_p = off_w + (size_t)nt * 8;
+    const size_t total = off_p + (size_t)(nq + 1) * 4;
+    HIPTS_TRY(h->ws_q.reserve(total));
+    std::vector<char> host(total, 0);
+    memcpy(host.data(), q_terms, (size_t)nt * 4);
+    memcpy(host.data() + off_w, q_weights, (size_t)nt * 8);
+    memcpy(host.data() + off_p, q_ptr, (size_t)(nq + 1) * 4);
+    HIPTS_HIP(hipMemcpyAsync(h->ws_q.p, host.data(), total, hipMemcpyHostToDevice, s));
+    HIPTS_HIP(hipStreamSynchronize(s));   // `host` goes out of scope
+    *qt = h->ws_q.as<int32_t>();
+    *qw = reinterpret_cast<const double*>(h->ws_q.as<char>() + off_w);
+    *qp = reinterpret_cast<const int32_t*>(h->ws_q.as<char>() + off_p);
+    return HIPTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+int hipts_bm25_build(const int64_t* doc_ptr, const int32_t* term_ids, int64_t num_docs, int32_t vocab, int device,
+                     hipts_bm25_t** out) {
+    HIPTS_REQUIRE(doc_ptr && out && num_docs >= 0 && vocab >= 0, "hipts_bm25_build: bad arguments");
+    HIPTS_REQUIRE(term_ids || doc_ptr[num_docs] == 0, "hipts_bm25_build: term_ids is NULL");
+    HIPTS_TRY(use_device(device));
+    auto* h = new hipts_bm25();
+    h->device = device;
+    h->D = num_docs;
+    h->V = vocab;
+    h->h_ptr.assign(1, 0);
+    h->h_df.assign((size_t)vocab, 0);
+    h->h_dl.reserve((size_t)num_docs);
+    std::unordered_map<int32_t, int32_t> slot;   // term -> position in this document's list (dict insertion order)
+    int64_t sum_dl = 0;
+    for (int64_t d = 0; d < num_docs; ++d) {     // genmodel.py:57-73
+        slot.clear();
+        const size_t base = h->h_term.size();
+        int64_t dl = 0;
+        for (int64_t i = doc_ptr[d]; i < doc_ptr[d + 1]; ++i) {
+            const int32_t t = term_ids[i];
+            if (t < 0 || t >= vocab) continue;   // tag not in dictionary (:59)
+            ++dl;
+            auto it = slot.find(t);
+            if (it == slot.end()) {
+                slot.emplace(t, (int32_t)(h->h_term.size() - base));
+                h->h_term.push_back(t);
+                h->h_tf.push_back(1);
+            } else {
+                h->h_tf[base + it->second] += 1;
+            }
+        }
+        for (size_t i = base; i < h->h_term.size(); ++i) h->h_df[h->h_term[i]] += 1;
+        h->h_dl.push_back(dl);
+        sum_dl += dl;
+        h->h_ptr.push_back((int64_t)h->h_term.size());
+    }
+    h->nnz = (int64_t)h->h_term.size();
+    // np.mean of an int64 array: exact integer sum (< 2^53) then one division          genmodel.py:76
+    h->avgdl = num_docs > 0 ? (double)sum_dl / (double)num_docs : std::numeric_limits<double>::quiet_NaN();
+    h->h_idf.assign((size_t)vocab, 0.0);
+    for (int32_t t = 0; t < vocab; ++t) {        // genmodel.py:80-82
+        const int64_t df = h->h_df[t];
+        if (df > 0) h->h_idf[t] = std::log(1 + ((double)(num_docs - df) + 0.5) / ((double)df + 0.5));
+    }
+    std::vector<int32_t> dl32((size_t)num_docs);
+    for (int64_t d = 0; d < num_docs; ++d) dl32[d] = (int32_t)h->h_dl[d];
+    int st = HIPTS_OK;
+    if ((st = h->d_ptr.alloc((size_t)(num_docs + 1) * 8)) || (st = h->d_term.alloc((size_t)h->nnz * 4)) ||
+        (st = h->d_tf.alloc((size_t)h->nnz * 4)) || (st = h->d_dl.alloc((size_t)num_docs * 4)) ||
+        (st = h->d_idf.alloc((size_t)vocab * 8)) || (st = upload(h->d_ptr.p, h->h_ptr.data(), (size_t)(num_docs + 1) * 8)) ||
+        (st = upload(h->d_term.p, h->h_term.data(), (size_t)h->nnz * 4)) ||
+        (st = upload(h->d_tf.p, h->h_tf.data(), (size_t)h->nnz * 4)) || (st = upload(h->d_dl.p, dl32.data(), (size_t)num_docs * 4)) ||
+        (st = upload(h->d_idf.p, h->h_idf.data(), (size_t)vocab * 8))) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return HIPTS_OK;
+}
+
+int hipts_bm25_destroy(hipts_bm25_t* h) {
+    if (h) {
+        (void)hipSetDevice(h->device);
+        delete h;
+    }
+    return HIPTS_OK;
+}
+
+int hipts_bm25_info(const hipts_bm25_t* h, int64_t* num_docs, int64_t* nnz, int32_t* vocab, double* avgdl) {
+    HIPTS_REQUIRE(h, "null handle");
+    if (num_docs) *num_docs = h->D;
+    if (nnz) *nnz = h->nnz;
+    if (vocab) *vocab = h->V;
+    if (avgdl) *avgdl = h->avgdl;
+    return HIPTS_OK;
+}
+
+int hipts_bm25_export(const hipts_bm25_t* h, int64_t* csr_ptr, int32_t* csr_term, int32_t* csr_tf, int64_t* doc_len,
+                      int64_t* df, double* idf) {
+    HIPTS_REQUIRE(h, "null handle");
+    if (csr_ptr) memcpy(csr_ptr, h->h_ptr.data(), h->h_ptr.size() * 8);
+    if (csr_term) memcpy(csr_term, h->h_term.data(), h->h_term.size() * 4);
+    if (csr_tf) memcpy(csr_tf, h->h_tf.data(), h->h_tf.size() * 4);
+    if (doc_len) memcpy(doc_len, h->h_dl.data(), h->h_dl.size() * 8);
+    if (df) memcpy(df, h->h_df.data(), h->h_df.size() * 8);
+    if (idf) memcpy(idf, h->h_idf.data(), h->h_idf.size() * 8);
+    return HIPTS_OK;
+}
+
+int hipts_bm25_set_idf(hipts_bm25_t* h, const double* idf) {
+    HIPTS_REQUIRE(h && idf, "null argument");
+    HIPTS_TRY(use_device(h->device));
+    h->h_idf.assign(idf, idf + h->V);
+    return upload(h->d_idf.p, h->h_idf.data(), (size_t)h->V * 8);
+}
+
+int hipts_bm25_score(hipts_bm25_t* h, const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr, int nq,
+                     double* scores_out, int out_memspace, void* stream) {
+    HIPTS_REQUIRE(h && q_ptr && scores_out && nq >= 1, "hipts_bm25_score: bad arguments");
+    HIPTS_TRY(use_device(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int32_t* qt;
+    const double* qw;
+    const int32_t* qp;
+    HIPTS_TRY(stage_queries(h, q_terms, q_weights, q_ptr, nq, &qt, &qw, &qp, s));
+    double* out_dev = scores_out;
+    if (out_memspace != HIPTS_DEVICE) {
+        HIPTS_TRY(h->ws_scores.reserve((size_t)nq * h->D * 8));
+        out_dev = h->ws_scores.as<double>();
+    }
+    HIPTS_TRY(launch_bm25(h, qt, qw, qp, nq, out_dev, s));
+    return copy_out(scores_out, out_dev, (size_t)nq * h->D * 8, out_memspace, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+int hipts_index_create(int dim, int64_t capacity, int device, hipts_index_t** out) {
+    HIPTS_REQUIRE(out && dim >= 4 && dim % 4 == 0 && dim <= 1280, "hipts_index_create: dim must be a multiple of 4 and <= 1280");
+    HIPTS_TRY(use_device(device));
+    auto* h = new hipts_index();
+    h->device = device;
+    h->dim = dim;
+    h->cap = capacity > 0 ? capacity : 1024;
+    int st = h->rows.alloc((size_t)h->cap * dim * 4);
+    if (st) {
+        delete h;
+        return st;
+    }
+    *out = h;
+    return HIPTS_OK;
+}
+
+int hipts_index_destroy(hipts_index_t* h) {
+    if (h) {
+        (void)hipSetDevice(h->device);
+        delete h;
+    }
+    return HIPTS_OK;
+}
+
+int hipts_index_add(hipts_index_t* h, const float* rows, int64_t nrows, int rows_memspace) {
+    HIPTS_REQUIRE(h && (rows || nrows == 0) && nrows >= 0, "hipts_index_add: bad arguments");
+    HIPTS_TRY(use_device(h->device));
+    if (h->len + nrows > h->cap) {
+        int64_t ncap = std::max<int64_t>(h->cap * 2, h->len + nrows);
+        DevBuf nb;
+        HIPTS_TRY(nb.alloc((size_t)ncap * h->dim * 4));
+        HIPTS_HIP(hipMemcpy(nb.p, h->rows.p, (size_t)h->len * h->dim * 4, hipMemcpyDeviceToDevice));
+        std::swap(nb.p, h->rows.p);
+        std::swap(nb.bytes, h->rows.bytes);
+        h->cap = ncap;
+    }
+    HIPTS_HIP(hipMemcpy(h->rows.as<float>() + h->len * h->dim, rows, (size_t)nrows * h->dim * 4,
+                        rows_memspace == HIPTS_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    h->len += nrows;
+    return HIPTS_OK;
+}
+
+int hipts_index_len(const hipts_index_t* h, int64_t* nrows) {
+    HIPTS_REQUIRE(h && nrows, "null argument");
+    *nrows = h->len;
+    return HIPTS_OK;
+}
+
+int hipts_index_vector_by_id(const hipts_index_t* h, int64_t id, float* out_host) {
+    HIPTS_REQUIRE(h && out_host && id >= 0 && id < h->len, "hipts_index_vector_by_id: id out of range");
+    HIPTS_TRY(use_device(h->device));
+    HIPTS_HIP(hipMemcpy(out_host, h->rows.as<float>() + id * h->dim, (size_t)h->dim * 4, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}
+
+int hipts_index_data(const hipts_index_t* h, void** device_ptr) {
+    HIPTS_REQUIRE(h && device_ptr, "null argument");
+    *device_ptr = h->rows.p;
+    return HIPTS_OK;
+}
+
+int hipts_index_query(hipts_index_t* h, const float* queries, int queries_memspace, int nq, float* scores_out,
+                      int out_memspace, void* stream) {
+    HIPTS_REQUIRE(h && queries && scores_out && nq >= 1, "hipts_index_query: bad arguments");
+    HIPTS_REQUIRE(h->len > 0, "hipts_index_query: empty index");
+    HIPTS_TRY(use_device(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const float* q_dev = queries;
+    if (queries_memspace != HIPTS_DEVICE) {
+        HIPTS_TRY(h->ws_q.reserve((size_t)nq * h->dim * 4));
+        HIPTS_HIP(hipMemcpyAsync(h->ws_q.p, queries, (size_t)nq * h->dim * 4, hipMemcpyHostToDevice, s));
+        q_dev = h->ws_q.as<float>();
+    }
+    float* out_dev = scores_out;
+    if (out_memspace != HIPTS_DEVICE) {
+        HIPTS_TRY(h->ws_out.reserve((size_t)nq * h->len * 4));
+        out_dev = h->ws_out.as<float>();
+    }
+    HIPTS_TRY(launch_sim(h->rows.as<float>(), h->len, h->dim, q_dev, nq, out_dev, h->len, s));
+    return copy_out(scores_out, out_dev, (size_t)nq * h->len * 4, out_memspace, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+int hipts_combine(const double* a, const float* b, int nq, int64_t n, double wa, double wb, int norm_a, int norm_b,
+                  double* out, int device, void* stream) {
+    HIPTS_REQUIRE(a && b && out && nq >= 1 && n >= 1, "hipts_combine: bad arguments");
+    HIPTS_TRY(use_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf& maxbuf = scratch_buf(device, 0);
+    HIPTS_TRY(maxbuf.reserve((size_t)nq * 16));
+    double* ma = maxbuf.as<double>();
+    float* mb = reinterpret_cast<float*>(ma + nq);
+    if (norm_a) {
+        rowmax_kernel<double><<<nq, 1024, 0, s>>>(a, n, ma);
+        HIPTS_LAUNCH_CHECK();
+    }
+    if (norm_b) {
+        rowmax_kernel<float><<<nq, 1024, 0, s>>>(b, n, mb);
+        HIPTS_LAUNCH_CHECK();
+    }
+    dim3 grid(ceil_div(n, 256), nq);
+    combine_kernel<<<grid, 256, 0, s>>>(a, b, n, wa, (float)wb, norm_a ? ma : nullptr, norm_b ? mb : nullptr, out);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+int hipts_topk(const double* vals, int nq, int64_t n, int k, int32_t* ids_out, double* vals_out, int out_memspace,
+               int device, void* stream) {
+    HIPTS_REQUIRE(vals && ids_out && vals_out && nq >= 1 && n >= 1, "hipts_topk: bad arguments");
+    HIPTS_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "hipts_topk: k must be in [1, %d]", TOPK_MAX_K);
+    HIPTS_REQUIRE(n < (1ll << 32), "hipts_topk: n too large");
+    HIPTS_TRY(use_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    const int kk = (int)std::min<int64_t>(k, n);
+    if (out_memspace == HIPTS_DEVICE) {
+        HIPTS_REQUIRE(kk == k, "hipts_topk: k > n needs host outputs");
+        topk_kernel<<<nq, 1024, 0, s>>>(vals, n, k, ids_out, vals_out);
+        HIPTS_LAUNCH_CHECK();
+        return HIPTS_OK;
+    }
+    DevBuf& obuf = scratch_buf(device, 1);
+    HIPTS_TRY(obuf.reserve((size_t)nq * kk * 12 + 64));
+    double* ov = obuf.as<double>();
+    int32_t* oi = reinterpret_cast<int32_t*>(ov + (size_t)nq * kk);
+    topk_kernel<<<nq, 1024, 0, s>>>(vals, n, kk, oi, ov);
+    HIPTS_LAUNCH_CHECK();
+    std::vector<int32_t> hi((size_t)nq * kk);
+    std::vector<double> hv((size_t)nq * kk);
+    HIPTS_HIP(hipMemcpyAsync(hi.data(), oi, hi.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPTS_HIP(hipMemcpyAsync(hv.data(), ov, hv.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPTS_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < nq; ++q)
+        for (int i = 0; i < k; ++i) {
+            ids_out[(size_t)q * k + i] = i < kk ? hi[(size_t)q * kk + i] : -1;
+            vals_out[(size_t)q * k + i] = i < kk ? hv[(size_t)q * kk + i] : -INFINITY;
+        }
+    return HIPTS_OK;
+}
+
+int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights,
+                 const int32_t* q_ptr, const float* q_vectors, int nq, double w_bm25, double w_sim, int k, int32_t* ids_out,
+                 double* vals_out, double* final_out_device, void* stream) {
+    HIPTS_REQUIRE(bm25 && index && q_ptr && q_vectors && ids_out && vals_out && nq >= 1, "hipts_search: bad arguments");
+    HIPTS_REQUIRE(bm25->device == index->device, "hipts_search: handles live on different devices");
+    HIPTS_REQUIRE(bm25->D == index->len, "hipts_search: BM25 corpus has %lld documents, index has %lld rows",
+                  (long long)bm25->D, (long long)index->len);
+    HIPTS_TRY(use_device(bm25->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t D = bm25->D;
+    const int32_t* qt;
+    const double* qw;
+    const int32_t* qp;
+    HIPTS_TRY(stage_queries(bm25, q_terms, q_weights, q_ptr, nq, &qt, &qw, &qp, s));
+    HIPTS_TRY(bm25->ws_scores.reserve((size_t)nq * D * 8));
+    HIPTS_TRY(bm25->ws_sims.reserve((size_t)nq * D * 4));
+    HIPTS_TRY(index->ws_q.reserve((size_t)nq * index->dim * 4));
+    HIPTS_HIP(hipMemcpyAsync(index->ws_q.p, q_vectors, (size_t)nq * index->dim * 4, hipMemcpyHostToDevice, s));
+    double* final_dev = final_out_device;
+    if (!final_dev) {
+        HIPTS_TRY(bm25->ws_final.reserve((size_t)nq * D * 8));
+        final_dev = bm25->ws_final.as<double>();
+    }
+    HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s));
+    HIPTS_TRY(launch_sim(index->rows.as<float>(), D, index->dim, index->ws_q.as<float>(), nq, bm25->ws_sims.as<float>(), D, s));
+    HIPTS_TRY(hipts_combine(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), nq, D, w_bm25, w_sim, 1, 1, final_dev,
+                            bm25->device, stream));
+    return hipts_topk(final_dev, nq, D, k, ids_out, vals_out, HIPTS_HOST, bm25->device, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,524 @@
+// vit.hip -- ViT tagger forward: handle, checkpoint upload, small kernels, orchestration.
+//
+// Replaces `model.forward(batched_tensor)` + `F.sigmoid` of tagging.py:174-176 for the contract
+// model (ViT-B/16 @448, no class token, mean pool).  Kernel sequence per forward:
+//   patchify (ToTensor + Normalize + BGR flip fused, tagging.py:241-243) -> GEMM(+bias+pos) ->
+//   depth x [ LN -> GEMM(QK) + GEMM(V^T) -> attention -> GEMM(+bias+residual) ->
+//             LN -> GEMM(+bias, GELU) -> GEMM(+bias+residual) ] ->
+//   final LN + token mean (partial sums) -> finalize (hi/lo bf16 split) -> head GEMM (+sigmoid).
+// The residual stream, LN statistics, softmax and every accumulation are float32; only MFMA
+// operands are bf16.
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "vit_internal.h"
+
+using namespace hipts;
+
+namespace {
+
+struct Layer {
+    DevBuf ln1_g, ln1_b, ln2_g, ln2_b;
+    DevBuf qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b;
+};
+
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct hipts_vit {
+    int device = 0;
+    hipts_vit_config_t cfg{};
+    int grid = 0, tokens = 0, tokens_pad = 0, patch_k = 0;
+    std::vector<Layer> layers;
+    DevBuf patch_w, patch_b, pos, norm_g, norm_b, head_w, head_b;
+    std::vector<std::string> missing;   // tensors not yet set
+    // workspace (sized for cfg.max_batch)
+    DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs;
+    int pool_splits = 1;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// patch matrix: A0[m][(ky*P + kx)*3 + c] = bf16(normalised pixel), c in memory (RGB) order; the
+// BGR flip of tagging.py:243 is folded into the weight permutation at upload time.
+// One thread per (token, ky): reads P*3 contiguous bytes, writes P*3 contiguous bf16.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, bf16_t* __restrict__ a0, int batch,
+                                                          int size, int P, int grid) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * grid * grid * P;
+    if (idx >= total) return;
+    const int ky = (int)(idx % P);
+    const int64_t tok = idx / P;
+    const int px = (int)(tok % grid), py = (int)((tok / grid) % grid), b = (int)(tok / ((int64_t)grid * grid));
+    const uint8_t* src = img + (((int64_t)b * size + (py * P + ky)) * size + px * P) * 3;
+    bf16_t* dst = a0 + tok * (int64_t)(P * P * 3) + ky * P * 3;
+    for (int i = 0; i < P * 3; ++i) {
+        // ToTensor: u8 -> float32 / 255 ; Normalize(mean .5, std .5): (x - .5) / .5   (float32, torch op order)
+        float v = (float)src[i] / 255.0f;
+        v = (v - 0.5f) / 0.5f;
+        dst[i] = (bf16_t)v;
+    }
+}
+
+// x: float32 [B][3][S][S] (BGR, already normalised).  Channel c of the patch matrix (memory/RGB
+// order) is model channel 2 - c.
+__global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ a0, int batch,
+                                                           int size, int P, int grid) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * grid * grid * P;
+    if (idx >= total) return;
+    const int ky = (int)(idx % P);
+    const int64_t tok = idx / P;
+    const int px = (int)(tok % grid), py = (int)((tok / grid) % grid), b = (int)(tok / ((int64_t)grid * grid));
+    bf16_t* dst = a0 + tok * (int64_t)(P * P * 3) + ky * P * 3;
+    for (int c = 0; c < 3; ++c) {
+        const float* src = x + (((int64_t)b * 3 + (2 - c)) * size + (py * P + ky)) * size + px * P;
+        for (int kx = 0; kx < P; ++kx) dst[kx * 3 + c] = (bf16_t)src[kx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (eps inside the sqrt, biased variance -- torch F.layer_norm), one
+// wave per row, float4 loads, two-pass statistics in registers, bf16 output.  D % 4 == 0, D <= 1024.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ bta, bf16_t* __restrict__ out, int64_t rows,
+                                                        int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i < nvec) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    const float4* gr = reinterpret_cast<const float4*>(g);
+    const float4* br = reinterpret_cast<const float4*>(bta);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            const float4 gg = gr[c], bb = br[c];
+            bf16x4 o;
+            o[0] = (bf16_t)((v[i].x - mean) * rstd * gg.x + bb.x);
+            o[1] = (bf16_t)((v[i].y - mean) * rstd * gg.y + bb.y);
+            o[2] = (bf16_t)((v[i].z - mean) * rstd * gg.z + bb.z);
+            o[3] = (bf16_t)((v[i].w - mean) * rstd * gg.w + bb.w);
+            *reinterpret_cast<bf16x4*>(out + row * D + 4 * c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// final norm + mean pool.  grid (splits, batch); each workgroup sums, over its share of the
+// image's tokens, either (x - mean) * rstd (norm-then-pool: affine applied after the mean, it is
+// linear) or x itself (pool-then-norm).  Partials [batch][splits][D] float32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int tokens,
+                                                           int D, float eps, int normalize, int splits) {
+    __shared__ float red[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int per = (tokens + splits - 1) / splits;
+    const int t0 = split * per, t1 = min(tokens, t0 + per);
+    const int nvec = D >> 2;
+    float4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + ((int64_t)b * tokens + t) * D);
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        float mean = 0.f, rstd = 1.f;
+        if (normalize) {
+            mean = wave_sum(s) / (float)D;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lane + 64 * i < nvec) {
+                    const float a = v[i].x - mean, bq = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                    ss += (a * a + bq * bq) + (c * c + d * d);
+                }
+            rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i].x += (v[i].x - mean) * rstd;
+            acc[i].y += (v[i].y - mean) * rstd;
+            acc[i].z += (v[i].z - mean) * rstd;
+            acc[i].w += (v[i].w - mean) * rstd;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            red[wave][4 * c + 0] = acc[i].x;
+            red[wave][4 * c + 1] = acc[i].y;
+            red[wave][4 * c + 2] = acc[i].z;
+            red[wave][4 * c + 3] = acc[i].w;
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+        part[((int64_t)b * splits + split) * D + d] = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+}
+
+// Sum the partials, apply the affine (or the LayerNorm for pool-then-norm), and split the float32
+// feature into bf16 hi + bf16 lo so the head GEMM (K = 2D against [W | W]) keeps ~16 bits of the
+// feature: out[b][0..D) = hi, out[b][D..2D) = lo.   One workgroup per image.
+__global__ __launch_bounds__(256) void pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ g,
+                                                            const float* __restrict__ bta, bf16_t* __restrict__ out, int tokens,
+                                                            int D, float eps, int normalize_after, int splits) {
+    __shared__ float feat[1024];
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float a = 0.f;
+        for (int sp = 0; sp < splits; ++sp) a += part[((int64_t)b * splits + sp) * D + d];
+        a = a / (float)tokens;
+        feat[d] = a;
+        s += a;
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (normalize_after) {
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D;
+        float ss = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float c = feat[d] - mean;
+            ss += c * c;
+        }
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = ss;
+        __syncthreads();
+        rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)D + eps);
+    }
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float f = (feat[d] - mean) * rstd * g[d] + bta[d];
+        const bf16_t hi = (bf16_t)f;
+        const bf16_t lo = (bf16_t)(f - (float)hi);
+        out[(int64_t)b * 2 * D + d] = hi;
+        out[(int64_t)b * 2 * D + D + d] = lo;
+    }
+}
+
+int set_f32(DevBuf& buf, const float* data, size_t n) {
+    HIPTS_TRY(buf.alloc(n * 4));
+    return upload(buf.p, data, n * 4);
+}
+
+// rows x cols float32 -> bf16, rows zero-padded to rows_pad
+int set_bf16_matrix(DevBuf& buf, const float* data, int rows, int cols, int rows_pad) {
+    std::vector<uint16_t> h((size_t)rows_pad * cols, 0);
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_bf16_rne(data[i]);
+    HIPTS_TRY(buf.alloc(h.size() * 2));
+    return upload(buf.p, h.data(), h.size() * 2);
+}
+
+bool erase_missing(hipts_vit* h, const std::string& key) {
+    for (size_t i = 0; i < h->missing.size(); ++i)
+        if (h->missing[i] == key) {
+            h->missing.erase(h->missing.begin() + i);
+            return true;
+        }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** out) {
+    HIPTS_REQUIRE(cfg && out, "hipts_vit_create: null argument");
+    HIPTS_REQUIRE(cfg->patch >= 4 && cfg->image_size % cfg->patch == 0, "image_size must be a multiple of patch");
+    HIPTS_REQUIRE(cfg->heads >= 1 && cfg->dim == cfg->heads * 64, "head dim must be 64 (dim = heads * 64)");
+    HIPTS_REQUIRE(cfg->dim % 64 == 0 && cfg->dim <= 1024, "dim must be a multiple of 64, <= 1024");
+    HIPTS_REQUIRE(cfg->mlp_dim % 64 == 0, "mlp_dim must be a multiple of 64");
+    HIPTS_REQUIRE((cfg->patch * cfg->patch * 3) % 64 == 0, "patch*patch*3 must be a multiple of 64");
+    HIPTS_REQUIRE(cfg->depth >= 1 && cfg->num_classes >= 1 && cfg->max_batch >= 1, "bad depth / classes / max_batch");
+    const int grid = cfg->image_size / cfg->patch;
+    HIPTS_REQUIRE((grid * grid) % 4 == 0, "token count must be a multiple of 4");
+    HIPTS_TRY(use_device(device));
+    auto* h = new hipts_vit();
+    h->device = device;
+    h->cfg = *cfg;
+    h->grid = grid;
+    h->tokens = grid * grid;
+    h->tokens_pad = round_up(h->tokens, 64);
+    h->patch_k = cfg->patch * cfg->patch * 3;
+    h->layers.resize(cfg->depth);
+    h->missing = {"patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed", "norm.weight", "norm.bias",
+                  "head.weight", "head.bias"};
+    for (int i = 0; i < cfg->depth; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        for (const char* s : {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                              "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                              "mlp.fc2.weight", "mlp.fc2.bias"})
+            h->missing.push_back(p + s);
+    }
+    const size_t B = cfg->max_batch, M = B * h->tokens, D = cfg->dim;
+    const size_t qkv_elems = B * cfg->heads * (size_t)h->tokens_pad * 64;
+    h->pool_splits = h->tokens >= 64 ? 8 : 1;
+    int st = HIPTS_OK;
+    if ((st = h->a0.alloc(M * h->patch_k * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
+        (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->vT.alloc(qkv_elems * 2)) ||
+        (st = h->att.alloc(M * D * 2)) || (st = h->hmid.alloc(M * (size_t)cfg->mlp_dim * 2)) ||
+        (st = h->pool_part.alloc(B * h->pool_splits * D * 4)) || (st = h->pooled2.alloc(B * 2 * D * 2)) ||
+        (st = h->logits.alloc(B * (size_t)cfg->num_classes * 4)) || (st = h->probs.alloc(B * (size_t)cfg->num_classes * 4))) {
+        delete h;
+        return st;
+    }
+    // padded token rows of q / k / vT must be finite (zero): cleared once, never written afterwards
+    hipError_t e;
+    if ((e = hipMemset(h->q.p, 0, h->q.bytes)) != hipSuccess || (e = hipMemset(h->k.p, 0, h->k.bytes)) != hipSuccess ||
+        (e = hipMemset(h->vT.p, 0, h->vT.bytes)) != hipSuccess) {
+        delete h;
+        return set_error(HIPTS_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return HIPTS_OK;
+}
+
+int hipts_vit_destroy(hipts_vit_t* h) {
+    if (h) {
+        (void)hipSetDevice(h->device);
+        delete h;
+    }
+    return HIPTS_OK;
+}
+
+int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, int64_t numel) {
+    HIPTS_REQUIRE(h && key_c && data, "hipts_vit_set_tensor: null argument");
+    HIPTS_TRY(use_device(h->device));
+    const std::string key(key_c);
+    const auto& c = h->cfg;
+    const int D = c.dim, P = c.patch, Mlp = c.mlp_dim, C = c.num_classes;
+#define EXPECT(n)                                                                                                      \
+    HIPTS_REQUIRE(numel == (int64_t)(n), "tensor %s: expected %lld elements, got %lld", key_c, (long long)(n),         \
+                  (long long)numel)
+    int st = HIPTS_ERR_INVALID;
+    if (key == "patch_embed.proj.weight") {
+        EXPECT((int64_t)D * 3 * P * P);
+        // [D][3][P][P] (model channel order = BGR) -> [D][(ky*P + kx)*3 + c_rgb], model channel 2 - c_rgb
+        std::vector<float> perm((size_t)D * h->patch_k);
+        for (int n = 0; n < D; ++n)
+            for (int ky = 0; ky < P; ++ky)
+                for (int kx = 0; kx < P; ++kx)
+                    for (int cr = 0; cr < 3; ++cr)
+                        perm[(size_t)n * h->patch_k + (ky * P + kx) * 3 + cr] = data[(((size_t)n * 3 + (2 - cr)) * P + ky) * P + kx];
+        st = set_bf16_matrix(h->patch_w, perm.data(), D, h->patch_k, round_up(D, 256));
+    } else if (key == "patch_embed.proj.bias") {
+        EXPECT(D);
+        st = set_f32(h->patch_b, data, D);
+    } else if (key == "pos_embed") {
+        EXPECT((int64_t)h->tokens * D);
+        st = set_f32(h->pos, data, (size_t)h->tokens * D);
+    } else if (key == "norm.weight") {
+        EXPECT(D);
+        st = set_f32(h->norm_g, data, D);
+    } else if (key == "norm.bias") {
+        EXPECT(D);
+        st = set_f32(h->norm_b, data, D);
+    } else if (key == "head.weight") {
+        EXPECT((int64_t)C * D);
+        // [C][D] -> [C][2D] = [W | W]: multiplies the (hi | lo) split of the pooled feature
+        std::vector<float> dup((size_t)C * 2 * D);
+        for (int n = 0; n < C; ++n) {
+            memcpy(&dup[(size_t)n * 2 * D], &data[(size_t)n * D], (size_t)D * 4);
+            memcpy(&dup[(size_t)n * 2 * D + D], &data[(size_t)n * D], (size_t)D * 4);
+        }
+        st = set_bf16_matrix(h->head_w, dup.data(), C, 2 * D, round_up(C, 256));
+    } else if (key == "head.bias") {
+        EXPECT(C);
+        st = set_f32(h->head_b, data, C);
+    } else if (key.rfind("blocks.", 0) == 0) {
+        const size_t dot = key.find('.', 7);
+        HIPTS_REQUIRE(dot != std::string::npos, "unknown tensor key %s", key_c);
+        const int li = atoi(key.substr(7, dot - 7).c_str());
+        HIPTS_REQUIRE(li >= 0 && li < c.depth, "tensor %s: block index out of range", key_c);
+        Layer& L = h->layers[li];
+        const std::string sub = key.substr(dot + 1);
+        if (sub == "norm1.weight") { EXPECT(D); st = set_f32(L.ln1_g, data, D); }
+        else if (sub == "norm1.bias") { EXPECT(D); st = set_f32(L.ln1_b, data, D); }
+        else if (sub == "norm2.weight") { EXPECT(D); st = set_f32(L.ln2_g, data, D); }
+        else if (sub == "norm2.bias") { EXPECT(D); st = set_f32(L.ln2_b, data, D); }
+        else if (sub == "attn.qkv.weight") { EXPECT((int64_t)3 * D * D); st = set_bf16_matrix(L.qkv_w, data, 3 * D, D, round_up(2 * D, 256) + round_up(D, 256) + 256); }
+        else if (sub == "attn.qkv.bias") { EXPECT(3 * D); st = set_f32(L.qkv_b, data, 3 * D); }
+        else if (sub == "attn.proj.weight") { EXPECT((int64_t)D * D); st = set_bf16_matrix(L.proj_w, data, D, D, round_up(D, 256)); }
+        else if (sub == "attn.proj.bias") { EXPECT(D); st = set_f32(L.proj_b, data, D); }
+        else if (sub == "mlp.fc1.weight") { EXPECT((int64_t)Mlp * D); st = set_bf16_matrix(L.fc1_w, data, Mlp, D, round_up(Mlp, 256)); }
+        else if (sub == "mlp.fc1.bias") { EXPECT(Mlp); st = set_f32(L.fc1_b, data, Mlp); }
+        else if (sub == "mlp.fc2.weight") { EXPECT((int64_t)D * Mlp); st = set_bf16_matrix(L.fc2_w, data, D, Mlp, round_up(D, 256)); }
+        else if (sub == "mlp.fc2.bias") { EXPECT(D); st = set_f32(L.fc2_b, data, D); }
+        else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+    } else {
+        return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+    }
+#undef EXPECT
+    if (st == HIPTS_OK) erase_missing(h, key);
+    return st;
+}
+
+int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops) {
+    HIPTS_REQUIRE(h && flops, "null argument");
+    const double N = h->tokens, D = h->cfg.dim, Ml = h->cfg.mlp_dim, C = h->cfg.num_classes, Kp = h->patch_k;
+    const double per_layer = 2 * N * D * 3 * D + 2 * 2 * N * N * D + 2 * N * D * D + 2 * 2 * N * D * Ml;
+    *flops = 2 * N * Kp * D + h->cfg.depth * per_layer + 2 * D * C;
+    return HIPTS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u8, int batch, float* logits_out,
+                     float* probs_out, int out_memspace, hipStream_t s) {
+    HIPTS_REQUIRE(h && input && batch >= 1, "hipts_vit_forward: bad arguments");
+    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
+    if (!h->missing.empty())
+        return set_error(HIPTS_ERR_STATE, "hipts_vit_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
+                         h->missing[0].c_str());
+    HIPTS_TRY(use_device(h->device));
+    const auto& c = h->cfg;
+    const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
+    const int M = batch * T;
+
+    const void* in_dev = input;
+    if (in_memspace != HIPTS_DEVICE) {
+        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
+        HIPTS_TRY(h->img_in.reserve(bytes));
+        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
+        in_dev = h->img_in.p;
+    }
+    {
+        const int64_t total = (int64_t)M * P;
+        const int blocks = ceil_div(total, 256);
+        if (is_u8)
+            patchify_u8_kernel<<<blocks, 256, 0, s>>>((const uint8_t*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+        else
+            patchify_f32_kernel<<<blocks, 256, 0, s>>>((const float*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+        HIPTS_LAUNCH_CHECK();
+    }
+    GemmArgs g;
+    // patch embedding: x = A0 W^T + b + pos
+    g = GemmArgs{};
+    g.A = h->a0.as<bf16_t>(); g.W = h->patch_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->patch_k;
+    g.bias = h->patch_b.as<float>(); g.out_f32 = h->x.as<float>(); g.pos = h->pos.as<float>(); g.tokens = T;
+    HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+
+    const int ln_blocks = ceil_div(M, 4);
+    for (int li = 0; li < c.depth; ++li) {
+        Layer& L = h->layers[li];
+        layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+        HIPTS_LAUNCH_CHECK();
+        // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled by head_dim^-0.5 = 0.125 (exact)
+        g = GemmArgs{};
+        g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
+        g.bias = L.qkv_b.as<float>(); g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
+        g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D; g.qscale = 0.125f;
+        HIPTS_TRY(launch_gemm(EPI_QK, g, s));
+        // v, written transposed
+        g = GemmArgs{};
+        g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
+        g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = h->vT.as<bf16_t>();
+        g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        HIPTS_TRY(launch_gemm(EPI_VT, g, s));
+        HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, s));
+        // x += att Wp^T + b
+        g = GemmArgs{};
+        g.A = h->att.as<bf16_t>(); g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
+        g.bias = L.proj_b.as<float>(); g.out_f32 = h->x.as<float>();
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+        HIPTS_LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.A = h->xn.as<bf16_t>(); g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
+        g.bias = L.fc1_b.as<float>(); g.out_bf16 = h->hmid.as<bf16_t>(); g.gelu_tanh = c.gelu_tanh;
+        HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
+        g = GemmArgs{};
+        g.A = h->hmid.as<bf16_t>(); g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
+        g.bias = L.fc2_b.as<float>(); g.out_f32 = h->x.as<float>();
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+    }
+    // final norm + mean pool (+ hi/lo split)
+    pool_partial_kernel<<<dim3(h->pool_splits, batch), 256, 0, s>>>(h->x.as<float>(), h->pool_part.as<float>(), T, D, c.ln_eps,
+                                                                   c.pool_then_norm ? 0 : 1, h->pool_splits);
+    HIPTS_LAUNCH_CHECK();
+    pool_finalize_kernel<<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
+                                               h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
+    HIPTS_LAUNCH_CHECK();
+    // head (+ sigmoid, tagging.py:176)
+    const bool dev_out = out_memspace == HIPTS_DEVICE;
+    float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
+    float* pr = (dev_out && probs_out) ? probs_out : h->probs.as<float>();
+    g = GemmArgs{};
+    g.A = h->pooled2.as<bf16_t>(); g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
+    g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = (probs_out || !dev_out) ? pr : nullptr;
+    HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
+    if (!dev_out) {
+        const size_t bytes = (size_t)batch * c.num_classes * 4;
+        if (logits_out) HIPTS_HIP(hipMemcpyAsync(logits_out, lg, bytes, hipMemcpyDeviceToHost, s));
+        if (probs_out) HIPTS_HIP(hipMemcpyAsync(probs_out, pr, bytes, hipMemcpyDeviceToHost, s));
+        HIPTS_HIP(hipStreamSynchronize(s));
+    }
+    return HIPTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipts_vit_forward_u8(hipts_vit_t* h, const uint8_t* images, int images_memspace, int batch, float* logits_out,
+                         float* probs_out, int out_memspace, void* stream) {
+    return vit_forward_impl(h, images, images_memspace, true, batch, logits_out, probs_out, out_memspace, (hipStream_t)stream);
+}
+
+int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int batch, float* logits_out, float* probs_out,
+                          int out_memspace, void* stream) {
+    return vit_forward_impl(h, x, x_memspace, false, batch, logits_out, probs_out, out_memspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+"""ctypes binding of libhip_tagsearch.so (the C ABI declared in include/hip_tagsearch.h).
+
+There is no CPU fallback: if the shared library is missing, or a compute entry point reports
+an error (for instance "no HIP device"), this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+HOST = 0
+DEVICE = 1
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "libhip_tagsearch.so")
+
+
+class HipTagSearchError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__("libhip_tagsearch status %d: %s" % (status, message))
+        self.status = status
+
+
+class VitConfig(ctypes.Structure):
+    _fields_ = [("image_size", c_int32), ("patch", c_int32), ("dim", c_int32), ("depth", c_int32),
+                ("heads", c_int32), ("mlp_dim", c_int32), ("num_classes", c_int32), ("ln_eps", c_float),
+                ("gelu_tanh", c_int32), ("pool_then_norm", c_int32), ("max_batch", c_int32)]
+
+
+# name -> (argtypes); every function returns int status unless listed in _PLAIN
+_SIGNATURES = {
+    "hipts_abi_version": [],
+    "hipts_last_error": [c_char_p, c_size_t],
+    "hipts_device_count": [POINTER(c_int)],
+    "hipts_vit_create": [POINTER(VitConfig), c_int, POINTER(c_void_p)],
+    "hipts_vit_destroy": [c_void_p],
+    "hipts_vit_set_tensor": [c_void_p, c_char_p, c_void_p, c_int64],
+    "hipts_vit_forward_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "hipts_vit_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "hipts_vit_flops_per_image": [c_void_p, POINTER(c_double)],
+    "hipts_tagsel_create": [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)],
+    "hipts_tagsel_destroy": [c_void_p],
+    "hipts_tagsel_run": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int,
+                         c_void_p, c_int, c_void_p],
+    "hipts_bm25_build": [c_void_p, c_void_p, c_int64, c_int32, c_int, POINTER(c_void_p)],
+    "hipts_bm25_destroy": [c_void_p],
+    "hipts_bm25_info": [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_double)],
+    "hipts_bm25_export": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "hipts_bm25_set_idf": [c_void_p, c_void_p],
+    "hipts_bm25_score": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "hipts_index_create": [c_int, c_int64, c_int, POINTER(c_void_p)],
+    "hipts_index_destroy": [c_void_p],
+    "hipts_index_add": [c_void_p, c_void_p, c_int64, c_int],
+    "hipts_index_len": [c_void_p, POINTER(c_int64)],
+    "hipts_index_vector_by_id": [c_void_p, c_int64, c_void_p],
+    "hipts_index_data": [c_void_p, POINTER(c_void_p)],
+    "hipts_index_query": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
+    "hipts_combine": [c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_int, c_int, c_void_p, c_int, c_void_p],
+    "hipts_topk": [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
+                     c_void_p, c_void_p, c_void_p, c_void_p],
+    "hipts_d2v_create": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_int, POINTER(c_void_p)],
+    "hipts_d2v_destroy": [c_void_p],
+    "hipts_d2v_infer": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p,
+                        c_int, c_void_p],
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libhip_tagsearch.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C anime-illust-image-searcher_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the header and the library disagree
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(1024)
+    load().hipts_last_error(buf, 1024)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status: int):
+    if status != 0:
+        raise HipTagSearchError(status, last_error())
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args))
+
+
+def device_count() -> int:
+    n = c_int(0)
+    call("hipts_device_count", ctypes.byref(n))
+    return n.value
+
+
+def ptr(x):
+    """void* of a numpy array (host), a torch tensor (host or device), an int address or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+        return x.ctypes.data_as(c_void_p)
+    if isinstance(x, int):
+        return c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous(), "tensor must be contiguous"
+        return c_void_p(x.data_ptr())
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+def memspace_of(x) -> int:
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
+        return DEVICE if x.is_cuda else HOST
+    return HOST
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream as void* (None = null stream when torch is absent
+    or has no device)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return c_void_p(torch.cuda.current_stream().cuda_stream)
+    except Exception:
+        pass
+    return None

@@ -1,0 +1,222 @@
+"""Query function: host-side mirror of webui.py:63-390 over the device kernels.
+
+  filter_searched_result                webui.py:63-80
+  normalize_and_apply_weight_doc2vec    webui.py:82-117
+  find_similar_documents                webui.py:345-390   (same name / arguments / return value)
+  get_doc2vec_based_reranked_scores     webui.py:189-253
+
+The reference keeps model, index, dictionary and the BM25 statistics in module globals that
+`load_model()` fills (webui.py:649-689); here they live in a SearchEngine, and the module-level
+functions of the same names operate on the engine installed with `set_engine()`.
+Scoring (BM25, index product, normalise, combine, top-k) runs in libhip_tagsearch.so; parsing,
+the 10-document pseudo-relevance bookkeeping and the gap filter are host logic.
+"""
+import ctypes
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import c_double, c_int64
+from .bm25 import BM25Index
+from .d2v import Doc2VecInference
+from .index import Similarity
+
+BM25_WEIGHT: float = 0.5               # webui.py:51
+DOC2VEC_WEIGHT: float = 0.5            # webui.py:52
+ORIGINAL_SCORE_WEIGHT: float = 0.7     # webui.py:55
+RERANKED_SCORE_WEIGHT: float = 0.3     # webui.py:56
+DIFF_FILTER_THRESH = 1e-6              # webui.py:58
+REQUIRE_TAG_MAGIC_NUMBER = 1000        # webui.py:60
+TOPK_MAX = 1024                        # hipts_topk limit
+
+
+def filter_searched_result(sorted_scores: List[Tuple[int, float]]) -> List[Tuple[int, float]]:
+    """webui.py:63-80: cut the ranked list at the second place where consecutive scores differ by
+    less than 1e-6 (equal scores do not count), drop non-positive scores, divide by the maximum."""
+    scores_ndarr = np.array([s for _, s in sorted_scores])
+    diff_arr = scores_ndarr[:-1] - scores_ndarr[1:]
+    diff_arr = np.where(diff_arr == 0, np.inf, diff_arr)
+    t = len(sorted_scores)
+    found_points = np.where(diff_arr < DIFF_FILTER_THRESH)[0]
+    if len(found_points) == 1:
+        t = found_points[0]
+    elif len(found_points) >= 2:
+        t = found_points[1]
+    max_val = scores_ndarr.max()
+    return [(sorted_scores[i][0], sorted_scores[i][1] / float(max_val)) for i in range(int(t)) if sorted_scores[i][1] > 0]
+
+
+def _split_weight(tag: str):
+    sp = tag.split(":")
+    if len(sp) >= 2 and (sp[-1].startswith("+") or sp[-1].startswith("-") or sp[-1].isdigit()):
+        return ":".join(sp[:-1]), sp[-1]
+    return ":".join(sp), None
+
+
+class SearchEngine:
+    def __init__(self, model: Doc2VecInference, index: Similarity, token2id: Dict[str, int], bm25: BM25Index,
+                 image_files_name_tags_arr: Sequence[str], search_mode: str = "normal", compat_rerank: bool = False):
+        self.model, self.index, self.token2id, self.bm25 = model, index, token2id, bm25
+        self.image_files_name_tags_arr = list(image_files_name_tags_arr)
+        self.search_mode = search_mode
+        self.compat_rerank = compat_rerank
+
+    # ---- webui.py:82-117 ------------------------------------------------------------------------
+    def normalize_and_apply_weight_doc2vec(self, new_doc: str) -> np.ndarray:
+        tag_and_weight: List[Tuple[str, int]] = []
+        all_weight = 0
+        for tag in new_doc.split(" "):
+            name, w = _split_weight(tag)
+            name = name.replace("\\(", "(").replace("\\)", ")").replace("(", "\\(").replace(")", "\\)")   # :92-98
+            wi = int(w) if w is not None else 1
+            tag_and_weight.append((name, wi))
+            all_weight += wi
+        if all_weight == 0:
+            all_weight = 1
+        vecs = self.model.infer_vectors([[t] for t, _ in tag_and_weight])            # :106, batched
+        got = np.zeros(self.model.vector_size)
+        for (tag, weight), v in zip(tag_and_weight, vecs):
+            v = v / np.linalg.norm(v)                                                # :107
+            got += weight * v                                                        # :108
+        got = got / all_weight
+        norm = np.linalg.norm(got)
+        if math.isinf(norm) or norm == 0:
+            norm = 1.0
+        return got / norm
+
+    # ---- webui.py:354-371 -----------------------------------------------------------------------
+    def parse_bm25_query(self, new_doc: str):
+        qw: Dict[int, float] = {}
+        required: List[str] = []
+        exclude: List[str] = []
+        for term in new_doc.split(" "):
+            name, w = _split_weight(term)
+            if w is not None:
+                if w.startswith("+"):
+                    qw[self.token2id[name]] = REQUIRE_TAG_MAGIC_NUMBER + int(w)      # KeyError like :364
+                    required.append(name)
+                else:
+                    qw[self.token2id[name]] = int(w)
+                    exclude.append(name)
+            else:
+                qw[self.token2id[name]] = 1
+        return qw, required, exclude
+
+    # ---- device scoring -------------------------------------------------------------------------
+    def score_topk(self, query_weights: Sequence[Dict[int, float]], query_vectors: np.ndarray, k: int,
+                   final_out=None) -> Tuple[np.ndarray, np.ndarray]:
+        """Fused webui.py:352-383 for a batch: returns (ids int32 [nq,k], scores float64 [nq,k]) in
+        rank order; `final_out` (device float64 tensor [nq, D]) receives all combined scores."""
+        nq = len(query_weights)
+        qp = np.zeros(nq + 1, dtype=np.int32)
+        qt: List[int] = []
+        qw: List[float] = []
+        for i, q in enumerate(query_weights):
+            for t, w in q.items():
+                qt.append(int(t))
+                qw.append(float(w))
+            qp[i + 1] = len(qt)
+        qt_a = np.asarray(qt if qt else [0], dtype=np.int32)
+        qw_a = np.asarray(qw if qw else [0.0], dtype=np.float64)
+        qv = np.ascontiguousarray(np.atleast_2d(query_vectors), dtype=np.float32)
+        ids = np.empty((nq, k), dtype=np.int32)
+        vals = np.empty((nq, k), dtype=np.float64)
+        _lib.call("hipts_search", self.bm25._h, self.index._h, _lib.ptr(qt_a), _lib.ptr(qw_a), _lib.ptr(qp), _lib.ptr(qv), nq,
+                  c_double(BM25_WEIGHT), c_double(DOC2VEC_WEIGHT), k, _lib.ptr(ids), _lib.ptr(vals),
+                  _lib.ptr(final_out) if final_out is not None else None, _lib.current_stream_ptr())
+        return ids, vals
+
+    # ---- webui.py:345-390 -----------------------------------------------------------------------
+    def find_similar_documents(self, new_doc: str, topn: int = 50) -> List[Tuple[int, float]]:
+        import torch
+        vec = self.normalize_and_apply_weight_doc2vec(new_doc)                        # :349
+        qw, required, exclude = self.parse_bm25_query(new_doc)                        # :354-371
+        D = len(self.index)
+        final_dev = torch.empty((1, D), dtype=torch.float64, device="cuda:%d" % self.index.device)
+        k = min(TOPK_MAX, D)
+        ids, vals = self.score_topk([qw], vec[None, :], k, final_out=final_dev)       # :352,374-383
+        if self.search_mode == "character oriented":
+            raise NotImplementedError("character-oriented rerank needs the CCIP encoder (DESIGN.md: out of scope this round)")
+        return self._doc2vec_rerank(final_dev, ids[0], vals[0], topn)                 # :390
+
+    # ---- webui.py:189-253 -----------------------------------------------------------------------
+    def _doc_tags(self, doc_id: int) -> List[str]:
+        return self.image_files_name_tags_arr[doc_id].split(",")[1:]                  # :183 (doc_id+1-1)
+
+    def _rerank_query(self, top10_ids: Sequence[int], top10_scores: Sequence[float]) -> np.ndarray:
+        vecs = self.model.infer_vectors([self._doc_tags(int(d)) for d in top10_ids])  # :198-199
+        mean = np.average(vecs.astype(np.float64), axis=0, weights=np.asarray(top10_scores, dtype=np.float64))   # :200 (value column)
+        if self.compat_rerank:
+            # webui.py:200-203 divides the (index, value) pairs by the Frobenius norm of the whole
+            # [300,2] array and rounds the indices: every index becomes 0, so the sparse query is
+            # sum(values) * e0, which gensim then unit-normalises  [analysis; gensim unavailable].
+            q = np.zeros_like(mean)
+            s = mean.sum()
+            q[0] = 1.0 if s >= 0 else -1.0
+            return q
+        n = np.linalg.norm(mean)
+        return mean / n if n > 0 else mean
+
+    def _ranked_prefix(self, scores_dev, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        ids = np.empty((1, k), dtype=np.int32)
+        vals = np.empty((1, k), dtype=np.float64)
+        _lib.call("hipts_topk", _lib.ptr(scores_dev), 1, c_int64(scores_dev.shape[-1]), k, _lib.ptr(ids), _lib.ptr(vals),
+                  _lib.HOST, self.index.device, _lib.current_stream_ptr())
+        return ids[0], vals[0]
+
+    def _doc2vec_rerank(self, final_dev, ids: np.ndarray, vals: np.ndarray, topn: int) -> List[Tuple[int, float]]:
+        import torch
+        D = final_dev.shape[-1]
+        if D <= 10:                                                                   # :247-253
+            sims = filter_searched_result([(int(i), float(v)) for i, v in zip(ids[:D], vals[:D])])
+            return sims[:min(topn, len(sims))]
+        top10_ids = [int(i) for i in ids[:10]]
+        top10_scores = [float(v) for v in vals[:10]]
+        q = self._rerank_query(top10_ids, top10_scores).astype(np.float32)
+        rs_dev = torch.empty((1, D), dtype=torch.float32, device=final_dev.device)
+        self.index.query(q, out=rs_dev)                                               # :205
+        rf_dev = torch.empty_like(final_dev)
+        _lib.call("hipts_combine", _lib.ptr(final_dev), _lib.ptr(rs_dev), 1, c_int64(D), c_double(ORIGINAL_SCORE_WEIGHT),
+                  c_double(RERANKED_SCORE_WEIGHT), 0, 0, _lib.ptr(rf_dev), self.index.device, _lib.current_stream_ptr())   # :208
+        k = min(TOPK_MAX, D)
+        rids, rvals = self._ranked_prefix(rf_dev, k)
+        mx = rvals[0]
+        if mx > 0:
+            rvals = rvals / mx                                                        # :210-211
+        top10_set = set(top10_ids)
+        final = [(d, 1.0) for d in top10_ids]                                         # :219-222
+        final += [(int(i), float(v)) for i, v in zip(rids, rvals) if int(i) not in top10_set]   # :217,225-237
+        if k < D and not self._two_cut_points(final):
+            # The gap filter looks for its *second* cut point anywhere in the ranked list.  It is almost
+            # always inside the first 1024 entries; if not, rank all D scores (host, rare path).
+            rf = rf_dev[0].cpu().numpy()
+            if mx > 0:
+                rf = rf / mx
+            order = np.lexsort((np.arange(D), -rf))
+            final = [(d, 1.0) for d in top10_ids] + [(int(i), float(rf[i])) for i in order if int(i) not in top10_set]
+        final = filter_searched_result(final)                                         # :240
+        return final[:min(topn, len(final))]
+
+    @staticmethod
+    def _two_cut_points(ranked: List[Tuple[int, float]]) -> bool:
+        s = np.array([v for _, v in ranked])
+        d = s[:-1] - s[1:]
+        d = np.where(d == 0, np.inf, d)
+        return int((d < DIFF_FILTER_THRESH).sum()) >= 2
+
+
+_engine: Optional[SearchEngine] = None
+
+
+def set_engine(engine: SearchEngine):
+    global _engine
+    _engine = engine
+
+
+def find_similar_documents(new_doc: str, topn: int = 50) -> List[Tuple[int, float]]:
+    """webui.py:345 -- module-level entry point with the reference's signature."""
+    if _engine is None:
+        raise RuntimeError("no SearchEngine installed: call set_engine(load_engine()) first (webui.py:585 load_model)")
+    return _engine.find_similar_documents(new_doc, topn)

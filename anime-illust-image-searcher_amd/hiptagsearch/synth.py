@@ -1,0 +1,185 @@
+"""Seeded synthetic inputs of the shapes BASELINE.json names.
+
+No dataset, checkpoint or label file exists in the build or GPU environment, so benchmarks and
+parity tests run on these.  Pure numpy; shared by tests, bench.py and the CLIs' --synthetic mode.
+"""
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------------
+# ViT tagger (config[1]: wd-tagger ViT-B/16 448px bf16)
+# ---------------------------------------------------------------------------------------------
+VIT_B16_448 = dict(image_size=448, patch=16, dim=768, depth=12, heads=12, mlp_dim=3072, num_classes=10861,
+                   ln_eps=1e-6, gelu_tanh=1, pool_then_norm=0)
+VIT_TINY = dict(image_size=64, patch=16, dim=128, depth=2, heads=2, mlp_dim=256, num_classes=200,
+                ln_eps=1e-6, gelu_tanh=1, pool_then_norm=0)
+
+
+def round_to_bf16(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest-even bfloat16 -> float32 (values exactly representable in bf16)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def _trunc_normal(rng, shape, std):
+    x = rng.standard_normal(shape, dtype=np.float32)
+    np.clip(x, -2.0, 2.0, out=x)
+    x *= np.float32(std)
+    return x
+
+
+def vit_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[str, np.ndarray]:
+    """Random-init checkpoint with timm state_dict keys.  W ~ N(0,0.02^2) truncated at 2 sigma,
+    biases ~ N(0,0.02^2), LN gamma ~ U(0.5,1.5), LN beta ~ N(0,0.02^2), pos_embed ~ N(0,0.02^2).
+    With bf16_matrices the GEMM weight matrices are bf16-representable (a bf16 checkpoint, as
+    config[1] names), so the float32 oracle and the bf16 MFMA path see identical weights."""
+    rng = np.random.default_rng(seed)
+    D, P, M, C = cfg["dim"], cfg["patch"], cfg["mlp_dim"], cfg["num_classes"]
+    N = (cfg["image_size"] // P) ** 2
+    rb = round_to_bf16 if bf16_matrices else (lambda a: a)
+    w: Dict[str, np.ndarray] = {}
+    w["patch_embed.proj.weight"] = rb(_trunc_normal(rng, (D, 3, P, P), 0.02))
+    w["patch_embed.proj.bias"] = _trunc_normal(rng, (D,), 0.02)
+    w["pos_embed"] = _trunc_normal(rng, (1, N, D), 0.02)
+    for i in range(cfg["depth"]):
+        p = "blocks.%d." % i
+        for ln in ("norm1", "norm2"):
+            w[p + ln + ".weight"] = rng.uniform(0.5, 1.5, D).astype(np.float32)
+            w[p + ln + ".bias"] = _trunc_normal(rng, (D,), 0.02)
+        w[p + "attn.qkv.weight"] = rb(_trunc_normal(rng, (3 * D, D), 0.02))
+        w[p + "attn.qkv.bias"] = _trunc_normal(rng, (3 * D,), 0.02)
+        w[p + "attn.proj.weight"] = rb(_trunc_normal(rng, (D, D), 0.02))
+        w[p + "attn.proj.bias"] = _trunc_normal(rng, (D,), 0.02)
+        w[p + "mlp.fc1.weight"] = rb(_trunc_normal(rng, (M, D), 0.02))
+        w[p + "mlp.fc1.bias"] = _trunc_normal(rng, (M,), 0.02)
+        w[p + "mlp.fc2.weight"] = rb(_trunc_normal(rng, (D, M), 0.02))
+        w[p + "mlp.fc2.bias"] = _trunc_normal(rng, (D,), 0.02)
+    w["norm.weight"] = rng.uniform(0.5, 1.5, D).astype(np.float32)
+    w["norm.bias"] = _trunc_normal(rng, (D,), 0.02)
+    w["head.weight"] = rb(_trunc_normal(rng, (C, D), 0.02))
+    w["head.bias"] = _trunc_normal(rng, (C,), 0.02)
+    return w
+
+
+def images_u8(n: int, size: int = 448, seed: int = 1234) -> np.ndarray:
+    return np.random.default_rng(seed).integers(0, 256, (n, size, size, 3), dtype=np.uint8)
+
+
+def label_table(num_classes: int = 10861) -> Tuple[List[str], np.ndarray]:
+    """Synthetic selected_tags.csv: first 4 rating (9), then general (0), last ~24 % character (4)."""
+    n_char = int(round(num_classes * 2600 / 10861))
+    cat = np.zeros(num_classes, dtype=np.int32)
+    cat[:min(4, num_classes)] = 9
+    cat[num_classes - n_char:] = 4
+    names = ["tag_%05d" % i for i in range(num_classes)]
+    return names, cat
+
+
+# ---------------------------------------------------------------------------------------------
+# Tag documents / queries (config[2]: 100k random tag-docs)
+# ---------------------------------------------------------------------------------------------
+def tag_corpus(D: int = 100_000, V: int = 10_000, seed: int = 42, mean_len: int = 20) -> Tuple[np.ndarray, np.ndarray]:
+    """CSR (doc_ptr int64[D+1], term_ids int32[nnz]) of token ids per document: Zipf(1.1) tag
+    popularity, clip(Poisson(mean_len),3,60) distinct tags, 1 % of documents repeat a tag (tf up
+    to 3).  Token id == popularity rank (id 0 most frequent)."""
+    rng = np.random.default_rng(seed)
+    p = np.arange(1, V + 1, dtype=np.float64) ** -1.1
+    cdf = np.cumsum(p / p.sum())
+    lens = np.clip(rng.poisson(mean_len, D), 3, 60)
+    ptr = np.zeros(D + 1, dtype=np.int64)
+    out: List[np.ndarray] = []
+    for d in range(D):
+        n = int(min(lens[d], V))
+        draws = np.searchsorted(cdf, rng.random(4 * n + 8)).astype(np.int32)
+        np.minimum(draws, V - 1, out=draws)
+        _, first = np.unique(draws, return_index=True)
+        ids = draws[np.sort(first)][:n]
+        if len(ids) < 3:   # cannot happen for V >= 3 in practice; keep the >= 3 tags invariant anyway
+            ids = np.unique(np.concatenate([ids, np.arange(3, dtype=np.int32)]))[:3]
+        if rng.random() < 0.01:
+            ids = np.concatenate([ids, np.repeat(ids[:1], int(rng.integers(1, 3)))])
+        out.append(ids.astype(np.int32))
+        ptr[d + 1] = ptr[d] + len(ids)
+    return ptr, np.concatenate(out)
+
+
+def vocab_tokens(V: int) -> List[str]:
+    return ["t%05d" % i for i in range(V)]
+
+
+def queries(nq: int = 1000, V: int = 10_000, seed: int = 43, head: int = 2000) -> List[List[Tuple[int, int]]]:
+    """nq queries of 1-4 distinct terms drawn from the `head` most popular ids; each term plain
+    (weight 1) 70 %, required (+w) 15 %, excluded (-w) 15 %, w in {1,2,3}.  Returned as
+    [(term_id, signed weight)] where required terms carry 1000 + w (webui.py:364)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(nq):
+        nt = int(rng.integers(1, 5))
+        ids = rng.choice(min(head, V), size=nt, replace=False)
+        q = []
+        for t in ids:
+            r = rng.random()
+            w = int(rng.integers(1, 4))
+            q.append((int(t), 1 if r < 0.7 else (1000 + w if r < 0.85 else -w)))
+        out.append(q)
+    return out
+
+
+def query_string(q: List[Tuple[int, int]], tokens: List[str]) -> str:
+    """Render a synthetic query in the reference's syntax (README.md:87-99): tag, tag:+w, tag:-w."""
+    parts = []
+    for t, w in q:
+        if w > 1000:
+            parts.append("%s:+%d" % (tokens[t], w - 1000))
+        elif w < 0:
+            parts.append("%s:%d" % (tokens[t], w))
+        else:
+            parts.append(tokens[t])
+    return " ".join(parts)
+
+
+# ---------------------------------------------------------------------------------------------
+# Doc2Vec model stand-in (training is out of scope: genmodel.py:159-162)
+# ---------------------------------------------------------------------------------------------
+def d2v_model(counts: np.ndarray, dim: int = 300, seed: int = 44, sample: float = 1e-3,
+              ns_exponent: float = 0.75) -> Dict[str, np.ndarray]:
+    """syn1neg ~ N(0,0.1^2) [V,dim]; cum_table / sample_int derived from the corpus counts the way
+    gensim's Word2Vec.make_cum_table / prepare_vocab do [published algorithm]."""
+    rng = np.random.default_rng(seed)
+    V = len(counts)
+    syn1neg = (rng.standard_normal((V, dim)) * 0.1).astype(np.float32)
+    counts = np.maximum(np.asarray(counts, dtype=np.float64), 1.0)
+    pw = counts ** ns_exponent
+    cum = np.cumsum(pw)
+    domain = 2 ** 31 - 1
+    cum_table = np.round(cum / cum[-1] * domain).astype(np.uint32)
+    cum_table[-1] = domain
+    retain_total = counts.sum()
+    threshold = sample * retain_total
+    prob = (np.sqrt(counts / threshold) + 1) * (threshold / counts)
+    prob = np.minimum(prob, 1.0)
+    sample_int = (prob * (2 ** 32 - 1)).astype(np.uint32)
+    return {"syn1neg": syn1neg, "cum_table": cum_table, "sample_int": sample_int}
+
+
+def d2v_inputs(ndocs: int, dim: int = 300, seed: int = 44) -> Tuple[np.ndarray, np.ndarray]:
+    """(v0 float32 [ndocs,dim] = (U(0,1)-0.5)/dim as gensim's pseudorandom_weak_vector, seeds uint64)."""
+    rng = np.random.default_rng(seed + 1)
+    v0 = ((rng.random((ndocs, dim), dtype=np.float32) - np.float32(0.5)) / np.float32(dim)).astype(np.float32)
+    seeds = rng.integers(0, 2 ** 63, ndocs, dtype=np.uint64)
+    return v0, seeds
+
+
+def term_counts(ptr: np.ndarray, terms: np.ndarray, V: int) -> np.ndarray:
+    return np.bincount(terms[terms >= 0], minlength=V).astype(np.int64)
+
+
+def index_vectors(D: int = 100_000, dim: int = 300, seed: int = 46, unit: bool = False) -> np.ndarray:
+    x = np.random.default_rng(seed).standard_normal((D, dim), dtype=np.float32)
+    if unit:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    else:
+        x *= np.float32(0.05)
+    return x

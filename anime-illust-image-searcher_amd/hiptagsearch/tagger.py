@@ -1,0 +1,302 @@
+"""Tagging stage: host-side mirror of tagging.py's Predictor over the device kernels.
+
+  ViTTagger.forward / .forward_u8     timm `model.forward` + `F.sigmoid`     tagging.py:174-176
+  TagSelector                         per-image MCut selection                 tagging.py:61-66,185-227
+  Predictor.predict(tensors, general_thresh, general_mcut_enabled, character_thresh,
+                    character_mcut_enabled) -> List[str]                       tagging.py:156-229
+  Predictor.prepare_image / gen_image_tensor / list_files_recursive / process_directory
+                                                                               tagging.py:91-120,234-359
+"""
+import ctypes
+import datetime
+import os
+import time
+import concurrent.futures
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, synth
+from ._lib import VitConfig, c_double, c_void_p
+
+EXTENSIONS: List[str] = ['.png', '.jpg', '.jpeg', ".PNG", ".JPG", ".JPEG"]   # tagging.py:47
+BATCH_SIZE: int = 10          # tagging.py:49 (reference default; the device path takes any batch <= max_batch)
+WORKER_NUM: int = 8           # tagging.py:52
+PROGRESS_INTERVAL: int = 1000  # tagging.py:50
+
+
+class ViTTagger:
+    """Device-resident ViT tagger.  `weights` uses timm state_dict keys (float32 numpy arrays)."""
+
+    def __init__(self, cfg: Dict, weights: Dict[str, np.ndarray], max_batch: int = 64, device: int = 0):
+        self.cfg = dict(cfg)
+        self.device = device
+        self.max_batch = max_batch
+        self.num_classes = cfg["num_classes"]
+        c = VitConfig(cfg["image_size"], cfg["patch"], cfg["dim"], cfg["depth"], cfg["heads"], cfg["mlp_dim"],
+                      cfg["num_classes"], cfg.get("ln_eps", 1e-6), cfg.get("gelu_tanh", 1), cfg.get("pool_then_norm", 0),
+                      max_batch)
+        self._h = c_void_p()
+        _lib.call("hipts_vit_create", ctypes.byref(c), device, ctypes.byref(self._h))
+        for key, val in weights.items():
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            _lib.call("hipts_vit_set_tensor", self._h, key.encode(), _lib.ptr(arr), ctypes.c_int64(arr.size))
+
+    @classmethod
+    def from_safetensors(cls, path: str, cfg: Dict, **kw) -> "ViTTagger":
+        """Load a timm-layout checkpoint (model.safetensors of a wd-vit-tagger style repo)."""
+        from safetensors.numpy import load_file
+        return cls(cfg, {k: v.astype(np.float32) for k, v in load_file(path).items()}, **kw)
+
+    def flops_per_image(self) -> float:
+        f = c_double()
+        _lib.call("hipts_vit_flops_per_image", self._h, ctypes.byref(f))
+        return f.value
+
+    def _run(self, fn: str, x, batch: int, logits, probs):
+        out_space = _lib.HOST
+        for o in (logits, probs):
+            if o is not None:
+                out_space = _lib.memspace_of(o)
+        _lib.call(fn, self._h, _lib.ptr(x), _lib.memspace_of(x), batch, _lib.ptr(logits), _lib.ptr(probs), out_space,
+                  _lib.current_stream_ptr())
+
+    def forward_u8(self, images, logits=None, probs=None, want: str = "both"):
+        """images: uint8 [B,S,S,3] RGB (numpy or torch, host or device).  Returns (logits, probs)
+        float32 [B,num_classes] in the same memory space as the outputs passed (host numpy by default)."""
+        B = int(images.shape[0])
+        if logits is None and want in ("both", "logits"):
+            logits = np.empty((B, self.num_classes), dtype=np.float32)
+        if probs is None and want in ("both", "probs"):
+            probs = np.empty((B, self.num_classes), dtype=np.float32)
+        if isinstance(images, np.ndarray):
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+        self._run("hipts_vit_forward_u8", images, B, logits, probs)
+        return logits, probs
+
+    def forward(self, x, logits=None, probs=None):
+        """x: float32 [B,3,S,S] normalised BGR -- the tensor tagging.py:174 feeds model.forward."""
+        B = int(x.shape[0])
+        if logits is None:
+            logits = np.empty((B, self.num_classes), dtype=np.float32)
+        if probs is None:
+            probs = np.empty((B, self.num_classes), dtype=np.float32)
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+        self._run("hipts_vit_forward_f32", x, B, logits, probs)
+        return logits, probs
+
+    def close(self):
+        if self._h:
+            _lib.call("hipts_vit_destroy", self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TagSelector:
+    def __init__(self, category: np.ndarray, max_batch: int = 64, device: int = 0):
+        self.category = np.ascontiguousarray(category, dtype=np.int32)
+        self.num_classes = len(self.category)
+        self._h = c_void_p()
+        _lib.call("hipts_tagsel_create", _lib.ptr(self.category), self.num_classes, device, max_batch, ctypes.byref(self._h))
+
+    def run(self, probs, general_thresh=0.3, general_mcut=True, character_thresh=0.3, character_mcut=True,
+            row_cap: Optional[int] = None):
+        """probs float32 [B,C] (host numpy or device tensor).  Returns (counts int32 [B,2], ids int32
+        [B,row_cap], thresholds float64 [B,2]) on the host."""
+        B = int(probs.shape[0])
+        row_cap = row_cap or self.num_classes
+        counts = np.empty((B, 2), dtype=np.int32)
+        ids = np.empty((B, row_cap), dtype=np.int32)
+        thr = np.empty((B, 2), dtype=np.float64)
+        if isinstance(probs, np.ndarray):
+            probs = np.ascontiguousarray(probs, dtype=np.float32)
+        _lib.call("hipts_tagsel_run", self._h, _lib.ptr(probs), _lib.memspace_of(probs), B, c_double(general_thresh),
+                  int(general_mcut), c_double(character_thresh), int(character_mcut), _lib.ptr(counts), _lib.ptr(ids),
+                  row_cap, _lib.ptr(thr), _lib.HOST, _lib.current_stream_ptr())
+        return counts, ids, thr
+
+    def close(self):
+        if self._h:
+            _lib.call("hipts_tagsel_destroy", self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_lines(names: Sequence[str], counts: np.ndarray, ids: np.ndarray) -> List[str]:
+    """tagging.py:210-225: general tags then character tags, ' ' -> '_', joined by ','."""
+    out = []
+    for r in range(len(counts)):
+        ng, nc = int(counts[r, 0]), int(counts[r, 1])
+        g = [names[i].replace(' ', '_') for i in ids[r, :ng]]
+        s = ",".join(g)
+        if nc > 0:
+            s += ","
+            s += ",".join(names[i].replace(' ', '_') for i in ids[r, ng:ng + nc])
+        out.append(s)
+    return out
+
+
+class Predictor:
+    """Same surface as tagging.py's Predictor.  `load_model` needs a checkpoint + label table, which
+    the reference downloads from the HF hub (tagging.py:146-151); offline it takes local files or the
+    seeded synthetic stand-ins."""
+
+    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False) -> None:
+        self.device = device
+        self.max_batch = max_batch
+        self.compat = compat            # reproduce the reference's dropped tail batch
+        self.tagger_model: Optional[ViTTagger] = None
+        self.selector: Optional[TagSelector] = None
+        self.tag_names: Optional[List[str]] = None
+        self.rating_index = self.general_index = self.character_index = None
+        self.cfg = None
+        self.f = None
+
+    # ---- tagging.py:91-98
+    def list_files_recursive(self, dir_path: str) -> List[str]:
+        file_list: List[str] = []
+        for root, _, files in os.walk(dir_path):
+            for file in files:
+                file_path = os.path.join(root, file)
+                if any(file_path.endswith(ext) for ext in EXTENSIONS):
+                    file_list.append(file_path)
+        return file_list
+
+    # ---- tagging.py:100-120
+    def prepare_image(self, image):
+        from PIL import Image
+        if image.mode in ('RGBA', 'LA'):
+            background = Image.new("RGB", image.size, (255, 255, 255))
+            background.paste(image, mask=image.split()[-1])
+            image = background
+        else:
+            image = image.copy().convert("RGB")
+        w, h = image.size
+        max_dim = max(w, h)
+        padded = Image.new("RGB", (max_dim, max_dim), (255, 255, 255))
+        padded.paste(image, ((max_dim - w) // 2, (max_dim - h) // 2))
+        return padded
+
+    # ---- tagging.py:122-154
+    def load_labels(self, names: Sequence[str], category: np.ndarray):
+        category = np.asarray(category)
+        self.rating_index = list(np.where(category == 9)[0])
+        self.general_index = list(np.where(category == 0)[0])
+        self.character_index = list(np.where(category == 4)[0])
+        self.tag_names = list(names)
+        self.selector = TagSelector(category, self.max_batch, self.device)
+
+    def load_model(self, checkpoint: Optional[str] = None, labels_csv: Optional[str] = None, cfg: Optional[Dict] = None,
+                   seed: int = 0) -> None:
+        if self.tagger_model is not None:
+            return
+        self.cfg = dict(cfg or synth.VIT_B16_448)
+        if checkpoint:
+            self.tagger_model = ViTTagger.from_safetensors(checkpoint, self.cfg, max_batch=self.max_batch, device=self.device)
+        else:
+            print("No checkpoint given: using the seeded synthetic ViT weights (no network in this environment).")
+            self.tagger_model = ViTTagger(self.cfg, synth.vit_weights(self.cfg, seed), self.max_batch, self.device)
+        if labels_csv:
+            import pandas as pd
+            df = pd.read_csv(labels_csv, usecols=["name", "category"])
+            self.load_labels(df["name"].tolist(), df["category"].to_numpy())
+        else:
+            names, cat = synth.label_table(self.cfg["num_classes"])
+            self.load_labels(names, cat)
+
+    # ---- tagging.py:234-252: returns the uint8 HWC image (the device kernel applies the transform)
+    def gen_image_tensor(self, file_path: str):
+        from PIL import Image
+        img = None
+        try:
+            img = Image.open(file_path)
+            img.load()
+            img_tmp = self.prepare_image(img)
+            size = self.cfg["image_size"]
+            if img_tmp.size != (size, size):
+                img_tmp = img_tmp.resize((size, size), Image.BICUBIC)   # timm eval transform: Resize(bicubic) + CenterCrop
+            return np.asarray(img_tmp, dtype=np.uint8)
+        except Exception as e:
+            if img is not None:
+                img.close()
+            print('%s: %s' % (type(e), str(e)))
+            return None
+
+    # ---- tagging.py:156-229
+    def predict(self, tensors: List, general_thresh: float, general_mcut_enabled: bool, character_thresh: float,
+                character_mcut_enabled: bool) -> List[str]:
+        first = tensors[0]
+        out: List[str] = []
+        for s in range(0, len(tensors), self.max_batch):
+            chunk = tensors[s:s + self.max_batch]
+            if hasattr(first, "dtype") and str(first.dtype) in ("uint8", "torch.uint8"):
+                batch = np.stack([np.asarray(t) for t in chunk])
+                _, probs = self.tagger_model.forward_u8(batch, want="probs")
+            else:   # float32 CHW tensors exactly as the reference's transform produces (tagging.py:241-243)
+                batch = np.stack([np.asarray(t, dtype=np.float32) for t in chunk])
+                _, probs = self.tagger_model.forward(batch)
+            counts, ids, _ = self.selector.run(probs, general_thresh, general_mcut_enabled, character_thresh,
+                                               character_mcut_enabled)
+            out.extend(format_lines(self.tag_names, counts, ids))
+        return out
+
+    def write_to_file(self, csv_line: str) -> None:
+        self.f.write(csv_line + '\n')
+
+    def filter_files_by_date(self, file_list: List[str], added_date: datetime.date) -> List[str]:
+        return [p for p in file_list if datetime.date.fromtimestamp(os.stat(p).st_ctime) >= added_date]   # tagging.py:266-274
+
+    # ---- tagging.py:276-359
+    def process_directory(self, dir_path: str, added_date: Optional[datetime.date] = None, batch_size: int = BATCH_SIZE) -> None:
+        file_list = self.list_files_recursive(dir_path)
+        print(f'{len(file_list)} files found')
+        if added_date is not None:
+            file_list = self.filter_files_by_date(file_list, added_date)
+            print(f'{len(file_list)} files found after {added_date}')
+            if os.path.exists('tags-wd-tagger.txt'):
+                with open('tags-wd-tagger.txt', 'r', encoding='utf-8') as f, \
+                        open('tags-wd-tagger.txt.bak', 'w', encoding='utf-8') as f_bak:
+                    f_bak.write(f.read())
+            else:
+                print('tags-wd-tagger.txt not found')
+                raise SystemExit(1)
+        self.f = open('tags-wd-tagger.txt', 'a', encoding='utf-8')
+        self.load_model()
+        start = time.perf_counter()
+        done = 0
+        last = 0
+        batches = [file_list[i:i + batch_size] for i in range(0, len(file_list), batch_size)]
+        if self.compat and batches:
+            batches = batches[:-1]      # the reference never consumes its last submitted batch (tagging.py:309)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as ex:
+            nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[0]] if batches else []
+            for bi, paths in enumerate(batches):
+                futs = nxt
+                nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[bi + 1]] if bi + 1 < len(batches) else []   # prefetch
+                tensors, kept = [], []
+                for p, fu in zip(paths, futs):
+                    t = fu.result()
+                    if t is not None:
+                        tensors.append(t)
+                        kept.append(p)
+                if tensors:
+                    for p, line in zip(kept, self.predict(tensors, 0.3, True, 0.3, True)):      # tagging.py:333
+                        self.write_to_file(p + ',' + line)
+                    self.f.flush()
+                done += len(paths)
+                if done - last >= PROGRESS_INTERVAL:
+                    diff = time.perf_counter() - start
+                    print(f'{done} files processed\n{diff:.2f} seconds elapsed\n{diff / done:.4f} seconds per file\n', flush=True)
+                    last = done
+        self.f.close()

@@ -1,0 +1,195 @@
+/* hip_tagsearch.h -- C ABI of libhip_tagsearch.so (MI355X / gfx950 only).
+ *
+ * The reference (ryogrid/anime-illust-image-searcher) has no FFI: its hot path sits behind
+ * plain Python call sites into timm/torch, gensim and numpy.  Each entry point below is what
+ * a ctypes binding for one of those call sites binds to; the call site it replaces is cited
+ * as  file:line  relative to the reference repository.  INTEGRATION.md shows the
+ * reference-side stubs.
+ *
+ * Conventions
+ *   - every function returns HIPTS_OK (0) or a negative hipts_status; the message of the last
+ *     failure on the calling thread is available from hipts_last_error().
+ *   - handles are opaque, created/destroyed explicitly, bound to one device, single-caller.
+ *   - the caller owns every input and output buffer.  `memspace` arguments say whether a
+ *     pointer is host memory (HIPTS_HOST) or memory of the handle's device (HIPTS_DEVICE).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  With device outputs
+ *     the call returns after enqueueing; with host outputs it returns after the copy-back.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *     fails with HIPTS_ERR_NO_DEVICE.
+ */
+#ifndef HIP_TAGSEARCH_H
+#define HIP_TAGSEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPTS_ABI_VERSION 1
+
+typedef enum hipts_status {
+    HIPTS_OK = 0,
+    HIPTS_ERR_INVALID = -1,     /* bad argument / shape the kernels do not support      */
+    HIPTS_ERR_NO_DEVICE = -2,   /* no gfx950 device / device index out of range          */
+    HIPTS_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed            */
+    HIPTS_ERR_OOM = -4,
+    HIPTS_ERR_STATE = -5        /* e.g. forward() before all weights were set            */
+} hipts_status;
+
+typedef enum hipts_memspace { HIPTS_HOST = 0, HIPTS_DEVICE = 1 } hipts_memspace;
+
+int hipts_abi_version(void);
+/* copies the calling thread's last error message (NUL terminated, truncated to n) */
+int hipts_last_error(char* buf, size_t n);
+int hipts_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------
+ * ViT tagger forward.   Replaces timm `model.forward(x)` + `F.sigmoid`      tagging.py:174,176
+ * (model construction / weight load: tagging.py:146-148).
+ * Graph: patch-embed conv k=s=patch -> +pos_embed -> depth x {LN, QKV, softmax(QK^T/sqrt(hd))V,
+ * proj, +res, LN, fc1, GELU, fc2, +res} -> final LN -> token mean -> head  (no class token).
+ * Matrix weights are held as bf16 (MFMA operands), everything else and all accumulation,
+ * the residual stream, LayerNorm and softmax statistics in float32.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_vit hipts_vit_t;
+
+typedef struct hipts_vit_config {
+    int32_t image_size;      /* 448                                   */
+    int32_t patch;           /* 16                                    */
+    int32_t dim;             /* 768                                   */
+    int32_t depth;           /* 12                                    */
+    int32_t heads;           /* 12  (head dim must be 64)             */
+    int32_t mlp_dim;         /* 3072                                  */
+    int32_t num_classes;     /* 10861                                 */
+    float   ln_eps;          /* 1e-6                                  */
+    int32_t gelu_tanh;       /* 1: tanh approximation, 0: erf         */
+    int32_t pool_then_norm;  /* 0: LN(tokens) then mean (fc_norm=False); 1: mean then LN */
+    int32_t max_batch;       /* workspace is sized for this many images per forward call */
+} hipts_vit_config_t;
+
+int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** out);
+int hipts_vit_destroy(hipts_vit_t* h);
+/* One tensor of the checkpoint by its timm state_dict key ("patch_embed.proj.weight",
+ * "pos_embed", "blocks.3.attn.qkv.weight", "norm.bias", "head.weight", ...); `data` is host
+ * float32 in the timm layout, `numel` its element count (checked).     tagging.py:147-148 */
+int hipts_vit_set_tensor(hipts_vit_t* h, const char* key, const float* data, int64_t numel);
+/* images: uint8 [batch][H][W][3] RGB (what PIL hands to the timm transform for an image that
+ * is already image_size^2); the kernel applies ToTensor + Normalize(.5,.5) + the RGB->BGR flip
+ * of tagging.py:241-243 while forming the patch matrix.  logits_out / probs_out: float32
+ * [batch][num_classes], either may be NULL. */
+int hipts_vit_forward_u8(hipts_vit_t* h, const uint8_t* images, int images_memspace, int batch,
+                         float* logits_out, float* probs_out, int out_memspace, void* stream);
+/* x: float32 [batch][3][H][W], already normalised and BGR -- exactly the tensor
+ * tagging.py:164 stacks and :174 passes to model.forward. */
+int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int batch,
+                          float* logits_out, float* probs_out, int out_memspace, void* stream);
+/* algorithmic FLOPs of one image's forward (2*M*N*K of every contraction), for roofline use */
+int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops);
+
+/* ------------------------------------------------------------------------------------------
+ * Tag selection.   Replaces the per-image numpy/Python post-processing   tagging.py:61-66,185-227
+ * (float64 MCut threshold per category, strict '>' filter, stable descending order).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_tagsel hipts_tagsel_t;
+/* category[c]: 0 general, 4 character, anything else ignored (9 = rating)  tagging.py:137-139 */
+int hipts_tagsel_create(const int32_t* category, int num_classes, int device, int max_batch,
+                        hipts_tagsel_t** out);
+int hipts_tagsel_destroy(hipts_tagsel_t* h);
+/* probs: float32 [batch][num_classes].  Per image writes counts_out[2] = {#general, #character},
+ * ids_out[row_cap] = label ids, general tags first then character tags, each group in output
+ * order; thresh_out[2] = the float64 thresholds used.  A row that selects more than row_cap
+ * labels is truncated and reports its full counts (caller can detect n_g+n_c > row_cap). */
+int hipts_tagsel_run(hipts_tagsel_t* h, const float* probs, int probs_memspace, int batch,
+                     double general_thresh, int general_mcut, double character_thresh, int character_mcut,
+                     int32_t* counts_out, int32_t* ids_out, int row_cap, double* thresh_out,
+                     int out_memspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BM25.   build replaces gen_and_save_bm25_index                            genmodel.py:51-99
+ *         score replaces compute_bm25_scores(query_weights=...)             webui.py:119-172
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_bm25 hipts_bm25_t;
+/* Documents in CSR form: token ids of document d are term_ids[doc_ptr[d] .. doc_ptr[d+1]) in
+ * document order, duplicates allowed (they count into tf), id < 0 = tag not in the dictionary
+ * (dropped, as genmodel.py:59).  vocab = number of dictionary ids. */
+int hipts_bm25_build(const int64_t* doc_ptr, const int32_t* term_ids, int64_t num_docs, int32_t vocab,
+                     int device, hipts_bm25_t** out);
+int hipts_bm25_destroy(hipts_bm25_t* h);
+int hipts_bm25_info(const hipts_bm25_t* h, int64_t* num_docs, int64_t* nnz, int32_t* vocab, double* avgdl);
+/* The five objects genmodel.py:84-97 pickles, as arrays (any pointer may be NULL):
+ * csr_ptr[D+1], csr_term[nnz], csr_tf[nnz] (per-document term->tf in first-occurrence order),
+ * doc_len[D], df[vocab], idf[vocab] (0 where df == 0). */
+int hipts_bm25_export(const hipts_bm25_t* h, int64_t* csr_ptr, int32_t* csr_term, int32_t* csr_tf,
+                      int64_t* doc_len, int64_t* df, double* idf);
+/* Replace the idf table (float64 [vocab]).  build computes idf = log(1+(D-df+.5)/(df+.5)) with
+ * the host libm, which is within 1 ulp of -- but not always bit-identical to -- numpy's log
+ * (genmodel.py:81); a caller that holds the reference's own `bm25_idf` pickle, or wants
+ * bit-identical pickles, sets those values here. */
+int hipts_bm25_set_idf(hipts_bm25_t* h, const double* idf);
+/* nq queries; query i has terms q_terms[q_ptr[i]..q_ptr[i+1]) with weights q_weights[...] in the
+ * iteration order of the reference's dict (webui.py:139).  weight < 0: exclude, weight > 1000:
+ * required with weight-1000 (webui.py:154-170).  scores_out: float64 [nq][num_docs]. */
+int hipts_bm25_score(hipts_bm25_t* h, const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr,
+                     int nq, double* scores_out, int out_memspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense similarity index.   Replaces gensim Similarity / MatrixSimilarity as the reference
+ * uses it: Similarity(prefix,[vec],num_features) / add_documents   genmodel.py:170-173,
+ * gen_cfeatures.py:311-314;  index[query]                         webui.py:205,352;
+ * vector_by_id / len                                               webui.py:306-309.
+ * scores[q][d] = sum_k rows[d][k]*query[q][k], float32, accumulated as the k-ordered fused
+ * chain acc = fma(row[k], query[k], acc) (bit-reproducible; v_mfma_f32_32x32x2_f32).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_index hipts_index_t;
+int hipts_index_create(int dim, int64_t capacity, int device, hipts_index_t** out);
+int hipts_index_destroy(hipts_index_t* h);
+int hipts_index_add(hipts_index_t* h, const float* rows, int64_t nrows, int rows_memspace);
+int hipts_index_len(const hipts_index_t* h, int64_t* nrows);
+int hipts_index_vector_by_id(const hipts_index_t* h, int64_t id, float* out_host);
+/* device address of the row-major [len][dim] float32 matrix (for zero-copy producers) */
+int hipts_index_data(const hipts_index_t* h, void** device_ptr);
+int hipts_index_query(hipts_index_t* h, const float* queries, int queries_memspace, int nq,
+                      float* scores_out, int out_memspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Score combination and ranking.   Replaces   webui.py:377-383  (normalise by max, weighted
+ * sum) and the full Python sort webui.py:191-192 (score descending, ties by ascending id).
+ * ---------------------------------------------------------------------------------------- */
+/* out[q][d] = wa * A + (double)((float)wb * B) with A = a[q][d] / max(a[q]) if norm_a and that
+ * max > 0 else a[q][d] (float64) and B likewise on the float32 b.  out may alias a. */
+int hipts_combine(const double* a, const float* b, int nq, int64_t n, double wa, double wb,
+                  int norm_a, int norm_b, double* out, int device, void* stream);
+/* per query the k best entries of vals[q][0..n): ids_out int32 [nq][k], vals_out float64
+ * [nq][k], in rank order (value descending, ties by ascending index).  k <= 1024.
+ * vals is device memory; outputs in out_memspace. */
+int hipts_topk(const double* vals, int nq, int64_t n, int k, int32_t* ids_out, double* vals_out,
+               int out_memspace, int device, void* stream);
+/* the fused query of webui.py:352-383 for nq queries: BM25 + index product + normalise +
+ * w_bm25/w_sim combine + top-k.  final_out (optional, device, float64 [nq][len]) receives the
+ * combined scores for the rerank stage (webui.py:189-253). */
+int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index,
+                 const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr,
+                 const float* q_vectors, int nq, double w_bm25, double w_sim, int k,
+                 int32_t* ids_out, double* vals_out, double* final_out_device, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Doc2Vec PV-DBOW inference.   Replaces gensim Doc2Vec.infer_vector      genmodel.py:169,
+ * webui.py:106,185  (model built at genmodel.py:159: dm=0, vector_size=300, negative=5).
+ * One wavefront per document; see DESIGN.md for the explicit (v0, seed) inputs.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_d2v hipts_d2v_t;
+int hipts_d2v_create(const float* syn1neg, const uint32_t* cum_table, const uint32_t* sample_int,
+                     int64_t vocab, int dim, int negative, double exp_scale, int device, hipts_d2v_t** out);
+int hipts_d2v_destroy(hipts_d2v_t* h);
+/* documents in CSR form over vocabulary indices (-1 = out of vocabulary); v0 float32
+ * [ndocs][dim] start vectors, seeds uint64 [ndocs]; out float32 [ndocs][dim]. */
+int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words, int64_t ndocs,
+                    const float* v0, const uint64_t* seeds, int epochs, float alpha, float min_alpha,
+                    float* out, int out_memspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_TAGSEARCH_H */

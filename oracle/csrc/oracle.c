@@ -1,0 +1,147 @@
+/* CPU oracle, C part -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+ *
+ * Plain C restatement of two float32 pieces of the hot path whose arithmetic
+ * lives in third-party code absent from /root/reference (gensim 4.3.3, numpy/BLAS):
+ *
+ *   orc_sim_chain    gensim Similarity.__getitem__ -> MatrixSimilarity.get_similarities:
+ *                    scores = index[D,K] . q[K]   (reference call sites webui.py:205,352).
+ *                    BLAS sgemv fixes no summation order; this oracle *defines* it as the
+ *                    k-ordered fused chain acc = fmaf(a[k], q[k], acc), k = 0..K-1, which is
+ *                    exactly what gfx950's v_mfma_f32_32x32x2_f32 computes.
+ *
+ *   orc_d2v_infer    gensim Doc2Vec.infer_vector for dm=0 (PV-DBOW), negative sampling,
+ *                    hs=0 (reference call sites genmodel.py:159,169; webui.py:106,185):
+ *                    doc2vec.py::infer_vector -> doc2vec_inner.pyx::train_document_dbow ->
+ *                    fast_document_dbow_neg, with word2vec_inner's 48-bit LCG, EXP_TABLE and
+ *                    bisect_left over cum_table.  PARITY UNPINNED (gensim absent; restated
+ *                    from the published algorithm).  Explicit inputs replace gensim's hidden
+ *                    state: the start vector v0 (gensim: SFC64(hash(' '.join(words)))) and a
+ *                    per-document 64-bit seed from which each epoch's 48-bit LCG state is
+ *                    derived with splitmix64 (gensim: two draws from model.random per epoch).
+ *                    sdot's order is defined as: 64 lane partials p[l] = fma-chain over
+ *                    elements l, l+64, l+128, ... then the xor butterfly 32,16,8,4,2,1.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fmaf() is explicit).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EXP_TABLE_SIZE 1000
+#define ORC_MAX_EXP 6
+
+void orc_sim_chain(const float* index, int64_t D, int K, int64_t ld, const float* q, float* out) {
+    for (int64_t d = 0; d < D; ++d) {
+        const float* a = index + d * ld;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) acc = fmaf(a[k], q[k], acc);
+        out[d] = acc;
+    }
+}
+
+/* word2vec_inner.pyx: EXP_TABLE[i] = exp((i / 1000 * 2 - 1) * 6); EXP_TABLE[i] /= (EXP_TABLE[i] + 1)  (REAL_t) */
+void orc_exp_table(float* table) {
+    for (int i = 0; i < ORC_EXP_TABLE_SIZE; ++i) {
+        float e = (float)exp((i / (float)ORC_EXP_TABLE_SIZE * 2 - 1) * ORC_MAX_EXP);
+        table[i] = (float)(e / (e + 1));
+    }
+}
+
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+/* the dot-product order shared with the HIP kernel (one wavefront per document) */
+static float dot_wave64(const float* v, const float* w, int dim) {
+    float p[64];
+    for (int l = 0; l < 64; ++l) {
+        float acc = 0.0f;
+        for (int i = l; i < dim; i += 64) acc = fmaf(v[i], w[i], acc);
+        p[l] = acc;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        float t[64];
+        for (int l = 0; l < 64; ++l) t[l] = p[l] + p[l ^ m];
+        memcpy(p, t, sizeof(p));
+    }
+    return p[0];
+}
+
+/* word2vec_inner.pyx bisect_left over the uint32 cumulative table */
+static uint32_t bisect_left_u32(const uint32_t* a, uint64_t x, uint64_t lo, uint64_t hi) {
+    while (hi > lo) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] >= x) hi = mid; else lo = mid + 1;
+    }
+    return (uint32_t)lo;
+}
+
+/* One document.  words: vocabulary indices, -1 = out of vocabulary (dropped).
+ * exp_scale: (EXP_TABLE_SIZE / MAX_EXP / 2) as the compiled gensim evaluates it (83 with
+ * integer folding, 83.33.. with true division) -- a parameter because it is unverifiable here. */
+static void infer_one(const float* syn1neg, const uint32_t* cum_table, int64_t V, const uint32_t* sample_int,
+                      int dim, const int32_t* words, int nwords, const float* v0, uint64_t seed,
+                      int epochs, float alpha0, float min_alpha, int negative, double exp_scale,
+                      const float* exp_table, float* out) {
+    const uint64_t MOD = 281474976710655ULL;
+    float* v = out;
+    float* work = (float*)malloc(sizeof(float) * (size_t)dim);
+    memcpy(v, v0, sizeof(float) * (size_t)dim);
+    /* doc2vec.py::infer_vector: alpha_delta = (alpha - min_alpha) / max(epochs - 1, 1)  (Python floats = double) */
+    double alpha = (double)alpha0;
+    double alpha_delta = ((double)alpha0 - (double)min_alpha) / (double)(epochs - 1 > 1 ? epochs - 1 : 1);
+    for (int e = 0; e < epochs; ++e) {
+        uint64_t next_random = splitmix64(seed + (uint64_t)e) & MOD;
+        const float a = (float)alpha;                       /* c.alpha is REAL_t */
+        for (int i = 0; i < nwords; ++i) {
+            int32_t w = words[i];
+            if (w < 0 || w >= V) continue;                  /* token not in vocabulary */
+            if (sample_int) {                               /* c.sample != 0 */
+                uint64_t r = next_random >> 16;             /* random_int32 */
+                next_random = (next_random * 25214903917ULL + 11) & MOD;
+                if ((uint64_t)sample_int[w] < r) continue;
+            }
+            /* fast_document_dbow_neg */
+            memset(work, 0, sizeof(float) * (size_t)dim);
+            for (int d = 0; d < negative + 1; ++d) {
+                uint32_t target;
+                float label;
+                if (d == 0) {
+                    target = (uint32_t)w;
+                    label = 1.0f;
+                } else {
+                    target = bisect_left_u32(cum_table, (next_random >> 16) % cum_table[V - 1], 0, (uint64_t)V);
+                    next_random = (next_random * 25214903917ULL + 11) & MOD;
+                    if (target == (uint32_t)w) continue;
+                    label = 0.0f;
+                }
+                const float* row = syn1neg + (int64_t)target * dim;
+                float f = dot_wave64(v, row, dim);
+                if (f <= -ORC_MAX_EXP || f >= ORC_MAX_EXP) continue;
+                f = exp_table[(int)((double)(f + (float)ORC_MAX_EXP) * exp_scale)];
+                float g = (label - f) * a;
+                for (int k = 0; k < dim; ++k) work[k] = fmaf(g, row[k], work[k]);   /* saxpy */
+            }
+            for (int k = 0; k < dim; ++k) v[k] = v[k] + work[k];                    /* lockf = 1.0 */
+        }
+        alpha -= alpha_delta;
+    }
+    free(work);
+}
+
+/* docs in CSR form: words of document d are words[doc_ptr[d] .. doc_ptr[d+1]) */
+void orc_d2v_infer(const float* syn1neg, const uint32_t* cum_table, int64_t V, const uint32_t* sample_int,
+                   int dim, const int64_t* doc_ptr, const int32_t* words, int64_t ndocs,
+                   const float* v0, const uint64_t* seeds, int epochs, float alpha, float min_alpha,
+                   int negative, double exp_scale, float* out) {
+    float table[ORC_EXP_TABLE_SIZE];
+    orc_exp_table(table);
+    for (int64_t d = 0; d < ndocs; ++d) {
+        infer_one(syn1neg, cum_table, V, sample_int, dim, words + doc_ptr[d], (int)(doc_ptr[d + 1] - doc_ptr[d]),
+                  v0 + d * dim, seeds[d], epochs, alpha, min_alpha, negative, exp_scale, table, out + d * dim);
+    }
+}
