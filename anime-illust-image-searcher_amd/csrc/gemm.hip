@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a, int tiles_m
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
                     f32x4 v = c + bv;
                     if constexpr (EPI == EPI_PATCH) {
+                        v = c * a.qscale + bv;
                         const int t = m % a.tokens;
                         const f32x4 pv = *reinterpret_cast<const f32x4*>(a.pos + (size_t)t * a.N + n);
                         *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + n) = v + pv;

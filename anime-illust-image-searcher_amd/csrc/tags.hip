@@ -144,7 +144,8 @@ __device__ void select_category(const float* __restrict__ probs, const int32_t* 
 __global__ __launch_bounds__(1024) void tagsel_kernel(const float* __restrict__ probs, int C, const int32_t* __restrict__ gidx,
                                                       int ng, const int32_t* __restrict__ cidx, int nc, int npad,
                                                       double g_thresh, int g_mcut, double c_thresh, int c_mcut,
-                                                      int32_t* __restrict__ counts, int32_t* __restrict__ ids, int row_cap,
+                                                      int32_t* __restrict__ counts, int counts_stride,
+                                                      int32_t* __restrict__ ids, int ids_stride, int row_cap,
                                                       double* __restrict__ thresh) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
     __shared__ double sh_d[17];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(1024) void tagsel_kernel(const float* __restrict__ 
     __shared__ double sh_thr[2];
     const int b = blockIdx.x;
     const float* __restrict__ row = probs + (int64_t)b * C;
-    int32_t* __restrict__ out = ids + (int64_t)b * row_cap;
+    int32_t* __restrict__ out = ids + (int64_t)b * ids_stride;
     int npg = 64;
     while (npg < ng) npg <<= 1;
     int npc = 64;
@@ -164,10 +165,12 @@ __global__ __launch_bounds__(1024) void tagsel_kernel(const float* __restrict__ 
     select_category(row, cidx, nc, npc, c_mcut != 0, c_thresh, true, keys, sh_d, sh_i, out + used, row_cap - used, &sh_cnt[1],
                     &sh_thr[1]);
     if (threadIdx.x == 0) {
-        counts[2 * b] = sh_cnt[0];
-        counts[2 * b + 1] = sh_cnt[1];
-        thresh[2 * b] = sh_thr[0];
-        thresh[2 * b + 1] = sh_thr[1];
+        counts[(int64_t)b * counts_stride] = sh_cnt[0];
+        counts[(int64_t)b * counts_stride + 1] = sh_cnt[1];
+        if (thresh) {
+            thresh[2 * b] = sh_thr[0];
+            thresh[2 * b + 1] = sh_thr[1];
+        }
     }
 }
 
@@ -245,7 +248,7 @@ int hipts_tagsel_run(hipts_tagsel_t* h, const float* probs, int probs_memspace, 
     }
     tagsel_kernel<<<batch, 1024, (size_t)h->npad * 8, s>>>(p_dev, h->C, h->gidx.as<int32_t>(), h->ng, h->cidx.as<int32_t>(), h->nc,
                                                            h->npad, general_thresh, general_mcut, character_thresh,
-                                                           character_mcut, cnt_dev, ids_dev, row_cap, thr_dev);
+                                                           character_mcut, cnt_dev, 2, ids_dev, row_cap, row_cap, thr_dev);
     HIPTS_LAUNCH_CHECK();
     if (host_out) {
         HIPTS_HIP(hipMemcpyAsync(counts_out, cnt_dev, (size_t)batch * 8, hipMemcpyDeviceToHost, s));
@@ -253,6 +256,17 @@ int hipts_tagsel_run(hipts_tagsel_t* h, const float* probs, int probs_memspace, 
         if (thresh_out) HIPTS_HIP(hipMemcpyAsync(thresh_out, thr_dev, (size_t)batch * 16, hipMemcpyDeviceToHost, s));
         HIPTS_HIP(hipStreamSynchronize(s));
     }
+    return HIPTS_OK;
+}
+
+int hipts_tagsel_run_rows(hipts_tagsel_t* h, const float* probs_device, int batch, double general_thresh, int general_mcut,
+                          double character_thresh, int character_mcut, int32_t* rows_device, int row_width, void* stream) {
+    HIPTS_REQUIRE(h && probs_device && rows_device && batch >= 1 && row_width >= 3, "hipts_tagsel_run_rows: bad arguments");
+    HIPTS_TRY(use_device(h->device));
+    tagsel_kernel<<<batch, 1024, (size_t)h->npad * 8, (hipStream_t)stream>>>(
+        probs_device, h->C, h->gidx.as<int32_t>(), h->ng, h->cidx.as<int32_t>(), h->nc, h->npad, general_thresh, general_mcut,
+        character_thresh, character_mcut, rows_device, row_width, rows_device + 2, row_width, row_width - 2, nullptr);
+    HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
 

@@ -35,12 +35,31 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
+enum ProfCat { PC_PATCHIFY = 0, PC_GEMM_PATCH, PC_LAYERNORM, PC_GEMM_QK, PC_GEMM_VT, PC_ATTENTION, PC_GEMM_RESID,
+               PC_GEMM_GELU, PC_POOL, PC_GEMM_HEAD, PC_OTHER, PC_COUNT };
+static_assert(PC_COUNT == HIPTS_VIT_PROF_CATEGORIES, "category count");
+static const char* const kProfNames[PC_COUNT] = {
+    "patchify_kernel", "gemm_kernel<EPI_PATCH>", "layernorm_kernel", "gemm_kernel<EPI_QK>", "gemm_kernel<EPI_VT>",
+    "attn_kernel", "gemm_kernel<EPI_RESID>", "gemm_kernel<EPI_GELU>", "pool_kernels", "gemm_kernel<EPI_HEAD>", "other"};
+
+struct ProfRec {
+    int cat;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+
 struct hipts_vit {
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;      // recycled events
+    double acc_ms[PC_COUNT] = {0}, acc_flops[PC_COUNT] = {0}, acc_bytes[PC_COUNT] = {0};
+    int64_t acc_n[PC_COUNT] = {0};
     int device = 0;
     hipts_vit_config_t cfg{};
     int grid = 0, tokens = 0, tokens_pad = 0, patch_k = 0;
     std::vector<Layer> layers;
-    DevBuf patch_w, patch_b, pos, norm_g, norm_b, head_w, head_b;
+    DevBuf patch_w, patch_w2, patch_b, patch_b_u8, pos, norm_g, norm_b, head_w, head_b;
+    std::vector<float> h_patch_bias, h_patch_rowsum;   // bias and sum_k W[n][k] (of the bf16 values)
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs;
@@ -64,16 +83,16 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
     const int px = (int)(tok % grid), py = (int)((tok / grid) % grid), b = (int)(tok / ((int64_t)grid * grid));
     const uint8_t* src = img + (((int64_t)b * size + (py * P + ky)) * size + px * P) * 3;
     bf16_t* dst = a0 + tok * (int64_t)(P * P * 3) + ky * P * 3;
-    for (int i = 0; i < P * 3; ++i) {
-        // ToTensor: u8 -> float32 / 255 ; Normalize(mean .5, std .5): (x - .5) / .5   (float32, torch op order)
-        float v = (float)src[i] / 255.0f;
-        v = (v - 0.5f) / 0.5f;
-        dst[i] = (bf16_t)v;
-    }
+    // The pixel is stored as the exact integer 0..255 (exact in bf16).  ToTensor + Normalize,
+    // x = (u/255 - .5)/.5 = u*(2/255) - 1, is affine, so it is applied to the fp32 accumulator in the
+    // GEMM epilogue: W.x = (2/255) W.u - rowsum(W).  Rounding x itself to bf16 would put the same
+    // 256 rounding errors on every token -- a systematic error that mean-pooling does not average out.
+    for (int i = 0; i < P * 3; ++i) dst[i] = (bf16_t)(float)src[i];
 }
 
 // x: float32 [B][3][S][S] (BGR, already normalised).  Channel c of the patch matrix (memory/RGB
-// order) is model channel 2 - c.
+// order) is model channel 2 - c.  Each value is split into bf16 hi + bf16 lo (row = [hi(K) | lo(K)],
+// multiplied against [W | W]) so the float32 input keeps ~16 significant bits.
 __global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ a0, int batch,
                                                            int size, int P, int grid) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -82,10 +101,16 @@ __global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restri
     const int ky = (int)(idx % P);
     const int64_t tok = idx / P;
     const int px = (int)(tok % grid), py = (int)((tok / grid) % grid), b = (int)(tok / ((int64_t)grid * grid));
-    bf16_t* dst = a0 + tok * (int64_t)(P * P * 3) + ky * P * 3;
+    const int K = P * P * 3;
+    bf16_t* dst = a0 + tok * (int64_t)(2 * K) + ky * P * 3;
     for (int c = 0; c < 3; ++c) {
         const float* src = x + (((int64_t)b * 3 + (2 - c)) * size + (py * P + ky)) * size + px * P;
-        for (int kx = 0; kx < P; ++kx) dst[kx * 3 + c] = (bf16_t)src[kx];
+        for (int kx = 0; kx < P; ++kx) {
+            const float v = src[kx];
+            const bf16_t hi = (bf16_t)v;
+            dst[kx * 3 + c] = hi;
+            dst[K + kx * 3 + c] = (bf16_t)(v - (float)hi);
+        }
     }
 }
 
@@ -303,7 +328,7 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     const size_t qkv_elems = B * cfg->heads * (size_t)h->tokens_pad * 64;
     h->pool_splits = h->tokens >= 64 ? 8 : 1;
     int st = HIPTS_OK;
-    if ((st = h->a0.alloc(M * h->patch_k * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
+    if ((st = h->a0.alloc(M * h->patch_k * 2 * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
         (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->vT.alloc(qkv_elems * 2)) ||
         (st = h->att.alloc(M * D * 2)) || (st = h->hmid.alloc(M * (size_t)cfg->mlp_dim * 2)) ||
         (st = h->pool_part.alloc(B * h->pool_splits * D * 4)) || (st = h->pooled2.alloc(B * 2 * D * 2)) ||
@@ -350,8 +375,26 @@ int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, i
                     for (int cr = 0; cr < 3; ++cr)
                         perm[(size_t)n * h->patch_k + (ky * P + kx) * 3 + cr] = data[(((size_t)n * 3 + (2 - cr)) * P + ky) * P + kx];
         st = set_bf16_matrix(h->patch_w, perm.data(), D, h->patch_k, round_up(D, 256));
+        if (st == HIPTS_OK) {
+            std::vector<float> dup((size_t)D * 2 * h->patch_k);
+            h->h_patch_rowsum.assign(D, 0.f);
+            for (int n = 0; n < D; ++n) {
+                double rs = 0.0;
+                for (int kk = 0; kk < h->patch_k; ++kk) {
+                    const uint32_t bits = (uint32_t)f32_to_bf16_rne(perm[(size_t)n * h->patch_k + kk]) << 16;
+                    float wv;
+                    memcpy(&wv, &bits, 4);
+                    rs += (double)wv;
+                }
+                h->h_patch_rowsum[n] = (float)rs;
+                memcpy(&dup[(size_t)n * 2 * h->patch_k], &perm[(size_t)n * h->patch_k], (size_t)h->patch_k * 4);
+                memcpy(&dup[(size_t)n * 2 * h->patch_k + h->patch_k], &perm[(size_t)n * h->patch_k], (size_t)h->patch_k * 4);
+            }
+            st = set_bf16_matrix(h->patch_w2, dup.data(), D, 2 * h->patch_k, round_up(D, 256));
+        }
     } else if (key == "patch_embed.proj.bias") {
         EXPECT(D);
+        h->h_patch_bias.assign(data, data + D);
         st = set_f32(h->patch_b, data, D);
     } else if (key == "pos_embed") {
         EXPECT((int64_t)h->tokens * D);
@@ -399,7 +442,19 @@ int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, i
     }
 #undef EXPECT
     if (st == HIPTS_OK) erase_missing(h, key);
+    if (st == HIPTS_OK && (key == "patch_embed.proj.weight" || key == "patch_embed.proj.bias") &&
+        !h->h_patch_bias.empty() && !h->h_patch_rowsum.empty()) {
+        std::vector<float> eff(D);
+        for (int n = 0; n < D; ++n) eff[n] = (float)((double)h->h_patch_bias[n] - (double)h->h_patch_rowsum[n]);
+        st = set_f32(h->patch_b_u8, eff.data(), D);   // bias of the u8 path: b - rowsum(W)
+    }
     return st;
+}
+
+int hipts_vit_profile_name(int category, char* buf, size_t n) {
+    HIPTS_REQUIRE(buf && n > 0 && category >= 0 && category < PC_COUNT, "bad category");
+    snprintf(buf, n, "%s", kProfNames[category]);
+    return HIPTS_OK;
 }
 
 int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops) {
@@ -413,6 +468,55 @@ int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops) {
 }  // extern "C"
 
 namespace {
+
+struct ProfScope {
+    hipts_vit* h;
+    hipStream_t s;
+    ProfRec r{};
+    bool on;
+    ProfScope(hipts_vit* h_, hipStream_t s_, int cat, double flops, double bytes) : h(h_), s(s_), on(h_->prof) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!h->pool.empty()) {
+                e = h->pool.back();
+                h->pool.pop_back();
+            } else if (hipEventCreate(&e) != hipSuccess) {
+                e = nullptr;
+            }
+            return e;
+        };
+        r.cat = cat;
+        r.flops = flops;
+        r.bytes = bytes;
+        r.a = get();
+        r.b = get();
+        if (r.a) (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        if (r.b) (void)hipEventRecord(r.b, s);
+        h->recs.push_back(r);
+    }
+};
+
+int prof_resolve(hipts_vit* h) {
+    for (auto& r : h->recs) {
+        if (r.a && r.b) {
+            HIPTS_HIP(hipEventSynchronize(r.b));
+            float ms = 0.f;
+            HIPTS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+            h->acc_ms[r.cat] += ms;
+            h->acc_n[r.cat] += 1;
+            h->acc_flops[r.cat] += r.flops;
+            h->acc_bytes[r.cat] += r.bytes;
+        }
+        if (r.a) h->pool.push_back(r.a);
+        if (r.b) h->pool.push_back(r.b);
+    }
+    h->recs.clear();
+    return HIPTS_OK;
+}
 
 int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u8, int batch, float* logits_out,
                      float* probs_out, int out_memspace, hipStream_t s) {
@@ -433,7 +537,9 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
         in_dev = h->img_in.p;
     }
+    const double dM = (double)M, dD = (double)D, dMlp = (double)c.mlp_dim, dT = (double)T;
     {
+        ProfScope ps(h, s, PC_PATCHIFY, 0.0, dM * h->patch_k * (is_u8 ? 3.0 : 6.0));
         const int64_t total = (int64_t)M * P;
         const int blocks = ceil_div(total, 256);
         if (is_u8)
@@ -445,51 +551,85 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     GemmArgs g;
     // patch embedding: x = A0 W^T + b + pos
     g = GemmArgs{};
-    g.A = h->a0.as<bf16_t>(); g.W = h->patch_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->patch_k;
-    g.bias = h->patch_b.as<float>(); g.out_f32 = h->x.as<float>(); g.pos = h->pos.as<float>(); g.tokens = T;
-    HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+    g.A = h->a0.as<bf16_t>(); g.M = M; g.N = D; g.out_f32 = h->x.as<float>(); g.pos = h->pos.as<float>(); g.tokens = T;
+    if (is_u8) {   // exact integer pixels; affine normalisation folded into the epilogue
+        g.W = h->patch_w.as<bf16_t>(); g.K = h->patch_k; g.bias = h->patch_b_u8.as<float>(); g.qscale = 2.0f / 255.0f;
+    } else {       // hi | lo split of the float input against [W | W]
+        g.W = h->patch_w2.as<bf16_t>(); g.K = 2 * h->patch_k; g.bias = h->patch_b.as<float>(); g.qscale = 1.0f;
+    }
+    {
+        ProfScope ps(h, s, PC_GEMM_PATCH, 2.0 * dM * dD * h->patch_k, dM * h->patch_k * 2 + dM * dD * 4);
+        HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+    }
 
     const int ln_blocks = ceil_div(M, 4);
     for (int li = 0; li < c.depth; ++li) {
         Layer& L = h->layers[li];
-        layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
-        HIPTS_LAUNCH_CHECK();
+        {
+            ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
+            layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            HIPTS_LAUNCH_CHECK();
+        }
         // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled by head_dim^-0.5 = 0.125 (exact)
         g = GemmArgs{};
         g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
         g.bias = L.qkv_b.as<float>(); g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D; g.qscale = 0.125f;
-        HIPTS_TRY(launch_gemm(EPI_QK, g, s));
+        {
+            ProfScope ps(h, s, PC_GEMM_QK, 2.0 * dM * 2 * dD * dD, dM * dD * 2 + dM * 2 * dD * 2);
+            HIPTS_TRY(launch_gemm(EPI_QK, g, s));
+        }
         // v, written transposed
         g = GemmArgs{};
         g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
         g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = h->vT.as<bf16_t>();
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
-        HIPTS_TRY(launch_gemm(EPI_VT, g, s));
-        HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, s));
+        {
+            ProfScope ps(h, s, PC_GEMM_VT, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 2);
+            HIPTS_TRY(launch_gemm(EPI_VT, g, s));
+        }
+        {
+            ProfScope ps(h, s, PC_ATTENTION, 4.0 * batch * H * dT * dT * 64, dM * dD * 2 * 4);
+            HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, s));
+        }
         // x += att Wp^T + b
         g = GemmArgs{};
         g.A = h->att.as<bf16_t>(); g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
         g.bias = L.proj_b.as<float>(); g.out_f32 = h->x.as<float>();
-        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
-        layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
-        HIPTS_LAUNCH_CHECK();
+        {
+            ProfScope ps(h, s, PC_GEMM_RESID, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 8);
+            HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        }
+        {
+            ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
+            layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            HIPTS_LAUNCH_CHECK();
+        }
         g = GemmArgs{};
         g.A = h->xn.as<bf16_t>(); g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
         g.bias = L.fc1_b.as<float>(); g.out_bf16 = h->hmid.as<bf16_t>(); g.gelu_tanh = c.gelu_tanh;
-        HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
+        {
+            ProfScope ps(h, s, PC_GEMM_GELU, 2.0 * dM * dD * dMlp, dM * dD * 2 + dM * dMlp * 2);
+            HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
+        }
         g = GemmArgs{};
         g.A = h->hmid.as<bf16_t>(); g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
         g.bias = L.fc2_b.as<float>(); g.out_f32 = h->x.as<float>();
-        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        {
+            ProfScope ps(h, s, PC_GEMM_RESID, 2.0 * dM * dD * dMlp, dM * dMlp * 2 + dM * dD * 8);
+            HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        }
     }
     // final norm + mean pool (+ hi/lo split)
+    {
+    ProfScope ps(h, s, PC_POOL, 0.0, dM * dD * 4);
     pool_partial_kernel<<<dim3(h->pool_splits, batch), 256, 0, s>>>(h->x.as<float>(), h->pool_part.as<float>(), T, D, c.ln_eps,
                                                                    c.pool_then_norm ? 0 : 1, h->pool_splits);
     HIPTS_LAUNCH_CHECK();
     pool_finalize_kernel<<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
                                                h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
     HIPTS_LAUNCH_CHECK();
+    }
     // head (+ sigmoid, tagging.py:176)
     const bool dev_out = out_memspace == HIPTS_DEVICE;
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
@@ -497,7 +637,10 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     g = GemmArgs{};
     g.A = h->pooled2.as<bf16_t>(); g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
     g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = (probs_out || !dev_out) ? pr : nullptr;
-    HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
+    {
+        ProfScope ps(h, s, PC_GEMM_HEAD, 2.0 * batch * dD * c.num_classes, (double)c.num_classes * 2 * dD * 2);
+        HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
+    }
     if (!dev_out) {
         const size_t bytes = (size_t)batch * c.num_classes * 4;
         if (logits_out) HIPTS_HIP(hipMemcpyAsync(logits_out, lg, bytes, hipMemcpyDeviceToHost, s));
@@ -510,6 +653,30 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
 }  // namespace
 
 extern "C" {
+
+int hipts_vit_profile_enable(hipts_vit_t* h, int enable) {
+    HIPTS_REQUIRE(h, "null handle");
+    HIPTS_TRY(use_device(h->device));
+    HIPTS_TRY(prof_resolve(h));
+    for (int i = 0; i < PC_COUNT; ++i) {
+        h->acc_ms[i] = h->acc_flops[i] = h->acc_bytes[i] = 0.0;
+        h->acc_n[i] = 0;
+    }
+    h->prof = enable != 0;
+    return HIPTS_OK;
+}
+
+int hipts_vit_profile_read(hipts_vit_t* h, int category, double* total_ms, int64_t* launches, double* total_flops,
+                           double* total_bytes) {
+    HIPTS_REQUIRE(h && category >= 0 && category < PC_COUNT, "bad category");
+    HIPTS_TRY(use_device(h->device));
+    HIPTS_TRY(prof_resolve(h));
+    if (total_ms) *total_ms = h->acc_ms[category];
+    if (launches) *launches = h->acc_n[category];
+    if (total_flops) *total_flops = h->acc_flops[category];
+    if (total_bytes) *total_bytes = h->acc_bytes[category];
+    return HIPTS_OK;
+}
 
 int hipts_vit_forward_u8(hipts_vit_t* h, const uint8_t* images, int images_memspace, int batch, float* logits_out,
                          float* probs_out, int out_memspace, void* stream) {

@@ -14,7 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // accumulate on MFMA, fused epilogue.  K % 64 == 0; W must be allocated (zero padded) up to a
 // multiple of 256 rows; A rows beyond M are never read (row index clamped), stores are masked.
 enum GemmEpilogue {
-    EPI_PATCH = 0,   // x[m][n]  = acc + bias[n] + pos[(m % tokens)][n]                 (fp32 out)
+    EPI_PATCH = 0,   // x[m][n]  = acc * qscale + bias[n] + pos[(m % tokens)][n]        (fp32 out)
     EPI_QK = 1,      // q/k[b][h][t][d] = bf16((acc + bias[n]) * (n < dim ? qscale : 1)) (n in [0, 2*dim))
     EPI_VT = 2,      // vT[b][h][d][t] = bf16(acc + bias[dim2 + n])                      (n in [0, dim))
     EPI_RESID = 3,   // x[m][n] += acc + bias[n]                                        (fp32 in/out)

@@ -39,10 +39,14 @@ _SIGNATURES = {
     "hipts_vit_forward_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_vit_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_vit_flops_per_image": [c_void_p, POINTER(c_double)],
+    "hipts_vit_profile_enable": [c_void_p, c_int],
+    "hipts_vit_profile_read": [c_void_p, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
+    "hipts_vit_profile_name": [c_int, c_char_p, c_size_t],
     "hipts_tagsel_create": [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)],
     "hipts_tagsel_destroy": [c_void_p],
     "hipts_tagsel_run": [c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_double, c_int, c_void_p, c_void_p, c_int,
                          c_void_p, c_int, c_void_p],
+    "hipts_tagsel_run_rows": [c_void_p, c_void_p, c_int, c_double, c_int, c_double, c_int, c_void_p, c_int, c_void_p],
     "hipts_bm25_build": [c_void_p, c_void_p, c_int64, c_int32, c_int, POINTER(c_void_p)],
     "hipts_bm25_destroy": [c_void_p],
     "hipts_bm25_info": [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_double)],
@@ -79,13 +83,29 @@ def load():
         raise ImportError(
             "libhip_tagsearch.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C anime-illust-image-searcher_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+    # Device pointers are only meaningful inside ONE runtime instance, so torch must be imported
+    # first: the dynamic linker then binds this library's libamdhip64.so.7 dependency to the copy
+    # torch already loaded instead of opening /opt/rocm's as a second runtime.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    _check_single_hip_runtime()
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the header and the library disagree
         fn.argtypes = argtypes
         fn.restype = c_int
     _lib = lib
     return lib
+
+
+def _check_single_hip_runtime():
+    try:
+        paths = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise ImportError("two HIP runtimes are loaded in this process (%s): import torch before anything that "
+                          "links /opt/rocm's libamdhip64" % ", ".join(sorted(paths)))
 
 
 def last_error() -> str:

@@ -121,6 +121,15 @@ class TagSelector:
                   row_cap, _lib.ptr(thr), _lib.HOST, _lib.current_stream_ptr())
         return counts, ids, thr
 
+    def run_device(self, probs, rows, general_thresh=0.3, general_mcut=True, character_thresh=0.3, character_mcut=True):
+        """Device-resident variant: `rows` is an int32 device tensor [B, 2 + row_cap]; row b receives
+        {#general, #character, ids...} -- the fixed-width tag row that is all-gathered across ranks."""
+        B, width = int(rows.shape[0]), int(rows.shape[1])
+        assert rows.is_cuda and rows.is_contiguous() and width > 2
+        _lib.call("hipts_tagsel_run_rows", self._h, _lib.ptr(probs), B, c_double(general_thresh), int(general_mcut),
+                  c_double(character_thresh), int(character_mcut), _lib.ptr(rows), width, _lib.current_stream_ptr())
+        return rows
+
     def close(self):
         if self._h:
             _lib.call("hipts_tagsel_destroy", self._h)

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json):
+images/sec tagged (ViT-B/16 @448 forward + sigmoid + MCut tag selection, bf16 MFMA, batch 64 per
+GPU, inputs resident in HBM) on N GPUs of one node, plus -- on rank 0 at N=1 -- top-k queries/sec
+over a 100k-document index and the CPU restatement ("port") timed on the host cores.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the tagging path over one batch of 64 synthetic images per rank
+(config.workload).  Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "anime-illust-image-searcher_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+BATCH = 64
+ROW_WIDTH = 2 + 254                 # int32 {n_general, n_character, ids[254]} per image (1 KiB rows)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline_vit(cfg, weights, n_images=4, budget_s=20.0):
+    """The oracle (torch CPU float32 restatement of the same forward) on a bounded sample."""
+    from oracle import vit as ovit
+    from hiptagsearch import synth
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    w = ovit.to_torch(weights)
+    imgs = synth.images_u8(n_images, cfg["image_size"], seed=99)
+    x = ovit.preprocess_u8_nhwc(imgs)
+    kw = dict(patch=cfg["patch"], heads=cfg["heads"], eps=cfg["ln_eps"], gelu_kind="tanh" if cfg["gelu_tanh"] else "erf")
+    ovit.vit_forward(w, x[:1], **kw)      # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        torch.sigmoid(ovit.vit_forward(w, x, **kw))
+        done += n_images
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 4 * n_images:
+            break
+    return {"value": done / el, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d images (ViT-B/16@448 fp32 torch-CPU oracle forward+sigmoid, batch %d), %.1f s" % (done, n_images, el)}
+
+
+def query_section(device):
+    """top-k queries/sec over a 100k-document index (config[2]) + its CPU port baseline."""
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from oracle import bm25 as obm25
+    from oracle import search as osearch
+    D, V, K, NQ, TOPK = 100_000, 10_000, 300, 1024, 100
+    t0 = time.perf_counter()
+    ptr, terms = synth.tag_corpus(D, V, seed=42)
+    rows = synth.index_vectors(D, K, seed=46)
+    bm = BM25Index(ptr, terms, V, device)
+    idx = Similarity("bench", None, K, device, capacity=D)
+    idx.add_matrix(rows)
+    eng = SearchEngine(None, idx, {}, bm, [])
+    qs = [dict(q) for q in synth.queries(NQ, V, seed=43)]
+    rng = np.random.default_rng(5)
+    qv = rng.standard_normal((NQ, K))
+    qv = (qv / np.linalg.norm(qv, axis=1, keepdims=True)).astype(np.float32)
+    log("query corpus built in %.1f s" % (time.perf_counter() - t0))
+    chunk = 256
+    eng.score_topk(qs[:chunk], qv[:chunk], TOPK)                        # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(0, NQ, chunk):
+        ids, vals = eng.score_topk(qs[s:s + chunk], qv[s:s + chunk], TOPK)
+    torch.cuda.synchronize()
+    batched = NQ / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for i in range(64):
+        eng.score_topk(qs[i:i + 1], qv[i:i + 1], TOPK)
+    torch.cuda.synchronize()
+    single = 64 / (time.perf_counter() - t0)
+    # CPU port on a bounded sample (vectorised numpy BM25 + fma-chain similarity + stable sort)
+    e = bm.export()
+    nq_cpu = 4
+    t0 = time.perf_counter()
+    for i in range(nq_cpu):
+        q = qs[i]
+        b = obm25.bm25_score_csr(e["csr_ptr"], e["csr_term"], e["csr_tf"], e["idf"], bm.avgdl, e["doc_len"], list(q.keys()), list(q.values()))
+        s = osearch.similarity(rows, qv[i])
+        f = osearch.combine(b, s)
+        wi, wv = osearch.topk(f, TOPK)
+    cpu_qps = nq_cpu / (time.perf_counter() - t0)
+    gi, _ = eng.score_topk(qs[nq_cpu - 1:nq_cpu], qv[nq_cpu - 1:nq_cpu], TOPK)
+    assert np.array_equal(gi[0], wi), "GPU/CPU top-k mismatch"
+    bytes_per_query = D * K * 4 + bm.nnz * 8 + D * (4 + 8 + 4 + 8 + 8)
+    return {"metric": "top-100 queries/sec over 100k-doc index (BM25 + 300-d index product, fused)",
+            "batched_qps": batched, "single_query_qps": single, "batch": chunk,
+            "algorithmic_bytes_per_query": bytes_per_query,
+            "cpu_port_qps": cpu_qps, "cpu_port_sample": "%d queries, numpy CSR BM25 + C fma-chain + lexsort, 1 thread" % nq_cpu}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-query", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import hiptagsearch  # noqa: F401  (raises if libhip_tagsearch.so is missing: no CPU fallback)
+    from hiptagsearch import synth
+    from hiptagsearch.tagger import TagSelector, ViTTagger
+    from hiptagsearch import _lib
+    import ctypes
+
+    cfg = dict(synth.VIT_B16_448)
+    weights = synth.vit_weights(cfg, seed=0)
+    model = ViTTagger(cfg, weights, max_batch=BATCH, device=local_rank)
+    names, cat = synth.label_table(cfg["num_classes"])
+    selector = TagSelector(cat, max_batch=BATCH, device=local_rank)
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (BATCH, cfg["image_size"], cfg["image_size"], 3), dtype=torch.uint8, device=dev, generator=gen)
+    probs = torch.empty((BATCH, cfg["num_classes"]), dtype=torch.float32, device=dev)
+    rows = torch.zeros((BATCH, ROW_WIDTH), dtype=torch.int32, device=dev)
+    gathered = torch.empty((world * BATCH, ROW_WIDTH), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        model.forward_u8(images, probs=probs, want="probs")            # patchify ... head + sigmoid
+        selector.run_device(probs, rows)                               # MCut selection -> fixed-width tag rows
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, rows)                # RCCL: rank order == file order
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.call("hipts_vit_profile_enable", model._h, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time from the HIP events recorded on the launch stream during the timed steps
+    cats = []
+    for c in range(11):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        _lib.call("hipts_vit_profile_read", model._h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+        name = ctypes.create_string_buffer(64)
+        _lib.call("hipts_vit_profile_name", c, name, 64)
+        if n.value:
+            cats.append({"kernel": name.value.decode(), "launches": n.value, "total_ms": ms.value,
+                         "avg_us": 1e3 * ms.value / n.value, "tflops": fl.value / (ms.value * 1e9) if ms.value else 0.0,
+                         "gbs": by.value / (ms.value * 1e6) if ms.value else 0.0, "flops": fl.value, "bytes": by.value})
+    _lib.call("hipts_vit_profile_enable", model._h, 0)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    for c in cats:
+        log("%-26s n=%5d  avg %9.1f us  %8.1f TFLOP/s  %8.1f GB/s  (%.1f%% of step time)" % (
+            c["kernel"], c["launches"], c["avg_us"], c["tflops"], c["gbs"], 100 * c["total_ms"] / (elapsed * 1e3)))
+    gemms = [c for c in cats if c["kernel"].startswith("gemm_kernel")]
+    dom = max(gemms, key=lambda c: c["total_ms"])
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
+                "all_gemm_tflops": sum(c["flops"] for c in gemms) / (sum(c["total_ms"] for c in gemms) * 1e9)}
+    imgs_per_s = world * BATCH * args.steps / elapsed
+    flops_img = model.flops_per_image()
+    result = {
+        "metric": "images/sec tagged (ViT fwd)", "value": imgs_per_s, "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "wd-tagger ViT-B/16 448px bf16 forward + sigmoid + MCut tag selection, batch 64 per GPU, "
+                               "u8 NHWC images resident in HBM (BASELINE.json configs[1])",
+                   "batch_per_gpu": BATCH, "image": "448x448x3 u8", "classes": cfg["num_classes"],
+                   "parallelism": "dp%d (images sharded by rank, RCCL all-gather of tag rows)" % world if world > 1 else "single GPU",
+                   "flops_per_image": flops_img},
+        "model_tflops": imgs_per_s * flops_img / 1e12 / world,
+        "model_mfma_frac": imgs_per_s * flops_img / 1e12 / world / MFMA_BF16_PEAK_TFLOPS,
+        "roofline": roofline,
+        "kernels": [{k: c[k] for k in ("kernel", "launches", "avg_us", "tflops", "gbs")} for c in cats],
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_vit(cfg, weights)
+        result["cpu_baseline"]["published_reference"] = "0.59 images/sec (README: EVA02-L tagger on Ryzen 7 5700X; different model and hardware)"
+    if world == 1 and not args.no_query:
+        try:
+            result["query"] = query_section(local_rank)
+        except Exception as e:   # the headline line must still be printed
+            result["query"] = {"error": repr(e)}
+    if world > 1:
+        dist.destroy_process_group()
+    print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

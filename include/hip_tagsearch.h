@@ -85,6 +85,16 @@ int hipts_vit_forward_u8(hipts_vit_t* h, const uint8_t* images, int images_memsp
  * tagging.py:164 stacks and :174 passes to model.forward. */
 int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int batch,
                           float* logits_out, float* probs_out, int out_memspace, void* stream);
+/* Per-kernel timing for roofline accounting (bench.py): while enabled, every kernel launch of
+ * forward() is bracketed by HIP events on the stream it is launched on.  read() resolves them
+ * (synchronises) and returns, for one kernel category, the summed device time, the number of
+ * launches and the ALGORITHMIC flops / bytes those launches stand for.
+ * Categories are numbered 0 .. HIPTS_VIT_PROF_CATEGORIES-1; name() gives the kernel's name. */
+#define HIPTS_VIT_PROF_CATEGORIES 11
+int hipts_vit_profile_enable(hipts_vit_t* h, int enable);
+int hipts_vit_profile_read(hipts_vit_t* h, int category, double* total_ms, int64_t* launches,
+                           double* total_flops, double* total_bytes);
+int hipts_vit_profile_name(int category, char* buf, size_t n);
 /* algorithmic FLOPs of one image's forward (2*M*N*K of every contraction), for roofline use */
 int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops);
 
@@ -105,6 +115,12 @@ int hipts_tagsel_run(hipts_tagsel_t* h, const float* probs, int probs_memspace, 
                      double general_thresh, int general_mcut, double character_thresh, int character_mcut,
                      int32_t* counts_out, int32_t* ids_out, int row_cap, double* thresh_out,
                      int out_memspace, void* stream);
+
+/* Device-resident variant producing the fixed-width tag rows that ranks all-gather: row b of
+ * rows_device (int32 [batch][row_width]) = {#general, #character, ids[row_width-2]}. */
+int hipts_tagsel_run_rows(hipts_tagsel_t* h, const float* probs_device, int batch,
+                          double general_thresh, int general_mcut, double character_thresh, int character_mcut,
+                          int32_t* rows_device, int row_width, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BM25.   build replaces gen_and_save_bm25_index                            genmodel.py:51-99

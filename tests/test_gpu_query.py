@@ -1,0 +1,195 @@
+"""GPU parity: query-scoring path through the C ABI vs the CPU oracle.
+Bit-exact for float64 BM25, float32 index products (k-ordered fma chain) and ranking."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fh(x):
+    return float.fromhex(x)
+
+
+@pytest.fixture(scope="module")
+def corpus20k():
+    from hiptagsearch import synth
+    ptr, terms = synth.tag_corpus(D=20_000, V=3_000, seed=42)
+    return ptr, terms, 3_000
+
+
+def _oracle_index(ptr, terms, V):
+    """Build the oracle's BM25 objects from a CSR of token ids (ids are their own dictionary ids)."""
+    from oracle import bm25 as obm25
+    docs = [[str(t) for t in terms[ptr[d]:ptr[d + 1]]] for d in range(len(ptr) - 1)]
+    token2id = {str(i): i for i in range(V)}
+    return obm25.bm25_build(docs, token2id)
+
+
+# --------------------------------------------------------------------------------- BM25
+@pytest.mark.parametrize("case", ["tiny", "d1000"])
+def test_bm25_golden_bit_exact(golden_dir, case):
+    """Reference-captured vectors (genmodel.py / webui.py numpy code) through the HIP kernel."""
+    from hiptagsearch.bm25 import BM25Index
+    g1 = json.load(open(os.path.join(golden_dir, "g1_bm25_build.json")))[case]
+    g2 = json.load(open(os.path.join(golden_dir, "g2_bm25_score.json")))[case]
+    idx = BM25Index.from_tokens(g1["docs"], g1["token2id"])
+    corpus, idf, avgdl, D, dl = idx.reference_objects()
+    assert [{str(k): v for k, v in d.items()} for d in corpus] == g1["corpus"]
+    assert list(idf.keys()) == g1["idf_keys"]
+    assert [float(v).hex() for v in idf.values()] == g1["idf_hex"]
+    assert float(avgdl).hex() == g1["avgdl_hex"] and D == g1["D"]
+    assert dl.tolist() == g1["doc_lengths"] and str(dl.dtype) == g1["doc_lengths_dtype"]
+    queries = [{int(k): float(v) for k, v in q} for q in g2["queries"]]
+    got = idx.score(queries)
+    for i, want_hex in enumerate(g2["scores_hex"]):
+        want = np.array([fh(x) for x in want_hex])
+        assert got[i].tobytes() == want.tobytes(), "query %d" % i
+
+
+def test_bm25_20k_bit_exact(corpus20k):
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from oracle import bm25 as obm25
+    ptr, terms, V = corpus20k
+    idx = BM25Index(ptr, terms, V)
+    corpus, idf, avgdl, D, dl = _oracle_index(ptr, terms, V)
+    e = idx.export()
+    optr, oterm, otf = obm25.to_csr(corpus)
+    np.testing.assert_array_equal(e["csr_ptr"], optr)
+    np.testing.assert_array_equal(e["csr_term"], oterm)
+    np.testing.assert_array_equal(e["csr_tf"], otf)
+    np.testing.assert_array_equal(e["doc_len"], dl)
+    assert float(idx.avgdl).hex() == float(avgdl).hex()
+    idf_arr = np.zeros(V)
+    for k, v in idf.items():
+        idf_arr[k] = v
+    assert e["idf"].tobytes() == idf_arr.tobytes()          # numpy-evaluated idf installed by the wrapper
+    qs = synth.queries(64, V, seed=43, head=500)
+    got = idx.score([dict(q) for q in qs])
+    for i, q in enumerate(qs):
+        want = obm25.bm25_score_csr(optr, oterm, otf, idf_arr, avgdl, dl, [t for t, _ in q], [w for _, w in q])
+        assert got[i].tobytes() == want.tobytes(), "query %d: %r" % (i, q)
+
+
+def test_bm25_libm_idf_within_one_ulp(corpus20k):
+    from hiptagsearch.bm25 import BM25Index
+    ptr, terms, V = corpus20k
+    a = BM25Index(ptr, terms, V, numpy_idf=False).export()["idf"]
+    b = BM25Index(ptr, terms, V, numpy_idf=True).export()["idf"]
+    nz = b != 0
+    assert np.max(np.abs(a[nz] - b[nz]) / b[nz]) <= 2.3e-16      # tolerance: 1 ulp of float64
+
+
+# --------------------------------------------------------------------------------- similarity
+@pytest.mark.parametrize("D,K,nq", [(1000, 300, 1), (4099, 300, 5), (3000, 768, 33), (64, 8, 2), (31, 12, 1)])
+def test_similarity_bit_exact(D, K, nq):
+    from hiptagsearch.index import Similarity
+    from oracle import search as osearch
+    rng = np.random.default_rng(D + K)
+    rows = rng.standard_normal((D, K)).astype(np.float32)
+    q = rng.standard_normal((nq, K)).astype(np.float32)
+    idx = Similarity("t", None, K)
+    idx.add_matrix(rows[: D // 2])
+    idx.add_matrix(rows[D // 2:])                       # exercises growth
+    assert len(idx) == D
+    np.testing.assert_array_equal(idx.vector_by_id(D - 1), rows[D - 1])
+    got = idx.query(q)
+    for i in range(nq):
+        want = osearch.similarity(rows, q[i])
+        assert got[i].tobytes() == want.tobytes(), "query %d" % i
+
+
+def test_similarity_gensim_forms():
+    """Sparse list-of-tuples documents are unit-normalised on add (gen_cfeatures.py:310-314), ndarray
+    documents are stored as given (genmodel.py:171-173)."""
+    from hiptagsearch.index import Similarity
+    v = np.arange(1, 9, dtype=np.float32)
+    a = Similarity("a", [v], 8)
+    b = Similarity("b", [[(i, float(x)) for i, x in enumerate(v)]], 8)
+    np.testing.assert_array_equal(a.vector_by_id(0), v)
+    np.testing.assert_allclose(np.linalg.norm(b.vector_by_id(0)), 1.0, rtol=1e-6)
+    a.add_documents([v * 2])
+    assert len(a) == 2
+
+
+# --------------------------------------------------------------------------------- top-k
+def _rank_oracle(vals, k):
+    from oracle import search as osearch
+    return osearch.topk(vals, k)
+
+
+@pytest.mark.parametrize("n,k", [(100_000, 100), (100_000, 1024), (5000, 800), (70, 100), (1, 1)])
+def test_topk_random(n, k):
+    import torch
+    from hiptagsearch import _lib
+    rng = np.random.default_rng(n + k)
+    vals = rng.random((3, n))
+    vals[1, rng.integers(0, n, n // 3)] = -np.inf
+    vals[2] = np.round(vals[2], 2)                       # massive exact ties
+    dev = torch.from_numpy(vals).cuda()
+    ids = np.empty((3, k), np.int32)
+    out = np.empty((3, k), np.float64)
+    _lib.call("hipts_topk", _lib.ptr(dev), 3, _lib.c_int64(n), k, _lib.ptr(ids), _lib.ptr(out), _lib.HOST, 0, None)
+    kk = min(k, n)
+    for r in range(3):
+        wi, wv = _rank_oracle(vals[r], kk)
+        np.testing.assert_array_equal(ids[r, :kk], wi)
+        assert out[r, :kk].tobytes() == wv.tobytes()
+        assert (ids[r, kk:] == -1).all()
+
+
+def test_topk_all_equal_and_all_inf():
+    import torch
+    from hiptagsearch import _lib
+    n, k = 50_000, 700
+    vals = np.stack([np.full(n, 0.25), np.full(n, -np.inf), np.concatenate([np.zeros(n - 5), -np.zeros(5)])])
+    dev = torch.from_numpy(vals).cuda()
+    ids = np.empty((3, k), np.int32)
+    out = np.empty((3, k), np.float64)
+    _lib.call("hipts_topk", _lib.ptr(dev), 3, _lib.c_int64(n), k, _lib.ptr(ids), _lib.ptr(out), _lib.HOST, 0, None)
+    for r in range(3):
+        np.testing.assert_array_equal(ids[r], np.arange(k))      # all tied -> ascending doc id
+
+
+# --------------------------------------------------------------------------------- fused search
+def test_search_rank_equal(corpus20k):
+    """hipts_search (BM25 + index product + normalise + combine + top-k) vs the oracle restatement of
+    webui.py:352-383,191-192: identical ids, bit-identical scores."""
+    import torch
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from oracle import bm25 as obm25
+    from oracle import search as osearch
+    ptr, terms, V = corpus20k
+    D = len(ptr) - 1
+    rows = synth.index_vectors(D, 300, seed=46)
+    bm = BM25Index(ptr, terms, V)
+    index = Similarity("idx", None, 300, capacity=D)
+    index.add_matrix(rows)
+    eng = SearchEngine(None, index, {}, bm, [])
+    corpus, idf, avgdl, _, dl = _oracle_index(ptr, terms, V)
+    optr, oterm, otf = obm25.to_csr(corpus)
+    idf_arr = np.zeros(V)
+    for kk_, v in idf.items():
+        idf_arr[kk_] = v
+    qs = synth.queries(40, V, seed=44, head=300)
+    rng = np.random.default_rng(5)
+    qv = rng.standard_normal((len(qs), 300))
+    qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+    k = 100
+    final_dev = torch.empty((len(qs), D), dtype=torch.float64, device="cuda")
+    ids, vals = eng.score_topk([dict(q) for q in qs], qv, k, final_out=final_dev)
+    final_host = final_dev.cpu().numpy()
+    for i, q in enumerate(qs):
+        b = obm25.bm25_score_csr(optr, oterm, otf, idf_arr, avgdl, dl, [t for t, _ in q], [w for _, w in q])
+        s = osearch.similarity(rows, qv[i].astype(np.float32))
+        final = osearch.combine(b, s)
+        assert final_host[i].tobytes() == final.tobytes(), "query %d combined scores" % i
+        wi, wv = osearch.topk(final, k)
+        np.testing.assert_array_equal(ids[i], wi)
+        assert vals[i].tobytes() == wv.tobytes()
