@@ -5,6 +5,7 @@
 // Flash-style: K / V^T tiles of 64 keys are staged through LDS (registers -> ds_write, next
 // tile's global loads issued before the current tile's math), scores never leave registers.
 //
+// (q arrives pre-scaled by head_dim^-0.5 * log2 e, so exp2 of the raw scores is the softmax numerator.)
 //   S^T = K Q^T      v_mfma_f32_32x32x16_bf16, A = K tile rows (keys), B = Q^T held in registers.
 //                    The accumulator then has the QUERY on the lane (column) and 16 of the 32 keys in
 //                    its registers, so the online softmax is lane-local (one cross-half exchange).
@@ -27,9 +28,67 @@ constexpr int VS = 136;              // LDS bytes per V^T row (64 key* 2 B + 8)
 constexpr int K_BYTES = KV * KS;     // 9216
 constexpr int V_BYTES = 64 * VS;     // 8704
 constexpr int STAGE = K_BYTES + V_BYTES;
-constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// One 64-key tile for one wave (32 queries).  q is pre-scaled by head_dim^-0.5 * log2(e) in the QK
+// GEMM epilogue, so scores are already in the base-2 domain.  MASK (last tile only): keys >= tokens
+// start their accumulator at -inf, which the MFMA carries through (no per-score compare/select).
+template <bool MASK>
+__device__ __forceinline__ void attn_tile(const char* __restrict__ st, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[4],
+                                          f32x16 (&o)[2], float& m_run, float& l_run) {
+    f32x16 sacc[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (MASK) sacc[g][i] = (kv0 + g * 32 + crow(i, h) >= tokens) ? -INFINITY : 0.f;
+            else sacc[g][i] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
+            sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[g], 0, 0, 0);
+        }
+    }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(sacc[0][i], sacc[1][i]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float lsum0 = 0.f, lsum1 = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
+            if (i & 1) lsum1 += p; else lsum0 += p;
+            pf[g][i >> 3][i & 7] = (bf16_t)p;
+        }
+    l_run = l_run * alpha + (lsum0 + lsum1);
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const char* vrow = st + K_BYTES + (blk * 32 + r) * VS;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int key = g * 32 + 16 * s2 + 4 * h;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + key * 2);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (key + 8) * 2);
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][s2], o[blk], 0, 0, 0);
+            }
+    }
+}
 
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
@@ -51,28 +110,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
 
-    // staging assignment: K tile = 64 rows x 8 chunks of 16 B, V^T tile likewise; 2 chunks each per thread
-    const bf16_t* kbase = k + (size_t)bh * tokens_pad * 64;
-    const bf16_t* vbase = vT + (size_t)bh * 64 * tokens_pad;
-    uint4 kreg[2], vreg[2];
-    auto load_tile = [&](int kv0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, col = c & 7;
-            kreg[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)(kv0 + row) * 64 + col * 8);
-            vreg[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * tokens_pad + kv0 + col * 8);
-        }
-    };
-    auto write_tile = [&](char* st) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, col = c & 7;
-            *reinterpret_cast<uint4*>(st + row * KS + col * 16) = kreg[i];
-            uint2* vp = reinterpret_cast<uint2*>(st + K_BYTES + row * VS + col * 16);
-            vp[0] = make_uint2(vreg[i].x, vreg[i].y);
-            vp[1] = make_uint2(vreg[i].z, vreg[i].w);
-        }
-    };
+    // staging: K tile = 64 rows x 8 chunks of 16 B, V^T tile likewise; two chunks of each per thread
+    const int row0 = tid >> 3, col = tid & 7;            // chunk tid and tid + 256 (row + 32)
+    const bf16_t* kp = k + (size_t)bh * tokens_pad * 64 + (size_t)row0 * 64 + col * 8;
+    const bf16_t* vp = vT + (size_t)bh * 64 * tokens_pad + (size_t)row0 * tokens_pad + col * 8;
+    const size_t k_row32 = (size_t)32 * 64, v_row32 = (size_t)32 * tokens_pad;
+    const int kdst = row0 * KS + col * 16, vdst = K_BYTES + row0 * VS + col * 16;
+    uint4 kreg0, kreg1, vreg0, vreg1;
+#define ATTN_LOAD(kv0)                                                                  \
+    kreg0 = *reinterpret_cast<const uint4*>(kp + (size_t)(kv0) * 64);                   \
+    kreg1 = *reinterpret_cast<const uint4*>(kp + (size_t)(kv0) * 64 + k_row32);         \
+    vreg0 = *reinterpret_cast<const uint4*>(vp + (kv0));                                \
+    vreg1 = *reinterpret_cast<const uint4*>(vp + (kv0) + v_row32);
+#define ATTN_WRITE(st)                                                                  \
+    *reinterpret_cast<uint4*>((st) + kdst) = kreg0;                                     \
+    *reinterpret_cast<uint4*>((st) + kdst + 32 * KS) = kreg1;                           \
+    *reinterpret_cast<uint2*>((st) + vdst) = make_uint2(vreg0.x, vreg0.y);              \
+    *reinterpret_cast<uint2*>((st) + vdst + 8) = make_uint2(vreg0.z, vreg0.w);          \
+    *reinterpret_cast<uint2*>((st) + vdst + 32 * VS) = make_uint2(vreg1.x, vreg1.y);    \
+    *reinterpret_cast<uint2*>((st) + vdst + 32 * VS + 8) = make_uint2(vreg1.z, vreg1.w);
 
     f32x16 o[2];
 #pragma unroll
@@ -83,79 +139,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkv = tokens_pad / KV;
-    load_tile(0);
-    write_tile(smem);
+    ATTN_LOAD(0)
+    ATTN_WRITE(smem)
     __syncthreads();
-
-    for (int t = 0; t < nkv; ++t) {
-        const char* st = smem + (t & 1) * STAGE;
-        const int kv0 = t * KV;
-        if (t + 1 < nkv) load_tile(kv0 + KV);
-
-        // ---- S^T = K Q^T : two groups of 32 keys
-        f32x16 sacc[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[g][i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
-                sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[g], 0, 0, 0);
-            }
-        }
-        // ---- online softmax (base-2 domain); the query is on the lane
-        float mx = -INFINITY;
-        const bool tail = kv0 + KV > tokens;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = sacc[g][i] * LOG2E;
-                if (tail && kv0 + g * 32 + crow(i, h) >= tokens) v = -INFINITY;
-                sacc[g][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lsum = 0.f;
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
-                lsum += p;
-                pf[g][i >> 3][i & 7] = (bf16_t)p;
-            }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            o[0][i] *= alpha;
-            o[1][i] *= alpha;
-        }
-        // ---- O^T += V^T P^T
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const char* vrow = st + K_BYTES + (blk * 32 + r) * VS;
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int key = g * 32 + 16 * s2 + 4 * h;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + key * 2);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (key + 8) * 2);
-                    bf16x8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][s2], o[blk], 0, 0, 0);
-                }
-        }
-        if (t + 1 < nkv) write_tile(smem + ((t + 1) & 1) * STAGE);
+    for (int t = 0; t + 1 < nkv; ++t) {
+        ATTN_LOAD((t + 1) * KV)
+        attn_tile<false>(smem + (t & 1) * STAGE, t * KV, tokens, r, h, qf, o, m_run, l_run);
+        ATTN_WRITE(smem + ((t + 1) & 1) * STAGE)
         __syncthreads();
     }
+    {
+        const int t = nkv - 1;
+        if (tokens_pad > tokens) attn_tile<true>(smem + (t & 1) * STAGE, t * KV, tokens, r, h, qf, o, m_run, l_run);
+        else attn_tile<false>(smem + (t & 1) * STAGE, t * KV, tokens, r, h, qf, o, m_run, l_run);
+    }
+#undef ATTN_LOAD
+#undef ATTN_WRITE
 
     // ---- normalise and store: out[(b*tokens + q)][head*64 + d], 4 consecutive d per register group
     const float l_tot = l_run + __shfl_xor(l_run, 32);

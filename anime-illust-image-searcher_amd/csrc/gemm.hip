@@ -8,9 +8,10 @@
 //   128 x 64 output tile = 8 x 4 MFMA tiles of 16 x 16 (128 accumulator registers);
 //   LDS: 2 stages x (A 32 KiB + W 32 KiB) = 128 KiB -> one workgroup per CU;
 //   staging: global_load_lds_dwordx4 (no VGPR round trip).  An operand tile is stored as 32
-//   subtiles of 16 rows x 32 k (1 KiB = one wave instruction); inside a subtile the 16-byte chunk
-//   index is XORed with 2 for rows 8..15 (applied on the per-lane global SOURCE address and again
-//   on the ds_read_b128 address), which makes the fragment reads bank-conflict free;
+//   sub-tiles of 8 rows x 64 k = 8 FULL 128-byte lines (1 KiB = one wave instruction; half-line,
+//   "fragment shaped" pieces double the texture-addresser work per byte); inside a sub-tile the
+//   16-byte chunk index is XORed with the row index (applied on the per-lane global SOURCE address
+//   and again on the ds_read_b128 address), which makes the fragment reads bank-conflict free;
 //   the next K-step is staged while the current one is multiplied (2-stage pipeline).
 // Operands are swapped in the MFMA (W fragment as "A", activation fragment as "B") so that a lane
 // ends up with 4 consecutive output COLUMNS of one row: epilogue loads/stores are 16 B (fp32) or
@@ -18,6 +19,8 @@
 // which is what the transposed V layout wants.
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) walk
 // neighbouring tiles and reuse operand panels in that XCD's L2.
+#include <cstdlib>
+
 #include "vit_internal.h"
 
 namespace hipts {
@@ -33,36 +36,171 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-// Stage one 256 x 64 operand tile: 32 subtiles, 4 per wave.
+// Stage one 256 x 64 operand tile: 32 sub-tiles of 8 rows, 4 per wave.
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ X, int rows_total, int K, int row0, int kt,
                                            char* lds_tile, int wave, int lane) {
-    const int row_in = lane >> 2;
-    const int chunk = (lane & 3) ^ (((row_in >> 3) & 1) << 1);
+    const int row_in = lane >> 3;
+    const int chunk = (lane & 7) ^ row_in;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int s = wave * 4 + i;
-        const int rowblk = s >> 1, kblk = s & 1;
-        int grow = row0 + rowblk * 16 + row_in;
+        const int rb8 = wave * 4 + i;
+        int grow = row0 + rb8 * 8 + row_in;
         grow = grow < rows_total ? grow : rows_total - 1;
-        const bf16_t* g = X + (size_t)grow * K + (size_t)kt * BK + kblk * 32 + chunk * 8;
-        glds16(g, lds_tile + s * 1024);
+        const bf16_t* g = X + (size_t)grow * K + (size_t)kt * BK + chunk * 8;
+        glds16(g, lds_tile + rb8 * 1024);
     }
 }
 
+// MFMA 16x16x32 fragment of 16-row block `rowblk`, k-half kk: lane (r = lane & 15, q = lane >> 4)
+// takes row r, logical chunk 4 kk + q, stored at physical chunk (4 kk + q) ^ (r & 7).
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rowblk, int kk, int lane) {
     const int r = lane & 15;
-    const int c = (lane >> 4) ^ (((r >> 3) & 1) << 1);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + (rowblk * 2 + kk) * 1024 + r * 64 + c * 16);
+    const int c = (kk * 4 + (lane >> 4)) ^ (r & 7);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + (rowblk * 2 + (r >> 3)) * 1024 + (r & 7) * 128 + c * 16);
 }
 
 __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
     if (tanh_form) {
-        // torch gelu(approximate='tanh'): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+        // torch gelu(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
+        // 0.5 (1 + tanh(u)) = sigmoid(2u) = 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 + one v_rcp_f32.
         const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-        const float inner = kBeta * (x + kKappa * x * x * x);
-        return 0.5f * x * (1.0f + tanhf(inner));
+        const float u = kBeta * (x + kKappa * x * x * x);
+        const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * u);
+        return x * __builtin_amdgcn_rcpf(1.0f + e);
     }
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+
+// Epilogue shared by both main-loop variants.  acc[i][j]: 16 x 16 tile (i: 16-row block of the
+// wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
+// positional embedding, residual) are issued in batches of four before their first use so their
+// latencies overlap instead of forming a chain of 32 dependent round trips.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[8][4], int m0, int n0, int wave_m, int wave_n,
+                                              int lane) {
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ld = a.ld_out ? a.ld_out : a.N;
+    if constexpr (EPI == EPI_VT) {
+        // natural order: lane = column n, registers = 4 consecutive rows (tokens)
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wave_n * 64 + j * 16 + lr;
+            bv[j] = n < a.N ? a.bias[n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wave_m * 128 + i * 16 + 4 * lq;
+            if (m >= a.M) continue;
+            const int b = m / a.tokens, t = m - b * a.tokens;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wave_n * 64 + j * 16 + lr;
+                if (n >= a.N) continue;
+                const f32x4 c = acc[i][j];
+                const int head = n >> 6, d = n & 63;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(c[e] + bv[j]);
+                *reinterpret_cast<bf16x4*>(a.out_bf16 + ((size_t)(b * a.heads + head) * 64 + d) * a.tokens_pad + t) = o;
+            }
+        }
+    } else if constexpr (EPI == EPI_HEAD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wave_m * 128 + i * 16 + lr;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wave_n * 64 + j * 16 + 4 * lq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < a.N) {
+                        const float v = acc[i][j][e] + a.bias[n + e];
+                        if (a.out_f32) a.out_f32[(size_t)m * ld + n + e] = v;
+                        if (a.out2_f32) a.out2_f32[(size_t)m * ld + n + e] = 1.0f / (1.0f + expf(-v));
+                    }
+                }
+            }
+        }
+    } else {
+        // swapped order: lane = row m, registers = 4 consecutive columns n
+        int nc[4];
+        bool nv[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            nc[j] = n0 + wave_n * 64 + j * 16 + 4 * lq;
+            nv[j] = nc[j] < a.N;
+            bv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.bias + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (EPI == EPI_RESID) {
+            // read-modify-write of the fp32 residual stream: 8 x 16 B loads per lane in flight
+            // (two 16-row blocks) before the first dependent add, so a CU keeps ~64 KB outstanding.
+#pragma unroll
+            for (int i2 = 0; i2 < 8; i2 += 2) {
+                f32x4 xv[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = m0 + wave_m * 128 + (i2 + u) * 16 + lr;
+                    const float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int m = m0 + wave_m * 128 + (i2 + u) * 16 + lr;
+                    if (m >= a.M) continue;
+                    float* row = a.out_f32 + (size_t)m * ld;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nv[j]) *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + (acc[i2 + u][j] + bv[j]);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wave_m * 128 + i * 16 + lr;
+            if (m >= a.M) continue;
+            if constexpr (EPI == EPI_PATCH) {
+                const int t = m % a.tokens;
+                f32x4 pv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.pos + (size_t)t * a.N + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (nv[j]) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] * a.qscale + bv[j] + pv[j];
+            } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!nv[j]) continue;
+                    const f32x4 v = acc[i][j] + bv[j];
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)gelu_f(v[e], a.gelu_tanh);
+                    *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = o;
+                }
+            } else if constexpr (EPI == EPI_QK) {
+                const int b = m / a.tokens, t = m - b * a.tokens;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!nv[j]) continue;
+                    const int which = nc[j] >= a.dim ? 1 : 0;
+                    const int nn = nc[j] - which * a.dim;
+                    const int head = nn >> 6, d = nn & 63;
+                    const float sc = which ? 1.0f : a.qscale;
+                    const f32x4 v = acc[i][j] + bv[j];
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(v[e] * sc);
+                    bf16_t* base = which ? a.out2_bf16 : a.out_bf16;
+                    *reinterpret_cast<bf16x4*>(base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + d) = o;
+                }
+            }
+        }
+    }
 }
 
 template <int EPI>
@@ -122,77 +260,241 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a, int tiles_m
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------ epilogue
-    const int lr = lane & 15, lq = lane >> 4;
-    const int ld = a.ld_out ? a.ld_out : a.N;
+    gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong main loop (default).  Same tile geometry and LDS images as above, but the 8 waves run
+// as two groups of four (wave_m = 0 / 1; waves w and w+4 share a SIMD) staggered by one barrier:
+//
+//     group 0:          R(0) | C(0) | R(1) | C(1) | ...            | = s_barrier (all 8 waves)
+//     group 1:   (idle) |    | R(0) | C(0) | R(1) | ...
+//
+// R(P) = read segment: the ds_read_b128 fragment loads of phase P, two global_load_lds of the NEXT
+// K-tile, the counted waits; C(P) = compute segment: 16 MFMAs.  In every interval one wave of each
+// SIMD is in its compute segment, so the matrix pipe never waits for LDS or for a barrier.
+// A K-tile is 4 phases: (m-half, k-half) = (0,0) (0,1) (1,0) (1,1); the W fragments of a k-half are
+// read once (phases 0/1) and kept in registers for phases 2/3.
+// Staging order inside a K-tile follows the order of first use in the next one -- phase 0 and 1: the
+// two halves of W; 2: A-low rows (first used by phase 0); 3: A-high rows (first used by phase 2) --
+// so every load has >= 2 phases (4 barrier intervals) to land, is retired by a counted
+// `s_waitcnt vmcnt(N)` at the end of the R segment one phase before its first reader (RAW: wait,
+// then a barrier every reader passes; N = 2 before a new K-tile, 4 before phase 2), and no region is
+// restaged sooner than 3 phases after its last ds_read (WAR).
+// Barriers are raw s_barrier: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int K = a.K, nt = K / BK;
+    const int w_rows = tiles_n * BN;
+
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 c = acc[i][j];
-            if constexpr (EPI == EPI_VT) {
-                // natural order: lane = column n, registers = 4 consecutive rows (tokens)
-                const int n = n0 + wave_n * 64 + j * 16 + lr;
-                const int m = m0 + wave_m * 128 + i * 16 + 4 * lq;
-                if (m < a.M && n < a.N) {
-                    const float bv = a.bias[n];
-                    const int b = m / a.tokens, t = m - b * a.tokens;
-                    const int head = n >> 6, d = n & 63;
-                    bf16x4 o;
-                    o[0] = (bf16_t)(c[0] + bv);
-                    o[1] = (bf16_t)(c[1] + bv);
-                    o[2] = (bf16_t)(c[2] + bv);
-                    o[3] = (bf16_t)(c[3] + bv);
-                    bf16_t* dst = a.out_bf16 + ((size_t)(b * a.heads + head) * 64 + d) * a.tokens_pad + t;
-                    *reinterpret_cast<bf16x4*>(dst) = o;
-                }
-            } else {
-                // swapped order: lane = row m, registers = 4 consecutive columns n
-                const int m = m0 + wave_m * 128 + i * 16 + lr;
-                const int n = n0 + wave_n * 64 + j * 16 + 4 * lq;
-                if (m >= a.M || n >= a.N) continue;
-                if constexpr (EPI == EPI_HEAD) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e < a.N) {
-                            const float v = c[e] + a.bias[n + e];
-                            if (a.out_f32) a.out_f32[(size_t)m * ld + n + e] = v;
-                            if (a.out2_f32) a.out2_f32[(size_t)m * ld + n + e] = 1.0f / (1.0f + expf(-v));
-                        }
-                    }
-                } else {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-                    f32x4 v = c + bv;
-                    if constexpr (EPI == EPI_PATCH) {
-                        v = c * a.qscale + bv;
-                        const int t = m % a.tokens;
-                        const f32x4 pv = *reinterpret_cast<const f32x4*>(a.pos + (size_t)t * a.N + n);
-                        *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + n) = v + pv;
-                    } else if constexpr (EPI == EPI_RESID) {
-                        float* p = a.out_f32 + (size_t)m * ld + n;
-                        const f32x4 x = *reinterpret_cast<const f32x4*>(p);
-                        *reinterpret_cast<f32x4*>(p) = x + v;
-                    } else if constexpr (EPI == EPI_GELU) {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)gelu_f(v[e], a.gelu_tanh);
-                        *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + n) = o;
-                    } else if constexpr (EPI == EPI_QK) {
-                        const int which = n >= a.dim ? 1 : 0;
-                        const int nn = n - which * a.dim;
-                        const int head = nn >> 6, d = nn & 63;
-                        const int b = m / a.tokens, t = m - b * a.tokens;
-                        const float sc = which ? 1.0f : a.qscale;
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(v[e] * sc);
-                        bf16_t* base = which ? a.out2_bf16 : a.out_bf16;
-                        *reinterpret_cast<bf16x4*>(base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + d) = o;
-                    }
-                }
-            }
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: K-tile 0 complete
+    stage_tile(a.A, a.M, K, m0, 0, smem, wave, lane);
+    stage_tile(a.W, w_rows, K, n0, 0, smem + TILE_BYTES, wave, lane);
+
+    // This wave's eight staging slots of a K-tile (two per phase), as (global source pointer for
+    // K-tile 1, LDS offset inside a stage).  Phase lists of 16 sub-tiles (8 rows x 128 B each), wave w
+    // takes entries 2w, 2w+1:  0: W rows 0..127 | 1: W rows 128..255 | 2: A-low | 3: A-high, where
+    // A-low = the rows the two wave groups multiply in phases 0/1 (8-row blocks 0..7, 16..23).
+    const bf16_t* src[8];
+    int dst[8];
+    {
+        const int row_in = lane >> 3;
+        const int chunk = (lane & 7) ^ row_in;
+        auto slot = [&](int idx, bool isW, int rb8) {
+            int grow = (isW ? n0 : m0) + rb8 * 8 + row_in;
+            const int lim = isW ? w_rows : a.M;
+            grow = grow < lim ? grow : lim - 1;
+            src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + BK + chunk * 8;
+            dst[idx] = (isW ? TILE_BYTES : 0) + rb8 * 1024;
+        };
+        for (int u = 0; u < 2; ++u) {
+            const int e = 2 * wave + u;
+            slot(0 + u, true, e);
+            slot(2 + u, true, 16 + e);
+            slot(4 + u, false, e < 8 ? e : e + 8);
+            slot(6 + u, false, e < 8 ? 8 + e : 16 + e);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
+
+    bf16x8 wf[2][4];
+    for (int t = 0; t < nt; ++t) {
+        const char* cur = smem + (t & 1) * STAGE_BYTES;
+        char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+        const bool more = t + 1 < nt;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int mh = p >> 1, kk = p & 1;
+            // ---------------- R(P): issue only -- fragment reads of this phase, two loads of the next K-tile
+            bf16x8 af[4];
+            if (p < 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[kk][j] = read_frag(cur + TILE_BYTES, wave_n * 4 + j, kk, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag(cur, wave_m * 8 + mh * 4 + i, kk, lane);
+            if (more) {
+                glds16(src[2 * p], nxt + dst[2 * p]);
+                glds16(src[2 * p + 1], nxt + dst[2 * p + 1]);
+                src[2 * p] += BK;
+                src[2 * p + 1] += BK;
+                if (p == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // W and A-low of tile t+1 landed
+                else if (p == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+            } else if (p == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- C(P): the reads were issued a whole interval ago
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (EPI == EPI_VT)
+                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[kk][j], acc[mh * 4 + i][j], 0, 0, 0);
+                    else
+                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
+    gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Three-stage variant for epilogue-heavy shapes: block tile 256 x 128 x 32, 256 threads = 4 waves
+// (2 x 2, each wave still 128 x 64), LDS ring of 3 x 24 KiB = 72 KiB -> TWO workgroups per CU.
+// With K = 768 the fp32 residual read-modify-write (or the bf16 store of a 3072-wide hidden) of a
+// tile costs about as much time as its 12..24 K-steps; with one workgroup per CU all CUs hit their
+// epilogues together and the matrix pipe idles during that HBM burst.  Two independent workgroups
+// per CU drift apart, so one streams its epilogue while the other multiplies.
+// One raw barrier per K-step: wait (counted) for stage t, barrier, issue stage t+2 into the slot
+// everybody just finished reading, multiply stage t.
+// ---------------------------------------------------------------------------------------------
+constexpr int S3_BN = 128, S3_BK = 32, S3_STAGE = (BM + S3_BN) * S3_BK * 2, S3_LDS = 3 * S3_STAGE;   // 24 KiB, 72 KiB
+
+__device__ __forceinline__ void s3_stage(const GemmArgs& a, int m0, int n0, int w_rows, int kt, char* st, int wave, int lane) {
+    const int row_in = lane >> 2;
+    const int chunk = (lane & 3) ^ (((row_in >> 3) & 1) << 1);
+    const size_t koff = (size_t)kt * S3_BK + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rb = wave * 4 + i;
+        int grow = m0 + rb * 16 + row_in;
+        grow = grow < a.M ? grow : a.M - 1;
+        glds16(a.A + (size_t)grow * a.K + koff, st + rb * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rb = wave * 2 + i;
+        int grow = n0 + rb * 16 + row_in;
+        grow = grow < w_rows ? grow : w_rows - 1;
+        glds16(a.W + (size_t)grow * a.K + koff, st + BM * S3_BK * 2 + rb * 1024);
+    }
+}
+
+__device__ __forceinline__ bf16x8 s3_frag(const char* base, int rowblk, int lane) {
+    const int r = lane & 15;
+    const int c = (lane >> 4) ^ (((r >> 3) & 1) << 1);
+    return *reinterpret_cast<const bf16x8*>(base + rowblk * 1024 + r * 64 + c * 16);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_s3_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * S3_BN;
+    const int nt = a.K / S3_BK;
+    const int w_rows = ((a.N + 255) / 256) * 256;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    s3_stage(a, m0, n0, w_rows, 0, smem, wave, lane);
+    if (nt > 1) s3_stage(a, m0, n0, w_rows, 1, smem + S3_STAGE, wave, lane);
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        // stage t complete (6 loads of stage t+1 may stay in flight), visible to all after the barrier
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) {
+            int s2 = slot + 2;
+            s2 = s2 >= 3 ? s2 - 3 : s2;
+            s3_stage(a, m0, n0, w_rows, t + 2, smem + s2 * S3_STAGE, wave, lane);
+        }
+        const char* cur = smem + slot * S3_STAGE;
+        bf16x8 af[8], wf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = s3_frag(cur + BM * S3_BK * 2, wave_n * 4 + j, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = s3_frag(cur, wave_m * 8 + i, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (EPI == EPI_VT)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
+}
+
+// HIPTS_GEMM selects the main loop for A/B runs: "s3" (default) three-stage 256x128 tile, two
+// workgroups per CU; "pp" ping-pong 256x256; "v1" simple two-barrier 256x256.
+int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("HIPTS_GEMM");
+        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "pp") == 0) ? 1 : 2;
+    }
+    return v;
 }
 
 template <int EPI>
@@ -200,10 +502,22 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
         attr = true;
     }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    gemm_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int variant = gemm_variant();
+    if (variant == 2) {
+        const int tiles_n = (a.N + S3_BN - 1) / S3_BN;
+        gemm_s3_kernel<EPI><<<tiles_m * tiles_n, 256, S3_LDS, s>>>(a, tiles_m, tiles_n);
+    } else {
+        const int tiles_n = (a.N + BN - 1) / BN;
+        if (variant == 1)
+            gemm_pp_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+        else
+            gemm_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+    }
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }

@@ -570,11 +570,12 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
             layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
             HIPTS_LAUNCH_CHECK();
         }
-        // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled by head_dim^-0.5 = 0.125 (exact)
+        // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
         g = GemmArgs{};
         g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
         g.bias = L.qkv_b.as<float>(); g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
-        g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D; g.qscale = 0.125f;
+        g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        g.qscale = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 (64^-0.5) * log2(e): attention works in base 2
         {
             ProfScope ps(h, s, PC_GEMM_QK, 2.0 * dM * 2 * dD * dD, dM * dD * 2 + dM * 2 * dD * 2);
             HIPTS_TRY(launch_gemm(EPI_QK, g, s));
@@ -689,3 +690,52 @@ int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int ba
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Development aid (not part of the public ABI, not declared in include/hip_tagsearch.h): time one
+// GEMM shape with random bf16 operands.  Used by tools/gemm_bench.py under gpurun.
+// ---------------------------------------------------------------------------------------------
+extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out) {
+    HIPTS_TRY(use_device(0));
+    const int Np = round_up(N, 256);
+    DevBuf A, W, bias, of32, obf, obf2, pos;
+    HIPTS_TRY(A.alloc((size_t)M * K * 2));
+    HIPTS_TRY(W.alloc((size_t)Np * K * 2));
+    HIPTS_TRY(bias.alloc((size_t)Np * 4));
+    HIPTS_TRY(of32.alloc((size_t)M * Np * 4));
+    // q/k/vT layouts pad 784 tokens to 832 per image: size the bf16 outputs for the padded layout
+    const size_t padded_rows = ((size_t)M / 784 + 1) * 832;
+    const size_t obytes = (padded_rows > (size_t)M ? padded_rows : (size_t)M) * Np * 2 + (1 << 20);
+    HIPTS_TRY(obf.alloc(obytes));
+    HIPTS_TRY(obf2.alloc(obytes));
+    HIPTS_TRY(pos.alloc((size_t)1024 * Np * 4));
+    std::vector<uint16_t> ha((size_t)M * K), hw((size_t)Np * K);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f * 2.0f - 1.0f; };
+    for (auto& v : ha) v = f32_to_bf16_rne(rnd());
+    for (auto& v : hw) v = f32_to_bf16_rne(rnd() * 0.05f);
+    HIPTS_TRY(upload(A.p, ha.data(), ha.size() * 2));
+    HIPTS_TRY(upload(W.p, hw.data(), hw.size() * 2));
+    HIPTS_HIP(hipMemset(bias.p, 0, bias.bytes));
+    HIPTS_HIP(hipMemset(of32.p, 0, of32.bytes));
+    HIPTS_HIP(hipMemset(pos.p, 0, pos.bytes));
+    GemmArgs g{};
+    g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>();
+    g.out_f32 = of32.as<float>(); g.out_bf16 = obf.as<bf16_t>(); g.out2_bf16 = obf2.as<bf16_t>(); g.pos = pos.as<float>();
+    g.tokens = 784; g.tokens_pad = 832; g.heads = N / 128 > 0 ? N / 128 : 1; g.dim = N / 2; g.qscale = 0.125f;
+    if (epi == EPI_VT) { g.heads = N / 64; g.dim = N; }
+    hipEvent_t e0, e1;
+    HIPTS_HIP(hipEventCreate(&e0));
+    HIPTS_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HIPTS_TRY(launch_gemm((GemmEpilogue)epi, g, nullptr));
+    HIPTS_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIPTS_TRY(launch_gemm((GemmEpilogue)epi, g, nullptr));
+    HIPTS_HIP(hipEventRecord(e1, nullptr));
+    HIPTS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return HIPTS_OK;
+}
