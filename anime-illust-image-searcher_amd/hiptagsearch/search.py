@@ -220,3 +220,18 @@ def find_similar_documents(new_doc: str, topn: int = 50) -> List[Tuple[int, floa
     if _engine is None:
         raise RuntimeError("no SearchEngine installed: call set_engine(load_engine()) first (webui.py:585 load_model)")
     return _engine.find_similar_documents(new_doc, topn)
+
+
+def load_engine(device: int = 0, d2v_model: str = "doc2vec_model", compat_rerank: bool = False) -> SearchEngine:
+    """webui.py:649-689 load_model(): everything the query function needs, from the files
+    genmodel.py writes into the current directory."""
+    import pickle
+    from .bm25 import load_bm25_index
+    tag_file_path = 'tags-wd-tagger_doc2vec_idx.csv'
+    with open(tag_file_path, 'r', encoding='utf-8') as f:
+        lines = [line.strip() for line in f.readlines()]
+    model = Doc2VecInference.load(d2v_model, device)
+    index = Similarity.load("doc2vec_index", device)
+    dictionary = pickle.load(open("doc2vec_dictionary", "rb"))
+    bm25 = load_bm25_index(device)
+    return SearchEngine(model, index, dictionary.token2id, bm25, lines, compat_rerank=compat_rerank)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""python tagging.py --dir D [--after YYYY-MM-DD]        (same flags as the reference, tagging.py:361-383)
+
+Extra switches: --checkpoint model.safetensors (timm key layout) and --labels selected_tags.csv for a
+real wd-vit-tagger; without them the seeded synthetic stand-ins are used (no network here).
+--compat reproduces the reference's dropped tail batch; --batch sets the device batch size."""
+import argparse
+import datetime
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(arg_str: list) -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--dir', nargs=1, required=True, help='tagging target directory path')
+    parser.add_argument('--after', nargs=1, help='tagging new images after this date (mtime attribute). Format: YYYY-MM-DD')
+    parser.add_argument('--checkpoint', default=None)
+    parser.add_argument('--labels', default=None)
+    parser.add_argument('--compat', action='store_true')
+    parser.add_argument('--batch', type=int, default=64)
+    parser.add_argument('--device', type=int, default=0)
+    args = parser.parse_args(arg_str)
+    from hiptagsearch.tagger import Predictor
+    predictor = Predictor(device=args.device, max_batch=args.batch, compat=args.compat)
+    predictor.load_model(args.checkpoint, args.labels)
+    after_date = None
+    if args.after is not None:
+        try:
+            after_date = datetime.datetime.strptime(args.after[0], '%Y-%m-%d').date()
+        except Exception as e:
+            print('%s: %s' % (type(e), str(e)))
+            print('Invalid date format. format is YYYY-MM-DD')
+            raise SystemExit(1)
+    predictor.process_directory(args.dir[0], after_date, batch_size=10 if args.compat else args.batch)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

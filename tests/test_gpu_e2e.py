@@ -1,0 +1,61 @@
+"""GPU end-to-end: the CLI surface of the reference (tagging.py --dir, genmodel.py, query function)
+on a small synthetic image directory, through the device kernels."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "anime-illust-image-searcher_amd")
+
+
+def test_tagging_genmodel_query_pipeline(tmp_path, monkeypatch):
+    from PIL import Image
+    from hiptagsearch import search, synth
+    from hiptagsearch.tagger import Predictor
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("imgs/sub")
+    rng = np.random.default_rng(0)
+    n = 23
+    for i in range(n):
+        arr = rng.integers(0, 256, (40 + i, 64, 3), dtype=np.uint8)
+        Image.fromarray(arr).save("imgs/%s%03d.png" % ("sub/" if i % 3 == 0 else "", i))
+    open("imgs/notes.txt", "w").write("not an image")
+    # tagging stage with the tiny config (same code path as ViT-B/16, seconds instead of minutes of init)
+    pred = Predictor(max_batch=8)
+    pred.load_model(cfg=synth.VIT_TINY, seed=3)
+    pred.process_directory("imgs", batch_size=8)
+    lines = open("tags-wd-tagger.txt", encoding="utf-8").read().splitlines()
+    assert len(lines) == n                                         # default mode writes every file (no tail drop)
+    assert sorted(l.split(",")[0] for l in lines) == sorted(pred.list_files_recursive("imgs"))
+    assert all(len(l.split(",")) >= 2 for l in lines)
+    # compat mode reproduces the reference's dropped tail batch: (ceil(23/10)-1)*10 = 20 lines
+    os.remove("tags-wd-tagger.txt")
+    pred2 = Predictor(max_batch=8, compat=True)
+    pred2.tagger_model, pred2.selector, pred2.tag_names, pred2.cfg = pred.tagger_model, pred.selector, pred.tag_names, pred.cfg
+    pred2.process_directory("imgs", batch_size=10)
+    assert len(open("tags-wd-tagger.txt").read().splitlines()) == 20
+    # index stage
+    os.remove("tags-wd-tagger.txt")
+    open("tags-wd-tagger.txt", "w").write("\n".join(lines) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "genmodel.py"), "--synthetic-d2v", "--epochs", "5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for f in ("doc2vec_index", "doc2vec_dictionary", "bm25_corpus", "bm25_idf", "bm25_avgdl", "bm25_D", "bm25_doc_lengths",
+              "tags-wd-tagger_doc2vec_idx.csv"):
+        assert os.path.exists(f), f
+    # query stage
+    eng = search.load_engine()
+    search.set_engine(eng)
+    docs = [l.split(",")[1:] for l in open("tags-wd-tagger_doc2vec_idx.csv").read().splitlines()]
+    tag = docs[0][0]
+    res = search.find_similar_documents(tag, topn=5)
+    assert 1 <= len(res) <= 5 and all(0 <= d < len(docs) for d, _ in res)
+    assert res[0][1] == pytest.approx(1.0)
+    req = search.find_similar_documents(tag + ":+1", topn=50)
+    assert all(tag in docs[d] for d, _ in req)                     # required tag really required
+    with pytest.raises(KeyError):
+        search.find_similar_documents("definitely_not_a_tag", topn=5)   # webui.py:371 behaviour

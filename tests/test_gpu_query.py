@@ -193,3 +193,60 @@ def test_search_rank_equal(corpus20k):
         wi, wv = osearch.topk(final, k)
         np.testing.assert_array_equal(ids[i], wi)
         assert vals[i].tobytes() == wv.tobytes()
+
+
+# --------------------------------------------------------------------------------- full query function
+def test_find_similar_documents_matches_oracle():
+    """find_similar_documents (webui.py:345-390, normal mode incl. the 10-document rerank and the gap
+    filter) against the oracle restatement; Doc2Vec vectors come from the C oracle with the same
+    explicit start vectors / seeds the product derives."""
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.d2v import Doc2VecInference, pseudorandom_weak_vector
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from oracle import bm25 as obm25, d2v as od2v, search as osearch
+    V, D, dim, epochs = 400, 3000, 300, 8
+    ptr, terms = synth.tag_corpus(D=D, V=V, seed=11)
+    toks = synth.vocab_tokens(V)
+    docs = [[toks[t] for t in terms[ptr[d]:ptr[d + 1]]] for d in range(D)]
+    lines = ["img%05d.png," % d + ",".join(docs[d]) for d in range(D)]
+    token2id = {t: i for i, t in enumerate(toks)}
+    m = synth.d2v_model(synth.term_counts(ptr, terms, V), dim=dim, seed=44)
+    model = Doc2VecInference(m["syn1neg"], m["cum_table"], m["sample_int"], token2id, epochs=epochs)
+
+    def oracle_infer(list_of_docs):
+        p = np.zeros(len(list_of_docs) + 1, dtype=np.int64)
+        ids = []
+        for i, d in enumerate(list_of_docs):
+            ids.extend(token2id.get(t, -1) for t in d)
+            p[i + 1] = len(ids)
+        v0 = np.stack([pseudorandom_weak_vector(dim, " ".join(d)) for d in list_of_docs])
+        seeds = np.asarray([model._seed_for(d) for d in list_of_docs], dtype=np.uint64)
+        return od2v.infer(m["syn1neg"], m["cum_table"], m["sample_int"], p, np.asarray(ids, np.int32), v0, seeds, epochs)
+
+    rows = oracle_infer(docs)
+    got_rows = model.infer_vectors(docs)
+    assert got_rows.tobytes() == rows.tobytes()                    # genmodel.py:168-169 on the device == oracle
+    index = Similarity("idx", None, dim, capacity=D)
+    index.add_matrix(rows)
+    bm = BM25Index.from_tokens(docs, token2id)
+    eng = SearchEngine(model, index, token2id, bm, lines)
+    corpus, idf, avgdl, _, dl = obm25.bm25_build(docs, token2id)
+    for query in [toks[3], "%s %s:+2" % (toks[1], toks[7]), "%s:-1 %s %s:3" % (toks[0], toks[5], toks[9]), toks[2] + ":+1"]:
+        got = eng.find_similar_documents(query, topn=50)
+        d2v_terms, allw, bm_terms = osearch.parse_query(query)
+        qvec = osearch.query_vector(d2v_terms, allw, lambda words: oracle_infer([words])[0], dim)
+        sims = osearch.similarity(rows, qvec.astype(np.float32))
+        b = obm25.bm25_score(corpus, idf, avgdl, D, dl, osearch.query_weights(bm_terms, token2id))
+        final = osearch.combine(b, sims)
+
+        def rerank_sims(top_ids, top_scores):
+            vecs = oracle_infer([docs[int(i)] for i in top_ids]).astype(np.float64)
+            mean = np.average(vecs, axis=0, weights=top_scores)
+            mean = mean / np.linalg.norm(mean)
+            return osearch.similarity(rows, mean.astype(np.float32))
+
+        want = osearch.rerank(final, 50, rerank_sims)
+        assert [d for d, _ in got] == [d for d, _ in want], query
+        np.testing.assert_array_equal(np.array([s for _, s in got]), np.array([s for _, s in want]))
