@@ -96,7 +96,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+    // XCD-aware work id: workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
+    // L2).  Remap so that consecutive work items -- the query blocks of one (image, head), which all
+    // stream the same K / V^T -- run on ONE XCD and hit its L2 instead of each pulling its own copy
+    // through the fabric (measured: 1.23 GB fetched per launch vs 0.23 GB algorithmic before this).
+    int wid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qd = nwg >> 3, rm = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int bh = wid / qblocks, qb = wid - bh * qblocks;
     const int b = bh / heads, head = bh - b * heads;
     const int q0 = (qb * 4 + wave) * 32;
     int qrow = q0 + r;

@@ -486,13 +486,13 @@ __global__ __launch_bounds__(256, 2) void gemm_s3_kernel(const GemmArgs a, int t
     gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
 }
 
-// HIPTS_GEMM selects the main loop for A/B runs: "s3" (default) three-stage 256x128 tile, two
-// workgroups per CU; "pp" ping-pong 256x256; "v1" simple two-barrier 256x256.
+// HIPTS_GEMM selects the main loop for A/B runs: "pp" (default) ping-pong 256x256; "s3" three-stage
+// 256x128 tile, two workgroups per CU; "v1" simple two-barrier 256x256.
 int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("HIPTS_GEMM");
-        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "pp") == 0) ? 1 : 2;
+        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "s3") == 0) ? 2 : 1;
     }
     return v;
 }
