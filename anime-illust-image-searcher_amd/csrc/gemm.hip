@@ -392,6 +392,156 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ping-pong with 32-MFMA segments (HIPTS_GEMM=pp2): two phases per K-tile (phase = m-half, both
+// k-halves: 4 x 4 x 2 = 32 MFMAs per segment), half the barriers per flop.  In-kernel s_memtime stamps
+// (template parameter STAMP, tools/gemm_bench.py with HIPTS_GEMM_STAMPS=1) show where a K-tile's
+// ~4.6 k cycles go at 4096^3: a read segment costs 300-650 cycles to ISSUE (16 ds_read_b128 + 6
+// LDS-DMA loads at ~60-100 cycles each), its counted vmcnt wait another 350-640 (LDS-DMA issue ->
+// landed ~2.5 k cycles under load, more than the one K-tile of lead a 2 x 64 KiB ring allows), the
+// 32 MFMAs 610-650.  So the read segment, not the barrier count, bounds the interval.
+//   R(0): 8 W + 8 A fragment reads, 6 of the wave's 8 loads of the next K-tile (all of W and the
+//         A-low rows: what phase 0 of the next tile reads);  wait vmcnt(6) -> A-high of THIS tile landed
+//   R(1): 8 A fragment reads, the 2 A-high loads of the next tile;  wait vmcnt(2) -> W/A-low of next tile landed
+// RAW: every wait sits one phase before the first reader with a barrier in between; WAR: a region is
+// restaged two phases after its last ds_read.
+// ---------------------------------------------------------------------------------------------
+#define PP2_STAMP(idx)                                                                                   \
+    if constexpr (STAMP) {                                                                               \
+        if (blockIdx.x == 0 && (t == 10 || t == 11)) {                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            unsigned long long ts_;                                                                      \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");                 \
+            if (lane == 0) a.stamps[wave * 64 + (t - 10) * 16 + mh * 8 + (idx)] = ts_;                   \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    }
+
+template <int EPI, bool STAMP = false>
+__global__ __launch_bounds__(512) void gemm_pp2_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int K = a.K, nt = K / BK;
+    const int w_rows = tiles_n * BN;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_tile(a.A, a.M, K, m0, 0, smem, wave, lane);
+    stage_tile(a.W, w_rows, K, n0, 0, smem + TILE_BYTES, wave, lane);
+
+    // staging slots of this wave: [0..3] W sub-tiles 4w..4w+3, [4,5] A-low, [6,7] A-high
+    const bf16_t* src[8];
+    int dst[8];
+    {
+        const int row_in = lane >> 3;
+        const int chunk = (lane & 7) ^ row_in;
+        auto slot = [&](int idx, bool isW, int rb8) {
+            int grow = (isW ? n0 : m0) + rb8 * 8 + row_in;
+            const int lim = isW ? w_rows : a.M;
+            grow = grow < lim ? grow : lim - 1;
+            src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + BK + chunk * 8;
+            dst[idx] = (isW ? TILE_BYTES : 0) + rb8 * 1024;
+        };
+        for (int u = 0; u < 4; ++u) slot(u, true, 4 * wave + u);
+        for (int u = 0; u < 2; ++u) {
+            const int e = 2 * wave + u;
+            slot(4 + u, false, e < 8 ? e : e + 8);          // A-low : 8-row blocks 0..7, 16..23
+            slot(6 + u, false, e < 8 ? 8 + e : 16 + e);     // A-high: 8-row blocks 8..15, 24..31
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
+
+    bf16x8 wf[2][4];
+    for (int t = 0; t < nt; ++t) {
+        const char* cur = smem + (t & 1) * STAGE_BYTES;
+        char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+        const bool more = t + 1 < nt;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            // ---------------- R: issue only
+            PP2_STAMP(0)
+            bf16x8 af[2][4];
+            if (mh == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wf[kk][j] = read_frag(cur + TILE_BYTES, wave_n * 4 + j, kk, lane);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[kk][i] = read_frag(cur, wave_m * 8 + mh * 4 + i, kk, lane);
+            if (more) {
+                if (mh == 0) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        glds16(src[u], nxt + dst[u]);
+                        src[u] += BK;
+                    }
+                    PP2_STAMP(1)
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else {
+#pragma unroll
+                    for (int u = 6; u < 8; ++u) {
+                        glds16(src[u], nxt + dst[u]);
+                        src[u] += BK;
+                    }
+                    PP2_STAMP(1)
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+            } else if (mh == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP2_STAMP(2)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            PP2_STAMP(3)
+            // ---------------- C: 32 MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            PP2_STAMP(4)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (EPI == EPI_VT)
+                            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], wf[kk][j], acc[mh * 4 + i][j], 0, 0, 0);
+                        else
+                            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], af[kk][i], acc[mh * 4 + i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            PP2_STAMP(5)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            PP2_STAMP(6)
+        }
+    }
+    if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
+    gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Three-stage variant for epilogue-heavy shapes: block tile 256 x 128 x 32, 256 threads = 4 waves
 // (2 x 2, each wave still 128 x 64), LDS ring of 3 x 24 KiB = 72 KiB -> TWO workgroups per CU.
 // With K = 768 the fp32 residual read-modify-write (or the bf16 store of a 3072-wide hidden) of a
@@ -486,13 +636,14 @@ __global__ __launch_bounds__(256, 2) void gemm_s3_kernel(const GemmArgs a, int t
     gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
 }
 
-// HIPTS_GEMM selects the main loop for A/B runs: "pp" (default) ping-pong 256x256; "s3" three-stage
-// 256x128 tile, two workgroups per CU; "v1" simple two-barrier 256x256.
+// HIPTS_GEMM selects the main loop for A/B runs: "pp" (default) ping-pong with 16-MFMA segments;
+// "pp2" 32-MFMA segments (better at K >= 4096, slightly worse on the ViT's K = 768 shapes);
+// "s3" three-stage 256x128 tile, two workgroups per CU; "v1" simple two-barrier loop.
 int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("HIPTS_GEMM");
-        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "s3") == 0) ? 2 : 1;
+        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "pp2") == 0) ? 3 : (e && strcmp(e, "s3") == 0) ? 2 : 1;
     }
     return v;
 }
@@ -503,6 +654,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
     if (!attr) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
         attr = true;
     }
@@ -513,7 +665,18 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         gemm_s3_kernel<EPI><<<tiles_m * tiles_n, 256, S3_LDS, s>>>(a, tiles_m, tiles_n);
     } else {
         const int tiles_n = (a.N + BN - 1) / BN;
-        if (variant == 1)
+        if (variant == 3) {
+            if constexpr (EPI == EPI_GELU) {
+                if (a.stamps) {
+                    HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                    gemm_pp2_kernel<EPI, true><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+                    HIPTS_LAUNCH_CHECK();
+                    return HIPTS_OK;
+                }
+            }
+            gemm_pp2_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+        }
+        else if (variant == 1)
             gemm_pp_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
         else
             gemm_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);

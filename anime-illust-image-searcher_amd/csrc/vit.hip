@@ -724,6 +724,12 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     g.out_f32 = of32.as<float>(); g.out_bf16 = obf.as<bf16_t>(); g.out2_bf16 = obf2.as<bf16_t>(); g.pos = pos.as<float>();
     g.tokens = 784; g.tokens_pad = 832; g.heads = N / 128 > 0 ? N / 128 : 1; g.dim = N / 2; g.qscale = 0.125f;
     if (epi == EPI_VT) { g.heads = N / 64; g.dim = N; }
+    DevBuf stamps;
+    if (getenv("HIPTS_GEMM_STAMPS")) {
+        HIPTS_TRY(stamps.alloc(8 * 64 * 8));
+        HIPTS_HIP(hipMemset(stamps.p, 0, 8 * 64 * 8));
+        g.stamps = stamps.as<unsigned long long>();
+    }
     hipEvent_t e0, e1;
     HIPTS_HIP(hipEventCreate(&e0));
     HIPTS_HIP(hipEventCreate(&e1));
@@ -735,6 +741,21 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     float ms = 0.f;
     HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
+    if (g.stamps) {
+        unsigned long long h[8 * 64];
+        HIPTS_HIP(hipMemcpy(h, g.stamps, sizeof(h), hipMemcpyDeviceToHost));
+        unsigned long long base = ~0ull;
+        for (int w = 0; w < 8; ++w) if (h[w * 64] && h[w * 64] < base) base = h[w * 64];
+        fprintf(stderr, "stamps (cycles since first; per wave: t10 mh0 [S0..S6] | t10 mh1 | t11 mh0 | t11 mh1)\n");
+        for (int w = 0; w < 8; ++w) {
+            fprintf(stderr, "wave %d:", w);
+            for (int i = 0; i < 32; ++i) {
+                if ((i & 7) == 7) { fprintf(stderr, " |"); continue; }
+                fprintf(stderr, " %6lld", (long long)(h[w * 64 + i] - base));
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return HIPTS_OK;

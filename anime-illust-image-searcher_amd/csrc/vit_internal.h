@@ -39,6 +39,7 @@ struct GemmArgs {
     float qscale = 1.0f;
     int gelu_tanh = 1;
     int ld_out = 0;                 // row stride of out (elements); 0 = N
+    unsigned long long* stamps = nullptr;   // diagnostic build only (tools/gemm_bench.py): s_memtime stamps of block 0
 };
 
 int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);

@@ -1,0 +1,111 @@
+"""Character-feature stage: host-side mirror of gen_cfeatures.py around the pieces that exist here.
+
+  _normalize / _preprocess_image / gen_image_ndarray     gen_cfeatures.py:100-110,285-295  (pinned: g9)
+  write_vecs_to_index                                     gen_cfeatures.py:307-315         (index.Similarity)
+  character-oriented rerank                               webui.py:255-342, restated per BASELINE.json
+                                                          configs[4] as cosine over the feature index
+The CCIP encoder itself (an ONNX graph fetched from the HF hub, gen_cfeatures.py:112-118) cannot be
+obtained in this environment: `encoder` is a pluggable callable float32[B,3,384,384] -> float32[B,768]
+(DESIGN.md section 6).  The metric model (gen_cfeatures.py:124-130) is likewise opaque; BASELINE.json
+restates the rerank as cosine similarity, which is what runs on the device here:
+difference := 1 - cos(feature, query).
+"""
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .index import Similarity
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)          # gen_cfeatures.py:100
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+BATCH_SIZE = 20                                          # gen_cfeatures.py:50
+DEFAULT_THRESHOLD = 0.17847511429108218                  # docstring value, gen_cfeatures.py:195-196
+
+
+def _normalize(data, mean=CLIP_MEAN, std=CLIP_STD):
+    mean, std = np.asarray(mean), np.asarray(std)
+    return (data - mean[:, None, None]) / std[:, None, None]           # float64, like the reference
+
+
+def _preprocess_image(image, size: int = 384):
+    from PIL import Image
+    image = image.resize((size, size), resample=Image.BILINEAR)
+    data = np.array(image).transpose(2, 0, 1).astype(np.float32) / 255.0
+    return _normalize(data)
+
+
+def gen_image_ndarray(file_path: str) -> Optional[np.ndarray]:
+    """gen_cfeatures.py:285-295 (imgutils.load_images(mode='RGB') = alpha composited on white)."""
+    from PIL import Image
+    try:
+        img = Image.open(file_path)
+        img.load()
+        if img.mode in ("RGBA", "LA"):
+            bg = Image.new("RGB", img.size, (255, 255, 255))
+            bg.paste(img, mask=img.split()[-1])
+            img = bg
+        else:
+            img = img.convert("RGB")
+        return _preprocess_image(img, 384)
+    except Exception as e:
+        print('%s: %s' % (type(e), str(e)))
+        return None
+
+
+class CharacterFeatureIndex:
+    """charactor-featues-idx (+ .csv of paths): feature rows unit-normalised on add (gensim's
+    behaviour for sparse documents, gen_cfeatures.py:310-314), device resident."""
+
+    def __init__(self, encoder: Callable[[np.ndarray], np.ndarray], device: int = 0, prefix: str = "charactor-featues-idx"):
+        self.encoder = encoder
+        self.index = Similarity(prefix, None, 768, device)
+        self.paths: List[str] = []
+        self.threshold = DEFAULT_THRESHOLD
+
+    def ccip_batch_extract_features(self, images: Sequence[np.ndarray]) -> np.ndarray:      # :133-159
+        data = np.stack(images).astype(np.float32)
+        return np.asarray(self.encoder(data), dtype=np.float32)
+
+    def add_files(self, paths: Sequence[str]):
+        for s in range(0, len(paths), BATCH_SIZE):
+            chunk = [(p, gen_image_ndarray(p)) for p in paths[s:s + BATCH_SIZE]]
+            chunk = [(p, a) for p, a in chunk if a is not None]
+            if not chunk:
+                continue
+            feats = self.ccip_batch_extract_features([a for _, a in chunk])
+            self.add_features([p for p, _ in chunk], feats)
+
+    def add_features(self, paths: Sequence[str], feats: np.ndarray):
+        feats = np.asarray(feats, dtype=np.float32)
+        n = np.sqrt((feats.astype(np.float32) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+        self.index.add_matrix(np.where(n > 0, feats / np.where(n > 0, n, 1), feats).astype(np.float32))
+        self.paths.extend(paths)
+
+    def differences(self, query_feature: np.ndarray) -> np.ndarray:
+        """1 - cosine(row, query) for every indexed feature (rows are unit vectors)."""
+        q = np.asarray(query_feature, dtype=np.float32)
+        nq = np.float32(np.sqrt(np.sum(q * q)))
+        if nq > 0:
+            q = q / nq
+        return np.float32(1.0) - self.index.query(q)[0]
+
+
+def cfeatures_rerank(final_scores_top10: Sequence[Tuple[int, float]], top10_features: Sequence[np.ndarray],
+                     cindex: CharacterFeatureIndex, file_tag_index: Dict[str, Dict[str, bool]],
+                     filepath_docid: Dict[str, int], required_tags: Sequence[str], exclude_tags: Sequence[str],
+                     threshold: Optional[float] = None) -> List[Tuple[int, float]]:
+    """webui.py:283-335: mean feature of the top-10 images, difference to every indexed image,
+    keep those below the threshold that carry all required and no excluded tags, best first; the
+    original top-10 lead the list (returned without topn cut or gap filter, like the reference)."""
+    threshold = cindex.threshold if threshold is None else threshold
+    mean = np.average(np.stack(top10_features), axis=0)                               # :303
+    diffs = cindex.differences(mean)                                                  # :306-309 on the device
+    out: List[Tuple[int, float]] = []
+    for idx, path in enumerate(cindex.paths):
+        if path not in file_tag_index:
+            continue                                                                  # :312-323 (not found: ignored)
+        tags = file_tag_index[path]
+        if diffs[idx] < threshold and all(t in tags for t in required_tags) and all(t not in tags for t in exclude_tags):
+            out.append((filepath_docid[path], float(np.float32(1.0) - diffs[idx])))   # :325-328
+    out = sorted(out, key=lambda it: -it[1])                                          # :330
+    return list(final_scores_top10) + out                                            # :332-335

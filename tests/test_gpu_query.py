@@ -250,3 +250,29 @@ def test_find_similar_documents_matches_oracle():
         want = osearch.rerank(final, 50, rerank_sims)
         assert [d for d, _ in got] == [d for d, _ in want], query
         np.testing.assert_array_equal(np.array([s for _, s in got]), np.array([s for _, s in want]))
+
+
+# --------------------------------------------------------------------------------- character features (config[4] rerank)
+def test_cfeatures_rerank_cosine():
+    from hiptagsearch.cfeatures import CharacterFeatureIndex, cfeatures_rerank
+    rng = np.random.default_rng(3)
+    n = 5000
+    feats = rng.standard_normal((n, 768)).astype(np.float32)
+    feats[100:140] = feats[7] + 0.05 * rng.standard_normal((40, 768)).astype(np.float32)      # near-duplicates of image 7
+    paths = ["img%05d.png" % i for i in range(n)]
+    ci = CharacterFeatureIndex(encoder=lambda x: np.zeros((len(x), 768), np.float32))
+    ci.add_features(paths[: n // 2], feats[: n // 2])
+    ci.add_features(paths[n // 2:], feats[n // 2:])
+    unit = feats / np.linalg.norm(feats, axis=1, keepdims=True)
+    q = feats[7]
+    d = ci.differences(q)
+    want = 1.0 - unit @ (q / np.linalg.norm(q))
+    np.testing.assert_allclose(d, want, atol=2e-6)
+    tags = {p: {"a": True} if i % 2 == 0 else {"a": True, "b": True} for i, p in enumerate(paths)}
+    docid = {p: i for i, p in enumerate(paths)}
+    top10 = [(7, 0.9)]
+    res = cfeatures_rerank(top10, [feats[7]], ci, tags, docid, required_tags=["a"], exclude_tags=["b"], threshold=0.05)
+    ids = [i for i, _ in res[1:]]
+    assert res[0] == (7, 0.9)
+    assert set(ids) == {i for i in list(range(100, 140)) + [7] if i % 2 == 0}
+    assert all(res[i][1] >= res[i + 1][1] for i in range(1, len(res) - 1))

@@ -152,3 +152,22 @@ def test_query_parsers():
     assert allw == 3
     assert bm == [("1girl", "plain", 1), ("blue_eyes", "require", 2), ("hat", "exclude", -3), ("foo:bar", "plain", 1),
                   ("a_(b)", "exclude", 2)]
+
+
+# ---------------------------------------------------------------- G9: CCIP preprocessing
+def test_ccip_preprocess_matches_reference(golden_dir):
+    import hashlib
+    from PIL import Image
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "cfeatures_host", os.path.join(os.path.dirname(golden_dir), "..", "anime-illust-image-searcher_amd", "hiptagsearch", "cfeatures.py"))
+    src = open(spec.origin).read()
+    # host-only functions: exec the module text without its package-relative import
+    ns = {}
+    exec(compile(src.replace("from .index import Similarity", "Similarity = None"), spec.origin, "exec"), ns)
+    for c in _load(golden_dir, "g9_ccip_preprocess.json"):
+        arr = np.random.default_rng(c["seed"]).integers(0, 256, (c["h"], c["w"], 3), dtype=np.uint8)
+        o = ns["_preprocess_image"](Image.fromarray(arr), size=384)
+        assert str(o.dtype) == c["dtype"] and list(o.shape) == c["shape"]
+        assert [float(v).hex() for v in o[:, ::96, ::96].ravel()] == c["sample_hex"]
+        assert hashlib.sha256(np.ascontiguousarray(o).tobytes()).hexdigest() == c["sha256"]
