@@ -14,6 +14,7 @@
 // numpy's operation order with one rounding per operation.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <unordered_map>
 #include <vector>
@@ -34,7 +35,8 @@ struct hipts_bm25 {
     std::vector<int32_t> h_term, h_tf;
     std::vector<double> h_idf;
     DevBuf d_ptr, d_term, d_tf, d_dl, d_idf;   // int64[D+1], int32[nnz], int32[nnz], int32[D], double[V]
-    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final;
+    DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
+    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark;
 };
 
 namespace {
@@ -84,6 +86,83 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const int64_t* __restri
     out[(int64_t)q * D + d] = masked ? -INFINITY : s;
 }
 
+// Postings form of the same arithmetic (default): one workgroup per query walks the posting list
+// of each query term IN THE QUERY'S TERM ORDER (a barrier between terms keeps the float64 additions
+// of one document in the reference's order).  Documents that do not contain a term would add
+// idf * (0 / denom) = +0.0, which leaves a non-negative score unchanged, so skipping them is exact.
+// Reads sum(df) * 8 B + a few passes over D instead of the whole corpus per query.
+// mark[d]: bit 7 = an excluded term is present, low bits = number of required terms present.
+__global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __restrict__ tptr, const int32_t* __restrict__ tdoc,
+                                                             const int32_t* __restrict__ ttf, const int32_t* __restrict__ dl,
+                                                             const double* __restrict__ idf, int32_t V, double avgdl, int64_t D,
+                                                             const int32_t* __restrict__ q_terms, const double* __restrict__ q_weights,
+                                                             const int32_t* __restrict__ q_ptr, double* __restrict__ out,
+                                                             uint8_t* __restrict__ mark_all, double* __restrict__ max_out) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int qb = q_ptr[q], qe = q_ptr[q + 1];
+    double* __restrict__ scores = out + (int64_t)q * D;
+    uint8_t* __restrict__ mark = mark_all + (int64_t)q * D;
+    int n_required = 0;
+    bool masking = false;
+    for (int j = qb; j < qe; ++j) {
+        const double w = q_weights[j];
+        if (w > REQUIRE_MAGIC) ++n_required;
+        if (w > REQUIRE_MAGIC || w < 0.0) masking = true;
+    }
+    for (int64_t d = tid; d < D; d += 1024) {
+        scores[d] = 0.0;
+        if (masking) mark[d] = 0;
+    }
+    __syncthreads();
+    for (int j = qb; j < qe; ++j) {
+        const int32_t t = q_terms[j];
+        const double w = q_weights[j];
+        if (t >= 0 && t < V) {
+            const double idf_t = idf[t];
+            const int64_t b = tptr[t], e = tptr[t + 1];
+            for (int64_t i = b + tid; i < e; i += 1024) {
+                const int32_t d = tdoc[i];
+                if (w < 0.0) {
+                    mark[d] |= 0x80;
+                } else {
+                    const double tfd = (double)ttf[i];
+                    const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * ((double)dl[d] / avgdl));
+                    const double sc = idf_t * ((tfd * (BM25_K1 + 1.0)) / (tfd + nrm));
+                    if (w > REQUIRE_MAGIC) {
+                        scores[d] += (w - REQUIRE_MAGIC) * sc;
+                        mark[d] += 1;
+                    } else {
+                        scores[d] += w * sc;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double mx = -INFINITY;
+    if (masking) {
+        for (int64_t d = tid; d < D; d += 1024) {
+            const uint8_t m = mark[d];
+            double v = scores[d];
+            if ((m & 0x80) || (m & 0x7f) != n_required) scores[d] = v = -INFINITY;
+            mx = fmax(mx, v);
+        }
+    } else if (max_out) {
+        for (int64_t d = tid; d < D; d += 1024) mx = fmax(mx, scores[d]);
+    }
+    if (max_out) {      // row maximum for the normalisation of webui.py:379-380, fused here
+        __shared__ double part[16];
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) part[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            double m = part[0];
+            for (int w = 1; w < 16; ++w) m = fmax(m, part[w]);
+            max_out[q] = m;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // row maxima (numpy .max(): NaN-free inputs assumed)
 // ---------------------------------------------------------------------------------------------
@@ -103,11 +182,21 @@ __global__ __launch_bounds__(1024) void rowmax_kernel(const T* __restrict__ v, i
     }
 }
 
+// order-preserving u32 image of a float (for atomicMax); 0 is below every real value
+__device__ __forceinline__ uint32_t float_order_key(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_key(uint32_t k) {
+    return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k);
+}
+
 // webui.py:377-383 (and :208 with norm flags off):
 //   out = wa * (a / max_a) + (double)((float)wb * (b / max_b))
 __global__ __launch_bounds__(256) void combine_kernel(const double* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                       double wa, float wb, const double* __restrict__ max_a,
-                                                      const float* __restrict__ max_b, double* __restrict__ out) {
+                                                      const float* __restrict__ max_b, const uint32_t* __restrict__ max_b_keys,
+                                                      double* __restrict__ out) {
     const int q = blockIdx.y;
     const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (d >= n) return;
@@ -117,8 +206,8 @@ __global__ __launch_bounds__(256) void combine_kernel(const double* __restrict__
         const double m = max_a[q];
         if (m > 0.0) A = A / m;
     }
-    if (max_b) {
-        const float m = max_b[q];
+    if (max_b || max_b_keys) {
+        const float m = max_b ? max_b[q] : float_from_key(max_b_keys[q]);
         if (m > 0.0f) B = B / m;
     }
     const float wB = wb * B;                      // python float * float32 array stays float32
@@ -132,6 +221,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const double* __restrict__
 // (the kernel is HBM-bound: 32 x 1200 B per 150 MFMAs per wave).
 // =============================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 
 __global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__ index, int64_t D, int K, int64_t ld,
                                                        const float* __restrict__ q, int nq, float* __restrict__ out,
@@ -409,12 +499,25 @@ int launch_sim(const float* index, int64_t D, int K, const float* q_dev, int nq,
 }
 
 int launch_bm25(hipts_bm25* h, const int32_t* qt_dev, const double* qw_dev, const int32_t* qp_dev, int nq, double* out_dev,
-                hipStream_t s) {
+                hipStream_t s, double* max_out = nullptr) {
+    static const bool scan = getenv("HIPTS_BM25") && strcmp(getenv("HIPTS_BM25"), "scan") == 0;   // A/B: document-major scan
+    if (!scan) {
+        HIPTS_TRY(h->ws_mark.reserve((size_t)nq * h->D));
+        bm25_postings_kernel<<<nq, 1024, 0, s>>>(h->d_tptr.as<int64_t>(), h->d_tdoc.as<int32_t>(), h->d_ttf.as<int32_t>(),
+                                                 h->d_dl.as<int32_t>(), h->d_idf.as<double>(), h->V, h->avgdl, h->D, qt_dev, qw_dev,
+                                                 qp_dev, out_dev, h->ws_mark.as<uint8_t>(), max_out);
+        HIPTS_LAUNCH_CHECK();
+        return HIPTS_OK;
+    }
     dim3 grid(ceil_div(h->D, 256), nq);
     bm25_score_kernel<<<grid, 256, 0, s>>>(h->d_ptr.as<int64_t>(), h->d_term.as<int32_t>(), h->d_tf.as<int32_t>(),
                                            h->d_dl.as<int32_t>(), h->d_idf.as<double>(), h->V, h->avgdl, h->D, qt_dev, qw_dev,
                                            qp_dev, out_dev);
     HIPTS_LAUNCH_CHECK();
+    if (max_out) {
+        rowmax_kernel<double><<<nq, 1024, 0, s>>>(out_dev, h->D, max_out);
+        HIPTS_LAUNCH_CHECK();
+    }
     return HIPTS_OK;
 }
 
@@ -490,13 +593,29 @@ int hipts_bm25_build(const int64_t* doc_ptr, const int32_t* term_ids, int64_t nu
     }
     std::vector<int32_t> dl32((size_t)num_docs);
     for (int64_t d = 0; d < num_docs; ++d) dl32[d] = (int32_t)h->h_dl[d];
+    // term-major postings (documents ascending inside a term) for the postings kernel
+    std::vector<int64_t> tptr((size_t)vocab + 1, 0);
+    for (int32_t t = 0; t < vocab; ++t) tptr[t + 1] = tptr[t] + h->h_df[t];
+    std::vector<int32_t> tdoc((size_t)h->nnz), ttf((size_t)h->nnz);
+    {
+        std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+        for (int64_t d = 0; d < num_docs; ++d)
+            for (int64_t i = h->h_ptr[d]; i < h->h_ptr[d + 1]; ++i) {
+                const int64_t pos = fill[h->h_term[i]]++;
+                tdoc[pos] = (int32_t)d;
+                ttf[pos] = h->h_tf[i];
+            }
+    }
     int st = HIPTS_OK;
     if ((st = h->d_ptr.alloc((size_t)(num_docs + 1) * 8)) || (st = h->d_term.alloc((size_t)h->nnz * 4)) ||
         (st = h->d_tf.alloc((size_t)h->nnz * 4)) || (st = h->d_dl.alloc((size_t)num_docs * 4)) ||
         (st = h->d_idf.alloc((size_t)vocab * 8)) || (st = upload(h->d_ptr.p, h->h_ptr.data(), (size_t)(num_docs + 1) * 8)) ||
         (st = upload(h->d_term.p, h->h_term.data(), (size_t)h->nnz * 4)) ||
         (st = upload(h->d_tf.p, h->h_tf.data(), (size_t)h->nnz * 4)) || (st = upload(h->d_dl.p, dl32.data(), (size_t)num_docs * 4)) ||
-        (st = upload(h->d_idf.p, h->h_idf.data(), (size_t)vocab * 8))) {
+        (st = upload(h->d_idf.p, h->h_idf.data(), (size_t)vocab * 8)) || (st = h->d_tptr.alloc((size_t)(vocab + 1) * 8)) ||
+        (st = h->d_tdoc.alloc((size_t)h->nnz * 4)) || (st = h->d_ttf.alloc((size_t)h->nnz * 4)) ||
+        (st = upload(h->d_tptr.p, tptr.data(), (size_t)(vocab + 1) * 8)) || (st = upload(h->d_tdoc.p, tdoc.data(), (size_t)h->nnz * 4)) ||
+        (st = upload(h->d_ttf.p, ttf.data(), (size_t)h->nnz * 4))) {
         delete h;
         return st;
     }
@@ -660,7 +779,7 @@ int hipts_combine(const double* a, const float* b, int nq, int64_t n, double wa,
         HIPTS_LAUNCH_CHECK();
     }
     dim3 grid(ceil_div(n, 256), nq);
-    combine_kernel<<<grid, 256, 0, s>>>(a, b, n, wa, (float)wb, norm_a ? ma : nullptr, norm_b ? mb : nullptr, out);
+    combine_kernel<<<grid, 256, 0, s>>>(a, b, n, wa, (float)wb, norm_a ? ma : nullptr, norm_b ? mb : nullptr, nullptr, out);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
@@ -721,10 +840,22 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
         HIPTS_TRY(bm25->ws_final.reserve((size_t)nq * D * 8));
         final_dev = bm25->ws_final.as<double>();
     }
-    HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s));
+    // row maxima (webui.py:377-380): the BM25 workgroup reduces its own row while it still owns it; the
+    // index product's maximum is a separate pass (folding it into the product with one atomicMax per
+    // tile and query was measured 3.5x SLOWER: 200k atomics on 32 addresses).
+    HIPTS_TRY(bm25->ws_max.reserve((size_t)nq * 16));
+    double* ma = bm25->ws_max.as<double>();
+    float* mb = reinterpret_cast<float*>(ma + nq);
+    HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
     HIPTS_TRY(launch_sim(index->rows.as<float>(), D, index->dim, index->ws_q.as<float>(), nq, bm25->ws_sims.as<float>(), D, s));
-    HIPTS_TRY(hipts_combine(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), nq, D, w_bm25, w_sim, 1, 1, final_dev,
-                            bm25->device, stream));
+    rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
+    HIPTS_LAUNCH_CHECK();
+    {
+        dim3 grid(ceil_div(D, 256), nq);
+        combine_kernel<<<grid, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, ma,
+                                            mb, nullptr, final_dev);
+        HIPTS_LAUNCH_CHECK();
+    }
     return hipts_topk(final_dev, nq, D, k, ids_out, vals_out, HIPTS_HOST, bm25->device, stream);
 }
 
