@@ -125,11 +125,29 @@ def query_section(device):
     cpu_qps = nq_cpu / (time.perf_counter() - t0)
     gi, _ = eng.score_topk(qs[nq_cpu - 1:nq_cpu], qv[nq_cpu - 1:nq_cpu], TOPK)
     assert np.array_equal(gi[0], wi), "GPU/CPU top-k mismatch"
+    # Doc2Vec PV-DBOW inference of every document (genmodel.py:168-169): 100 epochs, 300-d, negative 5
+    from hiptagsearch.d2v import Doc2VecInference
+    from oracle import d2v as od2v
+    m = synth.d2v_model(synth.term_counts(ptr, terms, V), dim=K, seed=44)
+    v0, seeds = synth.d2v_inputs(D, K, seed=44)
+    model = Doc2VecInference(m["syn1neg"], m["cum_table"], m["sample_int"], {}, epochs=100, device=device)
+    n_gpu = 20_000
+    model.infer_batch(ptr[:257], terms[:ptr[256]], v0[:256], seeds[:256])               # warm-up
+    t0 = time.perf_counter()
+    got = model.infer_batch(ptr[:n_gpu + 1], terms[:ptr[n_gpu]], v0[:n_gpu], seeds[:n_gpu])
+    d2v_gpu = n_gpu / (time.perf_counter() - t0)
+    n_cpu = 24
+    t0 = time.perf_counter()
+    want = od2v.infer(m["syn1neg"], m["cum_table"], m["sample_int"], ptr[:n_cpu + 1], terms[:ptr[n_cpu]], v0[:n_cpu], seeds[:n_cpu], 100)
+    d2v_cpu = n_cpu / (time.perf_counter() - t0)
+    assert got[:n_cpu].tobytes() == want.tobytes(), "GPU/CPU Doc2Vec vectors differ"
     bytes_per_query = D * K * 4 + bm.nnz * 8 + D * (4 + 8 + 4 + 8 + 8)
     return {"metric": "top-100 queries/sec over 100k-doc index (BM25 + 300-d index product, fused)",
             "batched_qps": batched, "single_query_qps": single, "batch": chunk,
             "algorithmic_bytes_per_query": bytes_per_query,
-            "cpu_port_qps": cpu_qps, "cpu_port_sample": "%d queries, numpy CSR BM25 + C fma-chain + lexsort, 1 thread" % nq_cpu}
+            "cpu_port_qps": cpu_qps, "cpu_port_sample": "%d queries, numpy CSR BM25 + C fma-chain + lexsort, 1 thread" % nq_cpu,
+            "d2v_infer_docs_per_s": d2v_gpu, "d2v_sample": "%d docs x 100 epochs, host buffers in/out" % n_gpu,
+            "d2v_cpu_port_docs_per_s": d2v_cpu, "d2v_cpu_sample": "%d docs, C oracle, 1 thread (reference: workers=1)" % n_cpu}
 
 
 def main():
