@@ -29,11 +29,13 @@ constexpr int K_BYTES = KV * KS;     // 9216
 constexpr int V_BYTES = 64 * VS;     // 8704
 constexpr int STAGE = K_BYTES + V_BYTES;
 
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// Written with plain fmaxf so the compiler sees the MFMA -> VALU dependency and inserts the required
+// wait states itself.  (An inline-asm v_max3_f32 here read accumulator registers before the MFMA had
+// retired them: hipcc pads nothing around asm operands -- results differed run to run by a few bf16
+// ulps.)  This file is compiled with -fno-honor-nans, which drops the canonicalising v_max that fmaxf
+// on MFMA results otherwise costs (45 v_max + 9 v_max3 per tile instead of 17 v_max3); no NaN can
+// occur: every tile has at least one unmasked key, so the running maximum is finite.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -57,8 +59,6 @@ __device__ __forceinline__ void attn_tile(const char* __restrict__ st, int kv0, 
             sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[g], 0, 0, 0);
         }
     }
-    // v_max3_f32 written out: fmaxf() on MFMA results makes hipcc insert a canonicalising v_max per
-    // operand (45 v_max + 9 v_max3 per tile instead of 17 instructions).
     float mx = max3f(sacc[0][0], sacc[1][0], m_run);
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = max3f(mx, sacc[0][i], sacc[1][i]);

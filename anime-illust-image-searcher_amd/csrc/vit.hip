@@ -760,3 +760,41 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     (void)hipEventDestroy(e1);
     return HIPTS_OK;
 }
+
+// Development/test aid (not part of the public ABI): C = A W^T through the production GEMM kernel
+// (EPI_RESID with a zero residual and zero bias), fp32 result copied to the host.
+extern "C" int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host) {
+    HIPTS_TRY(use_device(0));
+    HIPTS_REQUIRE(M >= 1 && N >= 16 && N % 16 == 0 && K >= 64 && K % 64 == 0, "hiptsdbg_gemm_run: unsupported shape");
+    const int Np = round_up(N, 256);
+    DevBuf A, W, bias, out;
+    HIPTS_TRY(A.alloc((size_t)M * K * 2));
+    HIPTS_TRY(W.alloc((size_t)Np * K * 2));
+    HIPTS_TRY(bias.alloc((size_t)Np * 4));
+    HIPTS_TRY(out.alloc((size_t)M * N * 4));
+    HIPTS_HIP(hipMemset(W.p, 0, W.bytes));
+    HIPTS_HIP(hipMemset(bias.p, 0, bias.bytes));
+    HIPTS_HIP(hipMemset(out.p, 0, out.bytes));
+    HIPTS_TRY(upload(A.p, a_bf16, (size_t)M * K * 2));
+    HIPTS_TRY(upload(W.p, w_bf16, (size_t)N * K * 2));
+    GemmArgs g{};
+    g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>(); g.out_f32 = out.as<float>();
+    HIPTS_TRY(launch_gemm(EPI_RESID, g, nullptr));
+    HIPTS_HIP(hipMemcpy(out_host, out.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}
+
+// Development aid: copy one workspace buffer of the last forward to the host (tools/determinism.py).
+extern "C" int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes) {
+    HIPTS_REQUIRE(h && name && out_host && bytes, "null argument");
+    HIPTS_TRY(use_device(h->device));
+    const std::string n(name);
+    const DevBuf* b = n == "a0" ? &h->a0 : n == "x" ? &h->x : n == "xn" ? &h->xn : n == "q" ? &h->q : n == "k" ? &h->k
+                      : n == "vT" ? &h->vT : n == "att" ? &h->att : n == "hmid" ? &h->hmid : n == "pool_part" ? &h->pool_part
+                      : n == "pooled2" ? &h->pooled2 : nullptr;
+    HIPTS_REQUIRE(b, "unknown buffer %s", name);
+    *bytes = b->bytes < max_bytes ? b->bytes : max_bytes;
+    HIPTS_HIP(hipDeviceSynchronize());
+    HIPTS_HIP(hipMemcpy(out_host, b->p, *bytes, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}

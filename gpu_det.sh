@@ -1,3 +1,3 @@
 #!/bin/bash
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
-timeout -k 10 900 python -m pytest "$@" -m gpu -x -q -s 2>&1 | tail -30
+timeout -k 10 300 python tools/determinism.py 1 2 2>&1 | tail -8

@@ -1,0 +1,66 @@
+"""GPU: the bf16 MFMA GEMM main loops (ping-pong 16/32-MFMA segments, three-stage, two-barrier) against
+a float64 product of the same bf16 operands, on ragged and exact shapes, plus run-to-run determinism of
+the whole forward (a race in the LDS-DMA pipeline shows up as nondeterminism before it shows as error)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = [(256, 256, 64), (1, 16, 64), (300, 272, 128), (784, 768, 768), (1000, 2304, 768), (513, 3072, 192), (777, 768, 3072)]
+
+_CHILD = r"""
+import ctypes, sys, numpy as np
+sys.path.insert(0, %(pkg)r)
+from hiptagsearch import _lib, synth
+lib = _lib.load()
+f = lib.hiptsdbg_gemm_run
+f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
+bad = []
+for (M, N, K) in %(shapes)r:
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = synth.round_to_bf16(rng.standard_normal((M, K)).astype(np.float32))
+    w = synth.round_to_bf16((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+    a16 = (a.view(np.uint32) >> 16).astype(np.uint16); w16 = (w.view(np.uint32) >> 16).astype(np.uint16)
+    out = np.empty((M, N), np.float32); out2 = np.empty((M, N), np.float32)
+    for o in (out, out2):
+        st = f(M, N, K, a16.ctypes.data, w16.ctypes.data, o.ctypes.data)
+        assert st == 0, _lib.last_error()
+    want = a.astype(np.float64) @ w.astype(np.float64).T
+    err = np.abs(out - want).max()
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-6          # fp32 accumulation of exact bf16 products
+    if err > tol or not np.array_equal(out, out2):
+        bad.append((M, N, K, float(err), tol, bool(np.array_equal(out, out2))))
+print("BAD", bad)
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("variant", ["pp", "pp2", "s3", "v1"])
+def test_gemm_variants_match_float64(variant):
+    """Each variant is selected per process (HIPTS_GEMM is read once), hence the child interpreter."""
+    env = dict(os.environ, HIPTS_GEMM=variant)
+    code = _CHILD % {"pkg": os.path.join(ROOT, "anime-illust-image-searcher_amd"), "shapes": SHAPES}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_forward_is_deterministic_and_batch_invariant():
+    from hiptagsearch import synth
+    from hiptagsearch.tagger import ViTTagger
+    cfg = dict(synth.VIT_B16_448)
+    cfg["depth"] = 3                                       # full-width layers, short enough to repeat
+    w = synth.vit_weights(cfg, seed=5)
+    imgs = synth.images_u8(9, 448, seed=6)
+    model = ViTTagger(cfg, w, max_batch=16)
+    ref, _ = model.forward_u8(imgs)
+    for _ in range(4):
+        again, _ = model.forward_u8(imgs)
+        np.testing.assert_array_equal(again, ref)          # bitwise: no race, no atomics in the forward
+    one, _ = model.forward_u8(imgs[4:5])                   # an image's logits do not depend on its batch
+    np.testing.assert_array_equal(one[0], ref[4])
