@@ -39,13 +39,15 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 
 __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
-// One 64-key tile for one wave (32 queries).  q is pre-scaled by head_dim^-0.5 * log2(e) in the QK
-// GEMM epilogue, so scores are already in the base-2 domain.  MASK (last tile only): keys >= tokens
-// start their accumulator at -inf, which the MFMA carries through (no per-score compare/select).
+// The per-tile work of one wave (32 queries x 64 keys), split in three so that the loop can be
+// software-pipelined:   S(t) MFMAs | P(t-1) V(t-1) MFMAs | softmax(t) on the VALU.
+// The second MFMA group keeps the matrix pipe busy while the VALU chews on S(t); by the time the
+// softmax wants to rescale O, the P V product it must include has retired.
+// q is pre-scaled by head_dim^-0.5 * log2(e) in the QK GEMM epilogue: scores are in the base-2 domain.
+// MASK (last tile only): keys >= tokens start their accumulator at -inf, which the MFMA carries through.
 template <bool MASK>
-__device__ __forceinline__ void attn_tile(const char* __restrict__ st, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[4],
-                                          f32x16 (&o)[2], float& m_run, float& l_run) {
-    f32x16 sacc[2];
+__device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[4],
+                                       f32x16 (&sacc)[2]) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -55,35 +57,16 @@ __device__ __forceinline__ void attn_tile(const char* __restrict__ st, int kv0, 
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
             sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[g], 0, 0, 0);
         }
     }
-    float mx = max3f(sacc[0][0], sacc[1][0], m_run);
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = max3f(mx, sacc[0][i], sacc[1][i]);
-    const float m_new = max3f(mx, __shfl_xor(mx, 32), mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float lsum0 = 0.f, lsum1 = 0.f;
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
-            if (i & 1) lsum1 += p; else lsum0 += p;
-            pf[g][i >> 3][i & 7] = (bf16_t)p;
-        }
-    l_run = l_run * alpha + (lsum0 + lsum1);
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        o[0][i] *= alpha;
-        o[1][i] *= alpha;
-    }
+}
+
+__device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int h, const bf16x8 (&pf)[2][2], f32x16 (&o)[2]) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-        const char* vrow = st + K_BYTES + (blk * 32 + r) * VS;
+        const char* vrow = vt + (blk * 32 + r) * VS;
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -97,10 +80,37 @@ __device__ __forceinline__ void attn_tile(const char* __restrict__ st, int kv0, 
     }
 }
 
+__device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2], float& m_run,
+                                             float& l_run) {
+    float mx = max3f(sacc[0][0], sacc[1][0], m_run);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = max3f(mx, sacc[0][i], sacc[1][i]);
+    const float m_new = fmaxf(mx, __shfl_xor(mx, 32));
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
+            if (i & 1) lsum1 += p; else lsum0 += p;
+            pf[g][i >> 3][i & 7] = (bf16_t)p;
+        }
+    l_run = l_run * alpha + (lsum0 + lsum1);
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {       // O already holds every tile before this one (incl. the P V just issued)
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
                                                    int tokens, int tokens_pad, int qblocks) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    // three stages: iteration t multiplies K(t) from stage t%3 and V(t-1) from stage (t-1)%3 while
+    // tile t+1 is written into stage (t+1)%3 (whose K and V were last read before the previous barrier)
+    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware work id: workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
@@ -153,22 +163,43 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
         o[1][i] = 0.f;
     }
     float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sacc[2];
+    bf16x8 pf[2][2];
 
     const int nkv = tokens_pad / KV;
+    const bool masked_tail = tokens_pad > tokens;
     ATTN_LOAD(0)
     ATTN_WRITE(smem)
     __syncthreads();
-    for (int t = 0; t + 1 < nkv; ++t) {
-        ATTN_LOAD((t + 1) * KV)
-        attn_tile<false>(smem + (t & 1) * STAGE, t * KV, tokens, r, h, qf, o, m_run, l_run);
-        ATTN_WRITE(smem + ((t + 1) & 1) * STAGE)
+    // tile 0: scores and softmax only (its P V is issued in the next iteration)
+    if (nkv > 1) {
+        ATTN_LOAD(KV)
+    }
+    if (nkv == 1 && masked_tail) s_tile<true>(smem, 0, tokens, r, h, qf, sacc);
+    else s_tile<false>(smem, 0, tokens, r, h, qf, sacc);
+    softmax_tile(sacc, pf, o, m_run, l_run);
+    if (nkv > 1) {
+        ATTN_WRITE(smem + STAGE)
+    }
+    __syncthreads();
+    int cur = 1, prev = 0;                    // stage of K(t) / of V(t-1)
+    for (int t = 1; t < nkv; ++t) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        if (t + 1 < nkv) {
+            ATTN_LOAD((t + 1) * KV)
+        }
+        if (t + 1 == nkv && masked_tail) s_tile<true>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
+        else s_tile<false>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
+        pv_tile(smem + prev * STAGE + K_BYTES, r, h, pf, o);
+        softmax_tile(sacc, pf, o, m_run, l_run);
+        if (t + 1 < nkv) {
+            ATTN_WRITE(smem + nxt * STAGE)
+        }
         __syncthreads();
+        prev = cur;
+        cur = nxt;
     }
-    {
-        const int t = nkv - 1;
-        if (tokens_pad > tokens) attn_tile<true>(smem + (t & 1) * STAGE, t * KV, tokens, r, h, qf, o, m_run, l_run);
-        else attn_tile<false>(smem + (t & 1) * STAGE, t * KV, tokens, r, h, qf, o, m_run, l_run);
-    }
+    pv_tile(smem + prev * STAGE + K_BYTES, r, h, pf, o);
 #undef ATTN_LOAD
 #undef ATTN_WRITE
 
