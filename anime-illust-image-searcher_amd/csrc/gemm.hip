@@ -75,8 +75,8 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
 // latencies overlap instead of forming a chain of 32 dependent round trips.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[8][4], int m0, int n0, int wave_m, int wave_n,
+template <int EPI, int MR = 8>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
                                               int lane) {
     const int lr = lane & 15, lq = lane >> 4;
     const int ld = a.ld_out ? a.ld_out : a.N;
@@ -89,8 +89,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             bv[j] = n < a.N ? a.bias[n] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wave_m * 128 + i * 16 + 4 * lq;
+        for (int i = 0; i < MR; ++i) {
+            const int m = m0 + wave_m * (MR * 16) + i * 16 + 4 * lq;
             if (m >= a.M) continue;
             const int b = m / a.tokens, t = m - b * a.tokens;
 #pragma unroll
@@ -107,8 +107,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         }
     } else if constexpr (EPI == EPI_HEAD) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wave_m * 128 + i * 16 + lr;
+        for (int i = 0; i < MR; ++i) {
+            const int m = m0 + wave_m * (MR * 16) + i * 16 + lr;
             if (m >= a.M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -138,18 +138,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             // read-modify-write of the fp32 residual stream: 8 x 16 B loads per lane in flight
             // (two 16-row blocks) before the first dependent add, so a CU keeps ~64 KB outstanding.
 #pragma unroll
-            for (int i2 = 0; i2 < 8; i2 += 2) {
+            for (int i2 = 0; i2 < MR; i2 += 2) {
                 f32x4 xv[2][4];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int m = m0 + wave_m * 128 + (i2 + u) * 16 + lr;
+                    if (i2 + u >= MR) continue;
+                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     const float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int m = m0 + wave_m * 128 + (i2 + u) * 16 + lr;
+                    if (i2 + u >= MR) continue;
+                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     if (m >= a.M) continue;
                     float* row = a.out_f32 + (size_t)m * ld;
 #pragma unroll
@@ -160,8 +162,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wave_m * 128 + i * 16 + lr;
+        for (int i = 0; i < MR; ++i) {
+            const int m = m0 + wave_m * (MR * 16) + i * 16 + lr;
             if (m >= a.M) continue;
             if constexpr (EPI == EPI_PATCH) {
                 const int t = m % a.tokens;
@@ -283,8 +285,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a, int tiles_m
 // restaged sooner than 3 phases after its last ds_read (WAR).
 // Barriers are raw s_barrier: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
 // ---------------------------------------------------------------------------------------------
-template <int EPI>
+// MR = 16-row blocks per wave: 8 -> 256-row tiles, 7 -> 224-row tiles (50176 = 224 * 224: for N = 768 the
+// grid becomes 672 tiles = 3 rounds of 0.875-size tiles instead of 588 = 3 rounds (2.3 needed) of full ones).
+template <int EPI, int MR = 8>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -297,18 +302,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * BN;
     const int K = a.K, nt = K / BK;
     const int w_rows = tiles_n * BN;
 
-    f32x4 acc[8][4];
+    f32x4 acc[MR][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // prologue: K-tile 0 complete
-    stage_tile(a.A, a.M, K, m0, 0, smem, wave, lane);
+    if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0, 0, smem, wave, lane);     // 4 MR sub-tiles of 8 rows (wave 7 idle for MR = 7)
     stage_tile(a.W, w_rows, K, n0, 0, smem + TILE_BYTES, wave, lane);
 
     // This wave's eight staging slots of a K-tile (two per phase), as (global source pointer for
@@ -327,14 +332,34 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
             src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + BK + chunk * 8;
             dst[idx] = (isW ? TILE_BYTES : 0) + rb8 * 1024;
         };
+        // A-low = the first 64 rows of each wave group (8-row blocks g*2*MR + 0..7): 16 sub-tiles, 2 per wave.
+        // A-high = the remaining (2 MR - 8) blocks of each group: 16 (MR = 8) or 12 (MR = 7) sub-tiles; with
+        // MR = 7 waves 4..7 have one (n_hi = 1) and their counted waits are one lower.
         for (int u = 0; u < 2; ++u) {
             const int e = 2 * wave + u;
             slot(0 + u, true, e);
             slot(2 + u, true, 16 + e);
-            slot(4 + u, false, e < 8 ? e : e + 8);
-            slot(6 + u, false, e < 8 ? 8 + e : 16 + e);
+            slot(4 + u, false, e < 8 ? e : 2 * MR + (e - 8));
+        }
+        if constexpr (MR == 8) {
+            for (int u = 0; u < 2; ++u) {
+                const int e = 2 * wave + u;
+                slot(6 + u, false, e < 8 ? 8 + e : 2 * MR + 8 + (e - 8));
+            }
+        } else {
+            // 12 sub-tiles: group 0 blocks 8..13, group 1 blocks 2MR+8 .. 2MR+13; waves 0..3 take two, 4..7 one
+            auto hi = [](int f) { return f < 6 ? 8 + f : 2 * MR + 8 + (f - 6); };
+            if (wave < 4) {
+                slot(6, false, hi(2 * wave));
+                slot(7, false, hi(2 * wave + 1));
+            } else {
+                slot(6, false, hi(8 + (wave - 4)));
+                src[7] = src[6];
+                dst[7] = dst[6];
+            }
         }
     }
+    const int n_hi = (MR == 8 || wave < 4) ? 2 : 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
@@ -354,14 +379,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                 for (int j = 0; j < 4; ++j) wf[kk][j] = read_frag(cur + TILE_BYTES, wave_n * 4 + j, kk, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag(cur, wave_m * 8 + mh * 4 + i, kk, lane);
+            for (int i = 0; i < 4; ++i)
+                if (mh * 4 + i < MR) af[i] = read_frag(cur, wave_m * MR + mh * 4 + i, kk, lane);
             if (more) {
                 glds16(src[2 * p], nxt + dst[2 * p]);
-                glds16(src[2 * p + 1], nxt + dst[2 * p + 1]);
                 src[2 * p] += BK;
-                src[2 * p + 1] += BK;
-                if (p == 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // W and A-low of tile t+1 landed
-                else if (p == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                if (p < 3 || n_hi == 2) {
+                    glds16(src[2 * p + 1], nxt + dst[2 * p + 1]);
+                    src[2 * p + 1] += BK;
+                }
+                if (p == 3) {           // W and A-low of tile t+1 landed; only this phase's A-high may be in flight
+                    if (n_hi == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                } else if (p == 1) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                }
             } else if (p == 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -376,6 +408,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if (mh * 4 + i >= MR) continue;
                     if constexpr (EPI == EPI_VT)
                         acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[kk][j], acc[mh * 4 + i][j], 0, 0, 0);
                     else
@@ -388,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         }
     }
     if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
-    gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
+    gemm_epilogue<EPI, MR>(a, acc, m0, n0, wave_m, wave_n, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -653,7 +686,8 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
         attr = true;
@@ -676,8 +710,27 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             }
             gemm_pp2_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
         }
-        else if (variant == 1)
-            gemm_pp_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+        else if (variant == 1) {
+            // 256- or 224-row tiles, whichever needs fewer (size-weighted) rounds over the CUs
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                HIPTS_HIP(hipGetDevice(&dev));
+                HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
+                cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            static const bool allow224 = !(getenv("HIPTS_GEMM_BM") && strcmp(getenv("HIPTS_GEMM_BM"), "256") == 0);
+            const int tiles_m7 = (a.M + 223) / 224;
+            const long r8 = ((long)tiles_m * tiles_n + cus - 1) / cus * 256;
+            const long r7 = ((long)tiles_m7 * tiles_n + cus - 1) / cus * 224;
+            // measured (r01): the switch pays when the predicted saving is large (N = 768: 2.625 vs 3 rounds,
+            // -4..6 %) and costs 3 % when it is marginal (N = 3072: 9.6 vs 10) -- smaller tiles re-read W more.
+            if (allow224 && r7 * 100 < r8 * 93)
+                gemm_pp_kernel<EPI, 7><<<tiles_m7 * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
+            else
+                gemm_pp_kernel<EPI, 8><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+        }
         else
             gemm_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
     }
