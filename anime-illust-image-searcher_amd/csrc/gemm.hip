@@ -63,9 +63,10 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
     if (tanh_form) {
         // torch gelu(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
         // 0.5 (1 + tanh(u)) = sigmoid(2u) = 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 + one v_rcp_f32.
-        const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-        const float u = kBeta * (x + kKappa * x * x * x);
-        const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * u);
+        // exponent of 2: -2 log2(e) sqrt(2/pi) (x + 0.044715 x^3) = x (c1 + c2 x^2), explicit fma (the file is
+        // built with -ffp-contract=off)
+        const float c1 = -2.885390081777927f * 0.7978845608028654f, c2 = c1 * 0.044715f;
+        const float e = __builtin_amdgcn_exp2f(x * fmaf(c2, x * x, c1));
         return x * __builtin_amdgcn_rcpf(1.0f + e);
     }
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));

@@ -49,7 +49,9 @@ struct ProfRec {
 };
 
 struct hipts_vit {
-    bool prof = false;
+    bool prof = false;          // events are recorded during THIS forward call
+    int prof_every = 0;         // 0 = off, n = record every n-th forward call (sampling keeps event overhead out of the step time)
+    long prof_calls = 0;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;      // recycled events
     double acc_ms[PC_COUNT] = {0}, acc_flops[PC_COUNT] = {0}, acc_bytes[PC_COUNT] = {0};
@@ -544,6 +546,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         return set_error(HIPTS_ERR_STATE, "hipts_vit_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
                          h->missing[0].c_str());
     HIPTS_TRY(use_device(h->device));
+    h->prof = h->prof_every > 0 && (h->prof_calls++ % h->prof_every) == 0;
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
     const int M = batch * T;
@@ -681,7 +684,9 @@ int hipts_vit_profile_enable(hipts_vit_t* h, int enable) {
         h->acc_ms[i] = h->acc_flops[i] = h->acc_bytes[i] = 0.0;
         h->acc_n[i] = 0;
     }
-    h->prof = enable != 0;
+    h->prof_every = enable > 0 ? enable : 0;
+    h->prof_calls = 0;
+    h->prof = false;
     return HIPTS_OK;
 }
 

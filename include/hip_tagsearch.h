@@ -85,8 +85,9 @@ int hipts_vit_forward_u8(hipts_vit_t* h, const uint8_t* images, int images_memsp
  * tagging.py:164 stacks and :174 passes to model.forward. */
 int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int batch,
                           float* logits_out, float* probs_out, int out_memspace, void* stream);
-/* Per-kernel timing for roofline accounting (bench.py): while enabled, every kernel launch of
- * forward() is bracketed by HIP events on the stream it is launched on.  read() resolves them
+/* Per-kernel timing for roofline accounting (bench.py): while enabled (enable = n > 0), every kernel
+ * launch of every n-th forward() call is bracketed by HIP events on the stream it is launched on
+ * (n = 1: every call; sampling keeps the ~220 event records per call out of most steps).  read() resolves them
  * (synchronises) and returns, for one kernel category, the summed device time, the number of
  * launches and the ALGORITHMIC flops / bytes those launches stand for.
  * Categories are numbered 0 .. HIPTS_VIT_PROF_CATEGORIES-1; name() gives the kernel's name. */
