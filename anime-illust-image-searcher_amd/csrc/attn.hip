@@ -45,7 +45,7 @@ __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (re
 // softmax wants to rescale O, the P V product it must include has retired.
 // q is pre-scaled by head_dim^-0.5 * log2(e) in the QK GEMM epilogue: scores are in the base-2 domain.
 // MASK (last tile only): keys >= tokens start their accumulator at -inf, which the MFMA carries through.
-template <bool MASK>
+template <bool MASK, bool F16>
 __device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[4],
                                        f32x16 (&sacc)[2]) {
 #pragma unroll
@@ -58,11 +58,12 @@ __device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
-            sacc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[g], 0, 0, 0);
+            sacc[g] = mfma_32x32x16<F16>(kf, qf[s], sacc[g]);
         }
     }
 }
 
+template <bool F16>
 __device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int h, const bf16x8 (&pf)[2][2], f32x16 (&o)[2]) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -75,11 +76,12 @@ __device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int 
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + key * 2);
                 const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (key + 8) * 2);
                 const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][s2], o[blk], 0, 0, 0);
+                o[blk] = mfma_32x32x16<F16>(vf, pf[g][s2], o[blk]);
             }
     }
 }
 
+template <bool F16>
 __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2], float& m_run,
                                              float& l_run) {
     float mx = max3f(sacc[0][0], sacc[1][0], m_run);
@@ -94,7 +96,7 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
         for (int i = 0; i < 16; ++i) {
             const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
             if (i & 1) lsum1 += p; else lsum0 += p;
-            pf[g][i >> 3][i & 7] = (bf16_t)p;
+            pf[g][i >> 3][i & 7] = to_op<F16>(p);
         }
     l_run = l_run * alpha + (lsum0 + lsum1);
     m_run = m_new;
@@ -105,6 +107,7 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
                                                    int tokens, int tokens_pad, int qblocks) {
@@ -175,9 +178,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     if (nkv > 1) {
         ATTN_LOAD(KV)
     }
-    if (nkv == 1 && masked_tail) s_tile<true>(smem, 0, tokens, r, h, qf, sacc);
-    else s_tile<false>(smem, 0, tokens, r, h, qf, sacc);
-    softmax_tile(sacc, pf, o, m_run, l_run);
+    if (nkv == 1 && masked_tail) s_tile<true, F16>(smem, 0, tokens, r, h, qf, sacc);
+    else s_tile<false, F16>(smem, 0, tokens, r, h, qf, sacc);
+    softmax_tile<F16>(sacc, pf, o, m_run, l_run);
     if (nkv > 1) {
         ATTN_WRITE(smem + STAGE)
     }
@@ -188,10 +191,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
         if (t + 1 < nkv) {
             ATTN_LOAD((t + 1) * KV)
         }
-        if (t + 1 == nkv && masked_tail) s_tile<true>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
-        else s_tile<false>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
-        pv_tile(smem + prev * STAGE + K_BYTES, r, h, pf, o);
-        softmax_tile(sacc, pf, o, m_run, l_run);
+        if (t + 1 == nkv && masked_tail) s_tile<true, F16>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
+        else s_tile<false, F16>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
+        pv_tile<F16>(smem + prev * STAGE + K_BYTES, r, h, pf, o);
+        softmax_tile<F16>(sacc, pf, o, m_run, l_run);
         if (t + 1 < nkv) {
             ATTN_WRITE(smem + nxt * STAGE)
         }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
         prev = cur;
         cur = nxt;
     }
-    pv_tile(smem + prev * STAGE + K_BYTES, r, h, pf, o);
+    pv_tile<F16>(smem + prev * STAGE + K_BYTES, r, h, pf, o);
 #undef ATTN_LOAD
 #undef ATTN_WRITE
 
@@ -213,10 +216,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[blk][4 * g4 + e] * inv);
-                *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) = v;
+                *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) =
+                    pack4<F16>(o[blk][4 * g4] * inv, o[blk][4 * g4 + 1] * inv, o[blk][4 * g4 + 2] * inv, o[blk][4 * g4 + 3] * inv);
             }
     }
 }
@@ -224,11 +225,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
 }  // namespace
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
-                     int tokens_pad, hipStream_t s) {
+                     int tokens_pad, bool f16, hipStream_t s) {
     HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens, "attention: tokens_pad must be a multiple of %d", KV);
     const int qtiles = (tokens + 31) / 32;
     const int qblocks = (qtiles + 3) / 4;
-    attn_kernel<<<batch * heads * qblocks, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+    if (f16) attn_kernel<true><<<batch * heads * qblocks, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+    else attn_kernel<false><<<batch * heads * qblocks, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }

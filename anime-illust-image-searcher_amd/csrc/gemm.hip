@@ -76,7 +76,7 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
 // latencies overlap instead of forming a chain of 32 dependent round trips.
-template <int EPI, int MR = 8>
+template <int EPI, int MR = 8, bool F16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
                                               int lane) {
     const int lr = lane & 15, lq = lane >> 4;
@@ -100,9 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 if (n >= a.N) continue;
                 const f32x4 c = acc[i][j];
                 const int head = n >> 6, d = n & 63;
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(c[e] + bv[j]);
+                const bf16x4 o = pack4<F16>(c[0] + bv[j], c[1] + bv[j], c[2] + bv[j], c[3] + bv[j]);
                 *reinterpret_cast<bf16x4*>(a.out_bf16 + ((size_t)(b * a.heads + head) * 64 + d) * a.tokens_pad + t) = o;
             }
         }
@@ -180,9 +178,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 for (int j = 0; j < 4; ++j) {
                     if (!nv[j]) continue;
                     const f32x4 v = acc[i][j] + bv[j];
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)gelu_f(v[e], a.gelu_tanh);
+                    const bf16x4 o = pack4<F16>(gelu_f(v[0], a.gelu_tanh), gelu_f(v[1], a.gelu_tanh), gelu_f(v[2], a.gelu_tanh),
+                                                gelu_f(v[3], a.gelu_tanh));
                     *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = o;
                 }
             } else if constexpr (EPI == EPI_QK) {
@@ -195,9 +192,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     const int head = nn >> 6, d = nn & 63;
                     const float sc = which ? 1.0f : a.qscale;
                     const f32x4 v = acc[i][j] + bv[j];
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(v[e] * sc);
+                    const bf16x4 o = pack4<F16>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
                     bf16_t* base = which ? a.out2_bf16 : a.out_bf16;
                     *reinterpret_cast<bf16x4*>(base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + d) = o;
                 }
@@ -288,7 +283,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a, int tiles_m
 // ---------------------------------------------------------------------------------------------
 // MR = 16-row blocks per wave: 8 -> 256-row tiles, 7 -> 224-row tiles (50176 = 224 * 224: for N = 768 the
 // grid becomes 672 tiles = 3 rounds of 0.875-size tiles instead of 588 = 3 rounds (2.3 needed) of full ones).
-template <int EPI, int MR = 8>
+template <int EPI, int MR = 8, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -411,9 +406,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                 for (int j = 0; j < 4; ++j) {
                     if (mh * 4 + i >= MR) continue;
                     if constexpr (EPI == EPI_VT)
-                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[kk][j], acc[mh * 4 + i][j], 0, 0, 0);
+                        acc[mh * 4 + i][j] = mfma_16x16x32<F16>(af[i], wf[kk][j], acc[mh * 4 + i][j]);
                     else
-                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+                        acc[mh * 4 + i][j] = mfma_16x16x32<F16>(wf[kk][j], af[i], acc[mh * 4 + i][j]);
                 }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -422,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         }
     }
     if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
-    gemm_epilogue<EPI, MR>(a, acc, m0, n0, wave_m, wave_n, lane);
+    gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -687,14 +682,17 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM;
     const int variant = gemm_variant();
+    HIPTS_REQUIRE(!a.f16 || variant == 1, "half-precision operands are only built for the default (pp) GEMM loop");
     if (variant == 2) {
         const int tiles_n = (a.N + S3_BN - 1) / S3_BN;
         gemm_s3_kernel<EPI><<<tiles_m * tiles_n, 256, S3_LDS, s>>>(a, tiles_m, tiles_n);
@@ -727,10 +725,14 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             const long r7 = ((long)tiles_m7 * tiles_n + cus - 1) / cus * 224;
             // measured (r01): the switch pays when the predicted saving is large (N = 768: 2.625 vs 3 rounds,
             // -4..6 %) and costs 3 % when it is marginal (N = 3072: 9.6 vs 10) -- smaller tiles re-read W more.
-            if (allow224 && r7 * 100 < r8 * 93)
-                gemm_pp_kernel<EPI, 7><<<tiles_m7 * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
-            else
-                gemm_pp_kernel<EPI, 8><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+            const bool use7 = allow224 && r7 * 100 < r8 * 93;
+            if (a.f16) {
+                if (use7) gemm_pp_kernel<EPI, 7, true><<<tiles_m7 * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
+                else gemm_pp_kernel<EPI, 8, true><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+            } else {
+                if (use7) gemm_pp_kernel<EPI, 7, false><<<tiles_m7 * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
+                else gemm_pp_kernel<EPI, 8, false><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+            }
         }
         else
             gemm_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);

@@ -31,6 +31,43 @@ inline uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// float -> IEEE half bits, round to nearest even (subnormals kept)
+inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                     // rounds to >= 65520 -> inf
+    if (x < 0x38800000u) {                                                       // below the smallest normal half
+        if (x < 0x33000000u) return (uint16_t)sign;                              // < 2^-25 -> 0
+        const int shift = 126 - (int)(x >> 23);                                  // 14..24: value = mant24 * 2^-24 >> shift
+        uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t round = (1u << (shift - 1)) - 1 + ((mant >> shift) & 1u);
+        mant += round;
+        return (uint16_t)(sign | (mant >> shift));
+    }
+    const uint32_t round = 0xfffu + ((x >> 13) & 1u);
+    x += round;
+    return (uint16_t)(sign | ((x - 0x38000000u) >> 13));
+}
+inline float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, out;
+    if (e == 0) {
+        if (m == 0) out = sign;
+        else {
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            out = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) out = sign | 0x7f800000u | (m << 13);
+    else out = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &out, 4);
+    return f;
+}
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
@@ -75,6 +112,7 @@ namespace {
 // BGR flip of tagging.py:243 is folded into the weight permutation at upload time.
 // One thread per (token, ky): reads P*3 contiguous bytes, writes P*3 contiguous bf16.
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, bf16_t* __restrict__ a0, int batch,
                                                           int size, int P, int grid) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -99,20 +137,21 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
             bf16x8 lo, hi;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                lo[e] = (bf16_t)(float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
-                hi[e] = (bf16_t)(float)((w[2 + (e >> 2)] >> (8 * (e & 3))) & 0xffu);
+                lo[e] = to_op<F16>((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu));
+                hi[e] = to_op<F16>((float)((w[2 + (e >> 2)] >> (8 * (e & 3))) & 0xffu));
             }
             d4[2 * v] = *reinterpret_cast<const uint4*>(&lo);
             d4[2 * v + 1] = *reinterpret_cast<const uint4*>(&hi);
         }
         return;
     }
-    for (int i = 0; i < P * 3; ++i) dst[i] = (bf16_t)(float)src[i];
+    for (int i = 0; i < P * 3; ++i) dst[i] = to_op<F16>((float)src[i]);
 }
 
 // x: float32 [B][3][S][S] (BGR, already normalised).  Channel c of the patch matrix (memory/RGB
 // order) is model channel 2 - c.  Each value is split into bf16 hi + bf16 lo (row = [hi(K) | lo(K)],
 // multiplied against [W | W]) so the float32 input keeps ~16 significant bits.
+template <bool F16>
 __global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ a0, int batch,
                                                            int size, int P, int grid) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -127,9 +166,9 @@ __global__ __launch_bounds__(256) void patchify_f32_kernel(const float* __restri
         const float* src = x + (((int64_t)b * 3 + (2 - c)) * size + (py * P + ky)) * size + px * P;
         for (int kx = 0; kx < P; ++kx) {
             const float v = src[kx];
-            const bf16_t hi = (bf16_t)v;
+            const bf16_t hi = to_op<F16>(v);
             dst[kx * 3 + c] = hi;
-            dst[K + kx * 3 + c] = (bf16_t)(v - (float)hi);
+            dst[K + kx * 3 + c] = to_op<F16>(v - from_op<F16>(hi));
         }
     }
 }
@@ -144,6 +183,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ bta, bf16_t* __restrict__ out, int64_t rows,
                                                         int D, float eps) {
@@ -177,12 +217,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < nvec) {
             const float4 gg = gr[c], bb = br[c];
-            bf16x4 o;
-            o[0] = (bf16_t)((v[i].x - mean) * rstd * gg.x + bb.x);
-            o[1] = (bf16_t)((v[i].y - mean) * rstd * gg.y + bb.y);
-            o[2] = (bf16_t)((v[i].z - mean) * rstd * gg.z + bb.z);
-            o[3] = (bf16_t)((v[i].w - mean) * rstd * gg.w + bb.w);
-            *reinterpret_cast<bf16x4*>(out + row * D + 4 * c) = o;
+            *reinterpret_cast<bf16x4*>(out + row * D + 4 * c) =
+                pack4<F16>((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                           (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
         }
     }
 }
@@ -251,6 +288,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
 // Sum the partials, apply the affine (or the LayerNorm for pool-then-norm), and split the float32
 // feature into bf16 hi + bf16 lo so the head GEMM (K = 2D against [W | W]) keeps ~16 bits of the
 // feature: out[b][0..D) = hi, out[b][D..2D) = lo.   One workgroup per image.
+template <bool F16>
 __global__ __launch_bounds__(256) void pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ g,
                                                             const float* __restrict__ bta, bf16_t* __restrict__ out, int tokens,
                                                             int D, float eps, int normalize_after, int splits) {
@@ -283,8 +321,8 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const float* __restr
     }
     for (int d = threadIdx.x; d < D; d += 256) {
         const float f = (feat[d] - mean) * rstd * g[d] + bta[d];
-        const bf16_t hi = (bf16_t)f;
-        const bf16_t lo = (bf16_t)(f - (float)hi);
+        const bf16_t hi = to_op<F16>(f);
+        const bf16_t lo = to_op<F16>(f - from_op<F16>(hi));
         out[(int64_t)b * 2 * D + d] = hi;
         out[(int64_t)b * 2 * D + D + d] = lo;
     }
@@ -295,10 +333,12 @@ int set_f32(DevBuf& buf, const float* data, size_t n) {
     return upload(buf.p, data, n * 4);
 }
 
-// rows x cols float32 -> bf16, rows zero-padded to rows_pad
+// rows x cols float32 -> bf16 (or half), rows zero-padded to rows_pad
+bool g_upload_f16 = false;      // set from the handle around hipts_vit_set_tensor (single caller per handle)
 int set_bf16_matrix(DevBuf& buf, const float* data, int rows, int cols, int rows_pad) {
     std::vector<uint16_t> h((size_t)rows_pad * cols, 0);
-    for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_bf16_rne(data[i]);
+    if (g_upload_f16) for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_f16_rne(data[i]);
+    else for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_bf16_rne(data[i]);
     HIPTS_TRY(buf.alloc(h.size() * 2));
     return upload(buf.p, h.data(), h.size() * 2);
 }
@@ -378,6 +418,7 @@ int hipts_vit_destroy(hipts_vit_t* h) {
 int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, int64_t numel) {
     HIPTS_REQUIRE(h && key_c && data, "hipts_vit_set_tensor: null argument");
     HIPTS_TRY(use_device(h->device));
+    g_upload_f16 = h->cfg.operand_f16 != 0;
     const std::string key(key_c);
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, Mlp = c.mlp_dim, C = c.num_classes;
@@ -401,9 +442,13 @@ int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, i
             for (int n = 0; n < D; ++n) {
                 double rs = 0.0;
                 for (int kk = 0; kk < h->patch_k; ++kk) {
-                    const uint32_t bits = (uint32_t)f32_to_bf16_rne(perm[(size_t)n * h->patch_k + kk]) << 16;
                     float wv;
-                    memcpy(&wv, &bits, 4);
+                    if (g_upload_f16) {
+                        wv = f16_bits_to_f32(f32_to_f16_rne(perm[(size_t)n * h->patch_k + kk]));
+                    } else {
+                        const uint32_t bits = (uint32_t)f32_to_bf16_rne(perm[(size_t)n * h->patch_k + kk]) << 16;
+                        memcpy(&wv, &bits, 4);
+                    }
                     rs += (double)wv;
                 }
                 h->h_patch_rowsum[n] = (float)rs;
@@ -550,6 +595,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
     const int M = batch * T;
+    const bool f16 = c.operand_f16 != 0;
 
     const void* in_dev = input;
     if (in_memspace != HIPTS_DEVICE) {
@@ -563,15 +609,19 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         ProfScope ps(h, s, PC_PATCHIFY, 0.0, dM * h->patch_k * (is_u8 ? 3.0 : 6.0));
         const int64_t total = (int64_t)M * P;
         const int blocks = ceil_div(total, 256);
-        if (is_u8)
-            patchify_u8_kernel<<<blocks, 256, 0, s>>>((const uint8_t*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
-        else
-            patchify_f32_kernel<<<blocks, 256, 0, s>>>((const float*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+        if (is_u8) {
+            if (f16) patchify_u8_kernel<true><<<blocks, 256, 0, s>>>((const uint8_t*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+            else patchify_u8_kernel<false><<<blocks, 256, 0, s>>>((const uint8_t*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+        } else {
+            if (f16) patchify_f32_kernel<true><<<blocks, 256, 0, s>>>((const float*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+            else patchify_f32_kernel<false><<<blocks, 256, 0, s>>>((const float*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+        }
         HIPTS_LAUNCH_CHECK();
     }
     GemmArgs g;
     // patch embedding: x = A0 W^T + b + pos
     g = GemmArgs{};
+    g.f16 = f16;
     g.A = h->a0.as<bf16_t>(); g.M = M; g.N = D; g.out_f32 = h->x.as<float>(); g.pos = h->pos.as<float>(); g.tokens = T;
     if (is_u8) {   // exact integer pixels; affine normalisation folded into the epilogue
         g.W = h->patch_w.as<bf16_t>(); g.K = h->patch_k; g.bias = h->patch_b_u8.as<float>(); g.qscale = 2.0f / 255.0f;
@@ -588,11 +638,13 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         Layer& L = h->layers[li];
         {
             ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
-            layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
             HIPTS_LAUNCH_CHECK();
         }
         // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
         g = GemmArgs{};
+        g.f16 = f16;
         g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
         g.bias = L.qkv_b.as<float>(); g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
@@ -603,6 +655,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         }
         // v, written transposed
         g = GemmArgs{};
+        g.f16 = f16;
         g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
         g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = h->vT.as<bf16_t>();
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
@@ -612,10 +665,11 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         }
         {
             ProfScope ps(h, s, PC_ATTENTION, 4.0 * batch * H * dT * dT * 64, dM * dD * 2 * 4);
-            HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, s));
+            HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, f16, s));
         }
         // x += att Wp^T + b
         g = GemmArgs{};
+        g.f16 = f16;
         g.A = h->att.as<bf16_t>(); g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
         g.bias = L.proj_b.as<float>(); g.out_f32 = h->x.as<float>();
         {
@@ -624,10 +678,12 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         }
         {
             ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
-            layernorm_kernel<<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
             HIPTS_LAUNCH_CHECK();
         }
         g = GemmArgs{};
+        g.f16 = f16;
         g.A = h->xn.as<bf16_t>(); g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
         g.bias = L.fc1_b.as<float>(); g.out_bf16 = h->hmid.as<bf16_t>(); g.gelu_tanh = c.gelu_tanh;
         {
@@ -635,6 +691,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
             HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
         }
         g = GemmArgs{};
+        g.f16 = f16;
         g.A = h->hmid.as<bf16_t>(); g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
         g.bias = L.fc2_b.as<float>(); g.out_f32 = h->x.as<float>();
         {
@@ -648,8 +705,12 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     pool_partial_kernel<<<dim3(h->pool_splits, batch), 256, 0, s>>>(h->x.as<float>(), h->pool_part.as<float>(), T, D, c.ln_eps,
                                                                    c.pool_then_norm ? 0 : 1, h->pool_splits);
     HIPTS_LAUNCH_CHECK();
-    pool_finalize_kernel<<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
-                                               h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
+    if (f16)
+        pool_finalize_kernel<true><<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
+                                                         h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
+    else
+        pool_finalize_kernel<false><<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
+                                                          h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
     HIPTS_LAUNCH_CHECK();
     }
     // head (+ sigmoid, tagging.py:176)
@@ -657,6 +718,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
     float* pr = (dev_out && probs_out) ? probs_out : h->probs.as<float>();
     g = GemmArgs{};
+    g.f16 = f16;
     g.A = h->pooled2.as<bf16_t>(); g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
     g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = (probs_out || !dev_out) ? pr : nullptr;
     {

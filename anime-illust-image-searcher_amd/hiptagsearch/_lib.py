@@ -25,7 +25,7 @@ class HipTagSearchError(RuntimeError):
 class VitConfig(ctypes.Structure):
     _fields_ = [("image_size", c_int32), ("patch", c_int32), ("dim", c_int32), ("depth", c_int32),
                 ("heads", c_int32), ("mlp_dim", c_int32), ("num_classes", c_int32), ("ln_eps", c_float),
-                ("gelu_tanh", c_int32), ("pool_then_norm", c_int32), ("max_batch", c_int32)]
+                ("gelu_tanh", c_int32), ("pool_then_norm", c_int32), ("max_batch", c_int32), ("operand_f16", c_int32)]
 
 
 # name -> (argtypes); every function returns int status unless listed in _PLAIN

@@ -35,7 +35,7 @@ class ViTTagger:
         self.num_classes = cfg["num_classes"]
         c = VitConfig(cfg["image_size"], cfg["patch"], cfg["dim"], cfg["depth"], cfg["heads"], cfg["mlp_dim"],
                       cfg["num_classes"], cfg.get("ln_eps", 1e-6), cfg.get("gelu_tanh", 1), cfg.get("pool_then_norm", 0),
-                      max_batch)
+                      max_batch, cfg.get("operand_f16", 0))
         self._h = c_void_p()
         _lib.call("hipts_vit_create", ctypes.byref(c), device, ctypes.byref(self._h))
         for key, val in weights.items():

@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
+    ap.add_argument("--operands", choices=["bf16", "f16"], default="bf16",
+                    help="16-bit MFMA operand type (bf16 = BASELINE.json configs[1]; f16 = same rate, 8x smaller rounding)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,6 +181,7 @@ def main():
     import ctypes
 
     cfg = dict(synth.VIT_B16_448)
+    cfg["operand_f16"] = 1 if args.operands == "f16" else 0
     weights = synth.vit_weights(cfg, seed=0)
     model = ViTTagger(cfg, weights, max_batch=BATCH, device=local_rank)
     names, cat = synth.label_table(cfg["num_classes"])
@@ -251,7 +254,7 @@ def main():
     result = {
         "metric": "images/sec tagged (ViT fwd)", "value": imgs_per_s, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.operands, "data": "synthetic",
         "config": {"workload": "wd-tagger ViT-B/16 448px bf16 forward + sigmoid + MCut tag selection, batch 64 per GPU, "
                                "u8 NHWC images resident in HBM (BASELINE.json configs[1])",
                    "batch_per_gpu": BATCH, "image": "448x448x3 u8", "classes": cfg["num_classes"],

@@ -67,6 +67,9 @@ typedef struct hipts_vit_config {
     int32_t gelu_tanh;       /* 1: tanh approximation, 0: erf         */
     int32_t pool_then_norm;  /* 0: LN(tokens) then mean (fc_norm=False); 1: mean then LN */
     int32_t max_batch;       /* workspace is sized for this many images per forward call */
+    int32_t operand_f16;     /* 0: bf16 MFMA operands (default, BASELINE.json configs[1]); 1: IEEE half operands --
+                                same MFMA rate, 8x smaller activation rounding: keeps |dlogit| <= 1e-3 also on flat
+                                images, where bf16 rounding is identical on every token and does not average out */
 } hipts_vit_config_t;
 
 int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** out);

@@ -60,6 +60,28 @@ def test_vit_b16_448_matches_oracle():
     assert abs(model.flops_per_image() - 156.78e9) / 156.78e9 < 1e-3
 
 
+def test_vit_half_operands_flat_image():
+    """operand_f16 = 1: same kernels with IEEE-half MFMA operands.  On a flat image every token
+    carries the same bf16 rounding error (it does not average out in the mean pool: ~4e-3 with bf16
+    operands); half operands keep the logits within the 1e-3 tolerance there too."""
+    from hiptagsearch import synth
+    from hiptagsearch.tagger import ViTTagger
+    cfg = dict(synth.VIT_B16_448)
+    cfg["operand_f16"] = 1
+    w = synth.vit_weights(cfg, seed=0)
+    imgs = synth.images_u8(3, 448, seed=77)
+    imgs[1, :, :, :] = imgs[1, :1, :1, :]          # constant colour
+    imgs[2] = (imgs[2] // 64) * 64                  # posterised
+    want, x = _oracle_logits(cfg, w, imgs)
+    model = ViTTagger(cfg, w, max_batch=4)
+    logits, _ = model.forward_u8(imgs)
+    err = np.abs(logits - want).max(axis=1)
+    print("half operands: max |logit error| per image (random, flat, posterised) =", err)
+    assert err.max() <= LOGIT_TOL
+    logits2, _ = model.forward(x)
+    assert np.abs(logits2 - want).max() <= LOGIT_TOL
+
+
 def test_vit_requires_all_tensors():
     import hiptagsearch
     from hiptagsearch import synth
