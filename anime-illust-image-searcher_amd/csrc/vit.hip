@@ -9,6 +9,7 @@
 // The residual stream, LN statistics, softmax and every accumulation are float32; only MFMA
 // operands are bf16.
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -103,6 +104,8 @@ struct hipts_vit {
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs;
     int pool_splits = 1;
+    hipStream_t sub[2] = {nullptr, nullptr};      // internal streams of the two half-batches
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -583,38 +586,41 @@ int prof_resolve(hipts_vit* h) {
     return HIPTS_OK;
 }
 
-int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u8, int batch, float* logits_out,
-                     float* probs_out, int out_memspace, hipStream_t s) {
-    HIPTS_REQUIRE(h && input && batch >= 1, "hipts_vit_forward: bad arguments");
-    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
-    if (!h->missing.empty())
-        return set_error(HIPTS_ERR_STATE, "hipts_vit_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
-                         h->missing[0].c_str());
-    HIPTS_TRY(use_device(h->device));
-    h->prof = h->prof_every > 0 && (h->prof_calls++ % h->prof_every) == 0;
+// The whole kernel sequence for images [i0, i0 + nb) of the current call, on stream s.  Every workspace
+// buffer is indexed by image (rows of M = batch * tokens, or (image, head) blocks), so disjoint image
+// ranges can run on different streams at the same time.
+int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb, float* lg, float* pr, hipStream_t s) {
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
-    const int M = batch * T;
+    const int M = nb * T;
     const bool f16 = c.operand_f16 != 0;
+    const size_t r0 = (size_t)i0 * T;                                   // first token row
+    const int a0_ld = is_u8 ? h->patch_k : 2 * h->patch_k;
+    bf16_t* a0 = h->a0.as<bf16_t>() + r0 * a0_ld;
+    float* x = h->x.as<float>() + r0 * D;
+    bf16_t* xn = h->xn.as<bf16_t>() + r0 * D;
+    bf16_t* att = h->att.as<bf16_t>() + r0 * D;
+    bf16_t* hmid = h->hmid.as<bf16_t>() + r0 * c.mlp_dim;
+    const size_t qoff = (size_t)i0 * H * Tp * 64;
+    bf16_t* q = h->q.as<bf16_t>() + qoff;
+    bf16_t* k = h->k.as<bf16_t>() + qoff;
+    bf16_t* vT = h->vT.as<bf16_t>() + qoff;
+    float* pool_part = h->pool_part.as<float>() + (size_t)i0 * h->pool_splits * D;
+    bf16_t* pooled2 = h->pooled2.as<bf16_t>() + (size_t)i0 * 2 * D;
+    const size_t img_bytes = (size_t)S * S * 3 * (is_u8 ? 1 : 4);
+    const char* in_p = (const char*)in_dev + (size_t)i0 * img_bytes;
 
-    const void* in_dev = input;
-    if (in_memspace != HIPTS_DEVICE) {
-        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
-        HIPTS_TRY(h->img_in.reserve(bytes));
-        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
-        in_dev = h->img_in.p;
-    }
     const double dM = (double)M, dD = (double)D, dMlp = (double)c.mlp_dim, dT = (double)T;
     {
         ProfScope ps(h, s, PC_PATCHIFY, 0.0, dM * h->patch_k * (is_u8 ? 3.0 : 6.0));
         const int64_t total = (int64_t)M * P;
         const int blocks = ceil_div(total, 256);
         if (is_u8) {
-            if (f16) patchify_u8_kernel<true><<<blocks, 256, 0, s>>>((const uint8_t*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
-            else patchify_u8_kernel<false><<<blocks, 256, 0, s>>>((const uint8_t*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+            if (f16) patchify_u8_kernel<true><<<blocks, 256, 0, s>>>((const uint8_t*)in_p, a0, nb, S, P, h->grid);
+            else patchify_u8_kernel<false><<<blocks, 256, 0, s>>>((const uint8_t*)in_p, a0, nb, S, P, h->grid);
         } else {
-            if (f16) patchify_f32_kernel<true><<<blocks, 256, 0, s>>>((const float*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
-            else patchify_f32_kernel<false><<<blocks, 256, 0, s>>>((const float*)in_dev, h->a0.as<bf16_t>(), batch, S, P, h->grid);
+            if (f16) patchify_f32_kernel<true><<<blocks, 256, 0, s>>>((const float*)in_p, a0, nb, S, P, h->grid);
+            else patchify_f32_kernel<false><<<blocks, 256, 0, s>>>((const float*)in_p, a0, nb, S, P, h->grid);
         }
         HIPTS_LAUNCH_CHECK();
     }
@@ -622,7 +628,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     // patch embedding: x = A0 W^T + b + pos
     g = GemmArgs{};
     g.f16 = f16;
-    g.A = h->a0.as<bf16_t>(); g.M = M; g.N = D; g.out_f32 = h->x.as<float>(); g.pos = h->pos.as<float>(); g.tokens = T;
+    g.A = a0; g.M = M; g.N = D; g.out_f32 = x; g.pos = h->pos.as<float>(); g.tokens = T;
     if (is_u8) {   // exact integer pixels; affine normalisation folded into the epilogue
         g.W = h->patch_w.as<bf16_t>(); g.K = h->patch_k; g.bias = h->patch_b_u8.as<float>(); g.qscale = 2.0f / 255.0f;
     } else {       // hi | lo split of the float input against [W | W]
@@ -638,15 +644,15 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         Layer& L = h->layers[li];
         {
             ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
-            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
-            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln1_g.as<float>(), L.ln1_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps);
+            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps);
             HIPTS_LAUNCH_CHECK();
         }
         // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
         g = GemmArgs{};
         g.f16 = f16;
-        g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
-        g.bias = L.qkv_b.as<float>(); g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
+        g.bias = L.qkv_b.as<float>(); g.out_bf16 = q; g.out2_bf16 = k;
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         g.qscale = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 (64^-0.5) * log2(e): attention works in base 2
         {
@@ -656,44 +662,44 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         // v, written transposed
         g = GemmArgs{};
         g.f16 = f16;
-        g.A = h->xn.as<bf16_t>(); g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
-        g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = h->vT.as<bf16_t>();
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
+        g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = vT;
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         {
             ProfScope ps(h, s, PC_GEMM_VT, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 2);
             HIPTS_TRY(launch_gemm(EPI_VT, g, s));
         }
         {
-            ProfScope ps(h, s, PC_ATTENTION, 4.0 * batch * H * dT * dT * 64, dM * dD * 2 * 4);
-            HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, f16, s));
+            ProfScope ps(h, s, PC_ATTENTION, 4.0 * nb * H * dT * dT * 64, dM * dD * 2 * 4);
+            HIPTS_TRY(launch_attention(q, k, vT, att, nb, H, T, Tp, f16, s));
         }
         // x += att Wp^T + b
         g = GemmArgs{};
         g.f16 = f16;
-        g.A = h->att.as<bf16_t>(); g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
-        g.bias = L.proj_b.as<float>(); g.out_f32 = h->x.as<float>();
+        g.A = att; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
+        g.bias = L.proj_b.as<float>(); g.out_f32 = x;
         {
             ProfScope ps(h, s, PC_GEMM_RESID, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 8);
             HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
         }
         {
             ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
-            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
-            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(h->x.as<float>(), L.ln2_g.as<float>(), L.ln2_b.as<float>(), h->xn.as<bf16_t>(), M, D, c.ln_eps);
+            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps);
+            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps);
             HIPTS_LAUNCH_CHECK();
         }
         g = GemmArgs{};
         g.f16 = f16;
-        g.A = h->xn.as<bf16_t>(); g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
-        g.bias = L.fc1_b.as<float>(); g.out_bf16 = h->hmid.as<bf16_t>(); g.gelu_tanh = c.gelu_tanh;
+        g.A = xn; g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
+        g.bias = L.fc1_b.as<float>(); g.out_bf16 = hmid; g.gelu_tanh = c.gelu_tanh;
         {
             ProfScope ps(h, s, PC_GEMM_GELU, 2.0 * dM * dD * dMlp, dM * dD * 2 + dM * dMlp * 2);
             HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
         }
         g = GemmArgs{};
         g.f16 = f16;
-        g.A = h->hmid.as<bf16_t>(); g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
-        g.bias = L.fc2_b.as<float>(); g.out_f32 = h->x.as<float>();
+        g.A = hmid; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
+        g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
         {
             ProfScope ps(h, s, PC_GEMM_RESID, 2.0 * dM * dD * dMlp, dM * dMlp * 2 + dM * dD * 8);
             HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
@@ -701,29 +707,74 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     }
     // final norm + mean pool (+ hi/lo split)
     {
-    ProfScope ps(h, s, PC_POOL, 0.0, dM * dD * 4);
-    pool_partial_kernel<<<dim3(h->pool_splits, batch), 256, 0, s>>>(h->x.as<float>(), h->pool_part.as<float>(), T, D, c.ln_eps,
-                                                                   c.pool_then_norm ? 0 : 1, h->pool_splits);
-    HIPTS_LAUNCH_CHECK();
-    if (f16)
-        pool_finalize_kernel<true><<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
-                                                         h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
-    else
-        pool_finalize_kernel<false><<<batch, 256, 0, s>>>(h->pool_part.as<float>(), h->norm_g.as<float>(), h->norm_b.as<float>(),
-                                                          h->pooled2.as<bf16_t>(), T, D, c.ln_eps, c.pool_then_norm ? 1 : 0, h->pool_splits);
-    HIPTS_LAUNCH_CHECK();
+        ProfScope ps(h, s, PC_POOL, 0.0, dM * dD * 4);
+        pool_partial_kernel<<<dim3(h->pool_splits, nb), 256, 0, s>>>(x, pool_part, T, D, c.ln_eps, c.pool_then_norm ? 0 : 1, h->pool_splits);
+        HIPTS_LAUNCH_CHECK();
+        if (f16)
+            pool_finalize_kernel<true><<<nb, 256, 0, s>>>(pool_part, h->norm_g.as<float>(), h->norm_b.as<float>(), pooled2, T, D, c.ln_eps,
+                                                          c.pool_then_norm ? 1 : 0, h->pool_splits);
+        else
+            pool_finalize_kernel<false><<<nb, 256, 0, s>>>(pool_part, h->norm_g.as<float>(), h->norm_b.as<float>(), pooled2, T, D, c.ln_eps,
+                                                           c.pool_then_norm ? 1 : 0, h->pool_splits);
+        HIPTS_LAUNCH_CHECK();
     }
     // head (+ sigmoid, tagging.py:176)
-    const bool dev_out = out_memspace == HIPTS_DEVICE;
-    float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
-    float* pr = (dev_out && probs_out) ? probs_out : h->probs.as<float>();
     g = GemmArgs{};
     g.f16 = f16;
-    g.A = h->pooled2.as<bf16_t>(); g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
-    g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = (probs_out || !dev_out) ? pr : nullptr;
+    g.A = pooled2; g.W = h->head_w.as<bf16_t>(); g.M = nb; g.N = c.num_classes; g.K = 2 * D;
+    g.bias = h->head_b.as<float>(); g.out_f32 = lg ? lg + (size_t)i0 * c.num_classes : nullptr;
+    g.out2_f32 = pr ? pr + (size_t)i0 * c.num_classes : nullptr;
     {
-        ProfScope ps(h, s, PC_GEMM_HEAD, 2.0 * batch * dD * c.num_classes, (double)c.num_classes * 2 * dD * 2);
+        ProfScope ps(h, s, PC_GEMM_HEAD, 2.0 * nb * dD * c.num_classes, (double)c.num_classes * 2 * dD * 2);
         HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
+    }
+    return HIPTS_OK;
+}
+
+int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u8, int batch, float* logits_out,
+                     float* probs_out, int out_memspace, hipStream_t s) {
+    HIPTS_REQUIRE(h && input && batch >= 1, "hipts_vit_forward: bad arguments");
+    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
+    if (!h->missing.empty())
+        return set_error(HIPTS_ERR_STATE, "hipts_vit_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
+                         h->missing[0].c_str());
+    HIPTS_TRY(use_device(h->device));
+    h->prof = h->prof_every > 0 && (h->prof_calls++ % h->prof_every) == 0;
+    const auto& c = h->cfg;
+    const int S = c.image_size;
+
+    const void* in_dev = input;
+    if (in_memspace != HIPTS_DEVICE) {
+        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
+        HIPTS_TRY(h->img_in.reserve(bytes));
+        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
+        in_dev = h->img_in.p;
+    }
+    const bool dev_out = out_memspace == HIPTS_DEVICE;
+    float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
+    float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
+
+    // Two half-batches on two internal streams: a GEMM grid's partial last round, an epilogue that is
+    // waiting on HBM and every kernel boundary of one half are filled with work of the other half.
+    static const int want_streams = getenv("HIPTS_VIT_STREAMS") ? atoi(getenv("HIPTS_VIT_STREAMS")) : 2;
+    if (want_streams >= 2 && batch >= 16) {
+        if (!h->sub[0]) {
+            HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[0], hipStreamNonBlocking));
+            HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[1], hipStreamNonBlocking));
+            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));
+            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[1], hipEventDisableTiming));
+        }
+        const int nb0 = (batch + 1) / 2;
+        HIPTS_HIP(hipEventRecord(h->ev_fork, s));
+        for (int i = 0; i < 2; ++i) {
+            HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, lg, pr, h->sub[i]));
+            HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
+            HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        }
+    } else {
+        HIPTS_TRY(vit_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s));
     }
     if (!dev_out) {
         const size_t bytes = (size_t)batch * c.num_classes * 4;

@@ -62,6 +62,10 @@ class SearchEngine:
         self.image_files_name_tags_arr = list(image_files_name_tags_arr)
         self.search_mode = search_mode
         self.compat_rerank = compat_rerank
+        self.cindex = None                     # cfeatures.CharacterFeatureIndex for 'character oriented' mode
+        # webui.py:623-646: path -> {tag: True} and path -> doc id, built from the same index file
+        self.file_tag_index_dict = {l.split(",")[0]: {t: True for t in l.split(",")[1:]} for l in self.image_files_name_tags_arr}
+        self.filepath_docid_dict = {l.split(",")[0]: i for i, l in enumerate(self.image_files_name_tags_arr)}
 
     # ---- webui.py:82-117 ------------------------------------------------------------------------
     def normalize_and_apply_weight_doc2vec(self, new_doc: str) -> np.ndarray:
@@ -137,9 +141,31 @@ class SearchEngine:
         final_dev = torch.empty((1, D), dtype=torch.float64, device="cuda:%d" % self.index.device)
         k = min(TOPK_MAX, D)
         ids, vals = self.score_topk([qw], vec[None, :], k, final_out=final_dev)       # :352,374-383
-        if self.search_mode == "character oriented":
-            raise NotImplementedError("character-oriented rerank needs the CCIP encoder (DESIGN.md: out of scope this round)")
+        if self.search_mode == "character oriented":                                  # :386-388
+            return self._cfeatures_rerank(ids[0], vals[0], topn, required, exclude)
         return self._doc2vec_rerank(final_dev, ids[0], vals[0], topn)                 # :390
+
+    # ---- webui.py:255-342 -----------------------------------------------------------------------
+    def _cfeatures_rerank(self, ids: np.ndarray, vals: np.ndarray, topn: int, required: List[str], exclude: List[str]):
+        from .cfeatures import cfeatures_rerank, gen_image_ndarray
+        if self.cindex is None:
+            raise RuntimeError("character oriented mode needs engine.cindex (a cfeatures.CharacterFeatureIndex with an encoder)")
+        D = len(self.index)
+        if D <= 10:                                                                   # :336-342
+            sims = filter_searched_result([(int(i), float(v)) for i, v in zip(ids[:D], vals[:D])])
+            return sims[:min(topn, len(sims))]
+        top10 = [(int(i), float(v)) for i, v in zip(ids[:10], vals[:10])]
+        feats = []
+        for doc_id, _ in top10:                                                       # :292-301
+            path = self.image_files_name_tags_arr[doc_id].split(",")[0]
+            arr = gen_image_ndarray(path)
+            if arr is None:
+                continue
+            feats.append(self.cindex.ccip_batch_extract_features([arr])[0])
+        if not feats:
+            return top10
+        return cfeatures_rerank(top10, feats, self.cindex, self.file_tag_index_dict, self.filepath_docid_dict, required, exclude,
+                                self.cindex.threshold / 1.5)                          # gen_cfeatures.py:298-299
 
     # ---- webui.py:189-253 -----------------------------------------------------------------------
     def _doc_tags(self, doc_id: int) -> List[str]:
