@@ -72,6 +72,21 @@ __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
 }
 
+// Four values at once: the tanh form in packed fp32 (v_pk_mul/fma/add_f32 process two floats per lane and
+// issue slot -- the GELU epilogue is VALU-bound: 128 values per lane, two waves per SIMD), same operation
+// order and roundings as gelu_f.
+__device__ __forceinline__ f32x4 gelu_f4(f32x4 x, int tanh_form) {
+    if (tanh_form) {
+        const float c1 = -2.885390081777927f * 0.7978845608028654f, c2 = c1 * 0.044715f;
+        const f32x4 t = x * x;
+        const f32x4 g = x * __builtin_elementwise_fma(f32x4{c2, c2, c2, c2}, t, f32x4{c1, c1, c1, c1});
+        f32x4 e{__builtin_amdgcn_exp2f(g[0]), __builtin_amdgcn_exp2f(g[1]), __builtin_amdgcn_exp2f(g[2]), __builtin_amdgcn_exp2f(g[3])};
+        e = e + f32x4{1.f, 1.f, 1.f, 1.f};
+        return x * f32x4{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), __builtin_amdgcn_rcpf(e[2]), __builtin_amdgcn_rcpf(e[3])};
+    }
+    return f32x4{gelu_f(x[0], 0), gelu_f(x[1], 0), gelu_f(x[2], 0), gelu_f(x[3], 0)};
+}
+
 // Epilogue shared by both main-loop variants.  acc[i][j]: 16 x 16 tile (i: 16-row block of the
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
@@ -134,13 +149,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             bv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.bias + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if constexpr (EPI == EPI_RESID) {
-            // read-modify-write of the fp32 residual stream: 8 x 16 B loads per lane in flight
-            // (two 16-row blocks) before the first dependent add, so a CU keeps ~64 KB outstanding.
+            // read-modify-write of the fp32 residual stream: RB x 4 loads of 16 B per lane in flight before the
+            // first dependent add (RB 16-row blocks; the fragment registers of the main loop are free here),
+            // so a CU keeps RB x 32 KB outstanding -- the epilogue is bound by HBM latency x bytes in flight.
+            constexpr int RB = 4;
 #pragma unroll
-            for (int i2 = 0; i2 < MR; i2 += 2) {
-                f32x4 xv[2][4];
+            for (int i2 = 0; i2 < MR; i2 += RB) {
+                f32x4 xv[RB][4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < RB; ++u) {
                     if (i2 + u >= MR) continue;
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     const float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
@@ -148,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < RB; ++u) {
                     if (i2 + u >= MR) continue;
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     if (m >= a.M) continue;
@@ -197,6 +214,118 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     *reinterpret_cast<bf16x4*>(base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + d) = o;
                 }
             }
+        }
+    }
+}
+
+// Half-precision epilogues through LDS.  After the main loop one stage of LDS is free, so every wave
+// packs its 16 MR x 64 output block, 64 rows at a time, into a private 8 KB LDS image and reads it back
+// row-contiguous: each global store instruction then writes whole 128 B lines (8 rows x 128 B) instead of
+// 16 scattered 32 B pieces.  Both LDS passes are bank-conflict free: the 16 B chunk of an image row is
+// XOR-swizzled with (row >> 1) & 7 and rows alternate between the two 128 B halves of the 64 banks.
+// Wave-private image: no workgroup barrier, LDS operations of one wave execute in order.
+template <int EPI, int MR, bool F16>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
+                                                     int lane, char* region) {
+    static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK, "staged epilogue: half-precision outputs only");
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ncol0 = n0 + wave_n * 64;
+    const int mrow0 = m0 + wave_m * (MR * 16);
+    const int lc = lane & 7, lrow = lane >> 3;
+    if constexpr (EPI == EPI_VT) {
+        // acc[i][j][e] = (token mrow0 + 16 i + 4 lq + e, column ncol0 + 16 j + lr); image [64 columns][128 B = 64 tokens]
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol0 + j * 16 + lr;
+            bv[j] = n < a.N ? a.bias[n] : 0.f;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = pass * 4 + ii;
+                if (i >= MR) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 c = acc[i][j];
+                    const int d = j * 16 + lr;
+                    const int pc = (ii * 2 + (lq >> 1)) ^ ((d >> 1) & 7);
+                    *reinterpret_cast<bf16x4*>(region + d * 128 + pc * 16 + (lq & 1) * 8) =
+                        pack4<F16>(c[0] + bv[j], c[1] + bv[j], c[2] + bv[j], c[3] + bv[j]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int m = mrow0 + pass * 64 + lc * 8;
+            const int b = m / a.tokens, t = m - b * a.tokens;
+            const bool mv = pass * 64 + lc * 8 < MR * 16 && m < a.M;
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int d = r8 * 8 + lrow;
+                const int n = ncol0 + d;
+                const uint4 v = *reinterpret_cast<const uint4*>(region + d * 128 + ((lc ^ ((d >> 1) & 7)) * 16));
+                if (mv && n < a.N)
+                    *reinterpret_cast<uint4*>(a.out_bf16 + ((size_t)(b * a.heads + (n >> 6)) * 64 + (n & 63)) * a.tokens_pad + t) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        // acc[i][j][e] = (row mrow0 + 16 i + lr, column ncol0 + 16 j + 4 lq + e); image [64 rows][128 B = 64 columns]
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nc = ncol0 + j * 16 + 4 * lq;
+            bv[j] = nc < a.N ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int which = (EPI == EPI_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
+        const float sc = (EPI == EPI_QK && !which) ? a.qscale : 1.0f;
+        const bool nvl = ncol0 + lc * 8 < a.N;
+        const int ld = a.ld_out ? a.ld_out : a.N;
+        bf16_t* qk_base = nullptr;
+        int head = 0;
+        if constexpr (EPI == EPI_QK) {
+            qk_base = which ? a.out2_bf16 : a.out_bf16;
+            head = (ncol0 - which * a.dim) >> 6;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = pass * 4 + ii;
+                if (i >= MR) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = ii * 16 + lr;
+                    const int pc = (j * 2 + (lq >> 1)) ^ ((row >> 1) & 7);
+                    const f32x4 v = acc[i][j] + bv[j];
+                    bf16x4 o;
+                    if constexpr (EPI == EPI_GELU) {
+                        const f32x4 gv = gelu_f4(v, a.gelu_tanh);
+                        o = pack4<F16>(gv[0], gv[1], gv[2], gv[3]);
+                    } else
+                        o = pack4<F16>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+                    *reinterpret_cast<bf16x4*>(region + row * 128 + pc * 16 + (lq & 1) * 8) = o;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int row = r8 * 8 + lrow;
+                const int m = mrow0 + pass * 64 + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+                if (pass * 64 + row >= MR * 16 || m >= a.M || !nvl) continue;
+                if constexpr (EPI == EPI_GELU) {
+                    *reinterpret_cast<uint4*>(a.out_bf16 + (size_t)m * ld + ncol0 + lc * 8) = v;
+                } else {
+                    const int b = m / a.tokens, t = m - b * a.tokens;
+                    *reinterpret_cast<uint4*>(qk_base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + lc * 8) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -291,133 +420,190 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
 
+    // Persistent: workgroup w walks tiles w, w + grid, w + 2 grid, ...  The grid is a multiple of 8 (or the
+    // whole problem), so every tile of a workgroup keeps its XCD and the bijective remap below still
+    // hands neighbouring tiles to the workgroups that share an L2.
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = tm * TBM, n0 = tn * BN;
+    auto tile_origin = [&](int id, int& m0, int& n0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        m0 = (bid / tiles_n) * TBM;
+        n0 = (bid % tiles_n) * BN;
+    };
     const int K = a.K, nt = K / BK;
     const int w_rows = tiles_n * BN;
 
-    f32x4 acc[MR][4];
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int stamp_tile = 0;
+#define PPSTAMP(idx)                                                                                     \
+    do {                                                                                                 \
+        if (a.stamps && blockIdx.x == 8 && stamp_tile < 8) {                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            const unsigned long long ts_ = __builtin_readcyclecounter();                                 \
+            if (lane == 0) a.stamps[wave * 64 + stamp_tile * 8 + (idx)] = ts_;                           \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+        }                                                                                                \
+    } while (0)
+    int tile = blockIdx.x, m0, n0;
+    tile_origin(tile, m0, n0);
+    int par = 0;        // K-tile t of the current output tile lives in LDS stage (par + t) & 1
 
-    // prologue: K-tile 0 complete
+    // prologue of the first tile: K-tile 0 complete
     if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0, 0, smem, wave, lane);     // 4 MR sub-tiles of 8 rows (wave 7 idle for MR = 7)
     stage_tile(a.W, w_rows, K, n0, 0, smem + TILE_BYTES, wave, lane);
 
-    // This wave's eight staging slots of a K-tile (two per phase), as (global source pointer for
-    // K-tile 1, LDS offset inside a stage).  Phase lists of 16 sub-tiles (8 rows x 128 B each), wave w
-    // takes entries 2w, 2w+1:  0: W rows 0..127 | 1: W rows 128..255 | 2: A-low | 3: A-high, where
-    // A-low = the rows the two wave groups multiply in phases 0/1 (8-row blocks 0..7, 16..23).
-    const bf16_t* src[8];
-    int dst[8];
-    {
-        const int row_in = lane >> 3;
-        const int chunk = (lane & 7) ^ row_in;
-        auto slot = [&](int idx, bool isW, int rb8) {
-            int grow = (isW ? n0 : m0) + rb8 * 8 + row_in;
-            const int lim = isW ? w_rows : a.M;
-            grow = grow < lim ? grow : lim - 1;
-            src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + BK + chunk * 8;
-            dst[idx] = (isW ? TILE_BYTES : 0) + rb8 * 1024;
-        };
-        // A-low = the first 64 rows of each wave group (8-row blocks g*2*MR + 0..7): 16 sub-tiles, 2 per wave.
-        // A-high = the remaining (2 MR - 8) blocks of each group: 16 (MR = 8) or 12 (MR = 7) sub-tiles; with
-        // MR = 7 waves 4..7 have one (n_hi = 1) and their counted waits are one lower.
-        for (int u = 0; u < 2; ++u) {
-            const int e = 2 * wave + u;
-            slot(0 + u, true, e);
-            slot(2 + u, true, 16 + e);
-            slot(4 + u, false, e < 8 ? e : 2 * MR + (e - 8));
-        }
-        if constexpr (MR == 8) {
+    for (;;) {
+        f32x4 acc[MR][4];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // This wave's eight staging slots of a K-tile (two per phase), as (global source pointer for
+        // K-tile 1, LDS offset inside a stage).  Phase lists of 16 sub-tiles (8 rows x 128 B each), wave w
+        // takes entries 2w, 2w+1:  0: W rows 0..127 | 1: W rows 128..255 | 2: A-low | 3: A-high, where
+        // A-low = the rows the two wave groups multiply in phases 0/1 (8-row blocks 0..7, 16..23).
+        const bf16_t* src[8];
+        int dst[8];
+        {
+            const int row_in = lane >> 3;
+            const int chunk = (lane & 7) ^ row_in;
+            auto slot = [&](int idx, bool isW, int rb8) {
+                int grow = (isW ? n0 : m0) + rb8 * 8 + row_in;
+                const int lim = isW ? w_rows : a.M;
+                grow = grow < lim ? grow : lim - 1;
+                src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + BK + chunk * 8;
+                dst[idx] = (isW ? TILE_BYTES : 0) + rb8 * 1024;
+            };
+            // A-low = the first 64 rows of each wave group (8-row blocks g*2*MR + 0..7): 16 sub-tiles, 2 per wave.
+            // A-high = the remaining (2 MR - 8) blocks of each group: 16 (MR = 8) or 12 (MR = 7) sub-tiles; with
+            // MR = 7 waves 4..7 have one (n_hi = 1) and their counted waits are one lower.
             for (int u = 0; u < 2; ++u) {
                 const int e = 2 * wave + u;
-                slot(6 + u, false, e < 8 ? 8 + e : 2 * MR + 8 + (e - 8));
+                slot(0 + u, true, e);
+                slot(2 + u, true, 16 + e);
+                slot(4 + u, false, e < 8 ? e : 2 * MR + (e - 8));
             }
-        } else {
-            // 12 sub-tiles: group 0 blocks 8..13, group 1 blocks 2MR+8 .. 2MR+13; waves 0..3 take two, 4..7 one
-            auto hi = [](int f) { return f < 6 ? 8 + f : 2 * MR + 8 + (f - 6); };
-            if (wave < 4) {
-                slot(6, false, hi(2 * wave));
-                slot(7, false, hi(2 * wave + 1));
+            if constexpr (MR == 8) {
+                for (int u = 0; u < 2; ++u) {
+                    const int e = 2 * wave + u;
+                    slot(6 + u, false, e < 8 ? 8 + e : 2 * MR + 8 + (e - 8));
+                }
             } else {
-                slot(6, false, hi(8 + (wave - 4)));
-                src[7] = src[6];
-                dst[7] = dst[6];
+                // 12 sub-tiles: group 0 blocks 8..13, group 1 blocks 2MR+8 .. 2MR+13; waves 0..3 take two, 4..7 one
+                auto hi = [](int f) { return f < 6 ? 8 + f : 2 * MR + 8 + (f - 6); };
+                if (wave < 4) {
+                    slot(6, false, hi(2 * wave));
+                    slot(7, false, hi(2 * wave + 1));
+                } else {
+                    slot(6, false, hi(8 + (wave - 4)));
+                    src[7] = src[6];
+                    dst[7] = dst[6];
+                }
             }
         }
-    }
-    const int n_hi = (MR == 8 || wave < 4) ? 2 : 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
+        const int n_hi = (MR == 8 || wave < 4) ? 2 : 1;
+        // K-tile 0 landed; for every tile but the first this also retires the previous epilogue's stores,
+        // which had that epilogue and these address computations to drain
+        PPSTAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PPSTAMP(1);
+        __builtin_amdgcn_s_barrier();
+        if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
+        PPSTAMP(2);
 
-    bf16x8 wf[2][4];
-    for (int t = 0; t < nt; ++t) {
-        const char* cur = smem + (t & 1) * STAGE_BYTES;
-        char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-        const bool more = t + 1 < nt;
+        bf16x8 wf[2][4];
+        for (int t = 0; t < nt; ++t) {
+            const char* cur = smem + ((par + t) & 1) * STAGE_BYTES;
+            char* nxt = smem + ((par + t + 1) & 1) * STAGE_BYTES;
+            const bool more = t + 1 < nt;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int mh = p >> 1, kk = p & 1;
-            // ---------------- R(P): issue only -- fragment reads of this phase, two loads of the next K-tile
-            bf16x8 af[4];
-            if (p < 2) {
+            for (int p = 0; p < 4; ++p) {
+                const int mh = p >> 1, kk = p & 1;
+                // ---------------- R(P): issue only -- fragment reads of this phase, two loads of the next K-tile
+                bf16x8 af[4];
+                if (p < 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wf[kk][j] = read_frag(cur + TILE_BYTES, wave_n * 4 + j, kk, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (mh * 4 + i < MR) af[i] = read_frag(cur, wave_m * MR + mh * 4 + i, kk, lane);
-            if (more) {
-                glds16(src[2 * p], nxt + dst[2 * p]);
-                src[2 * p] += BK;
-                if (p < 3 || n_hi == 2) {
-                    glds16(src[2 * p + 1], nxt + dst[2 * p + 1]);
-                    src[2 * p + 1] += BK;
+                    for (int j = 0; j < 4; ++j) wf[kk][j] = read_frag(cur + TILE_BYTES, wave_n * 4 + j, kk, lane);
                 }
-                if (p == 3) {           // W and A-low of tile t+1 landed; only this phase's A-high may be in flight
-                    if (n_hi == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (mh * 4 + i < MR) af[i] = read_frag(cur, wave_m * MR + mh * 4 + i, kk, lane);
+                if (more) {
+                    glds16(src[2 * p], nxt + dst[2 * p]);
+                    src[2 * p] += BK;
+                    if (p < 3 || n_hi == 2) {
+                        glds16(src[2 * p + 1], nxt + dst[2 * p + 1]);
+                        src[2 * p + 1] += BK;
+                    }
+                    if (p == 3) {           // W and A-low of tile t+1 landed; only this phase's A-high may be in flight
+                        if (n_hi == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    } else if (p == 1) {
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                    }
                 } else if (p == 1) {
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-            } else if (p == 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- C(P): the reads were issued a whole interval ago
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (mh * 4 + i >= MR) continue;
+                        if constexpr (EPI == EPI_VT)
+                            acc[mh * 4 + i][j] = mfma_16x16x32<F16>(af[i], wf[kk][j], acc[mh * 4 + i][j]);
+                        else
+                            acc[mh * 4 + i][j] = mfma_16x16x32<F16>(wf[kk][j], af[i], acc[mh * 4 + i][j]);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- C(P): the reads were issued a whole interval ago
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (mh * 4 + i >= MR) continue;
-                    if constexpr (EPI == EPI_VT)
-                        acc[mh * 4 + i][j] = mfma_16x16x32<F16>(af[i], wf[kk][j], acc[mh * 4 + i][j]);
-                    else
-                        acc[mh * 4 + i][j] = mfma_16x16x32<F16>(wf[kk][j], af[i], acc[mh * 4 + i][j]);
-                }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
         }
+        if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
+        PPSTAMP(3);
+
+        // Every wave is past its last fragment read and no LDS-DMA is in flight.  Stage (par + nt) & 1 (last
+        // read in K-tile nt - 2) receives K-tile 0 of this workgroup's next tile now, so that its HBM
+        // latency is covered by the epilogue; the stage of the last K-tile is the epilogue's scratch.
+        const int next = tile + gridDim.x;
+        const bool has_next = next < nwg;
+        int m0n = 0, n0n = 0;
+        const int par_next = (par + nt) & 1;
+        if (has_next) {
+            tile_origin(next, m0n, n0n);
+            char* st = smem + par_next * STAGE_BYTES;
+            if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0n, 0, st, wave, lane);
+            stage_tile(a.W, w_rows, K, n0n, 0, st + TILE_BYTES, wave, lane);
+        }
+        PPSTAMP(4);
+        bool staged = false;
+        if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK) {
+            const bool ok = EPI == EPI_VT   ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
+                            : EPI == EPI_QK ? (a.dim % 64 == 0)
+                                            : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
+            if (ok) {
+                gemm_epilogue_staged<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane,
+                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192);
+                staged = true;
+            }
+        }
+        if (!staged) gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane);
+        PPSTAMP(5);
+        ++stamp_tile;
+        if (!has_next) break;
+        tile = next;
+        m0 = m0n;
+        n0 = n0n;
+        par = par_next;
     }
-    if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
-    gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -726,12 +912,17 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             // measured (r01): the switch pays when the predicted saving is large (N = 768: 2.625 vs 3 rounds,
             // -4..6 %) and costs 3 % when it is marginal (N = 3072: 9.6 vs 10) -- smaller tiles re-read W more.
             const bool use7 = allow224 && r7 * 100 < r8 * 93;
+            // persistent grid: one workgroup per CU (a multiple of 8 so that a workgroup's tiles keep their XCD)
+            static const bool persist = !(getenv("HIPTS_GEMM_PERSIST") && strcmp(getenv("HIPTS_GEMM_PERSIST"), "0") == 0);
+            const int ntile = (use7 ? tiles_m7 : tiles_m) * tiles_n;
+            const int slots = cus >= 8 ? cus / 8 * 8 : cus;
+            const int grid = (persist && ntile > slots) ? slots : ntile;
             if (a.f16) {
-                if (use7) gemm_pp_kernel<EPI, 7, true><<<tiles_m7 * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
-                else gemm_pp_kernel<EPI, 8, true><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+                if (use7) gemm_pp_kernel<EPI, 7, true><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
+                else gemm_pp_kernel<EPI, 8, true><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
             } else {
-                if (use7) gemm_pp_kernel<EPI, 7, false><<<tiles_m7 * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
-                else gemm_pp_kernel<EPI, 8, false><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+                if (use7) gemm_pp_kernel<EPI, 7, false><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
+                else gemm_pp_kernel<EPI, 8, false><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
             }
         }
         else

@@ -8,6 +8,7 @@
 //   final LN + token mean (partial sums) -> finalize (hi/lo bf16 split) -> head GEMM (+sigmoid).
 // The residual stream, LN statistics, softmax and every accumulation are float32; only MFMA
 // operands are bf16.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -104,8 +105,9 @@ struct hipts_vit {
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs;
     int pool_splits = 1;
-    hipStream_t sub[2] = {nullptr, nullptr};      // internal streams of the two half-batches
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    static constexpr int kMaxSub = 4;
+    hipStream_t sub[kMaxSub] = {};                // internal streams of the sub-batches
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
 };
 
 namespace {
@@ -413,6 +415,12 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
 int hipts_vit_destroy(hipts_vit_t* h) {
     if (h) {
         (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        for (auto st : h->sub)
+            if (st) (void)hipStreamDestroy(st);
+        for (auto e : h->ev_join)
+            if (e) (void)hipEventDestroy(e);
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
         delete h;
     }
     return HIPTS_OK;
@@ -757,19 +765,19 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     // Two half-batches on two internal streams: a GEMM grid's partial last round, an epilogue that is
     // waiting on HBM and every kernel boundary of one half are filled with work of the other half.
     static const int want_streams = getenv("HIPTS_VIT_STREAMS") ? atoi(getenv("HIPTS_VIT_STREAMS")) : 2;
-    if (want_streams >= 2 && batch >= 16) {
-        if (!h->sub[0]) {
-            HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[0], hipStreamNonBlocking));
-            HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[1], hipStreamNonBlocking));
-            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));
-            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[1], hipEventDisableTiming));
-        }
-        const int nb0 = (batch + 1) / 2;
+    const int ns = std::min({want_streams, (int)hipts_vit::kMaxSub, batch / 8});
+    if (ns >= 2) {
+        if (!h->ev_fork) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < ns; ++i)
+            if (!h->sub[i]) {
+                HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking));
+                HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+            }
         HIPTS_HIP(hipEventRecord(h->ev_fork, s));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < ns; ++i) {
+            const int i0 = (int)((int64_t)batch * i / ns), i1 = (int)((int64_t)batch * (i + 1) / ns);
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, lg, pr, h->sub[i]));
+            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i]));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
             HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
@@ -882,14 +890,14 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
         HIPTS_HIP(hipMemcpy(h, g.stamps, sizeof(h), hipMemcpyDeviceToHost));
         unsigned long long base = ~0ull;
         for (int w = 0; w < 8; ++w) if (h[w * 64] && h[w * 64] < base) base = h[w * 64];
-        fprintf(stderr, "stamps (cycles since first; per wave: t10 mh0 [S0..S6] | t10 mh1 | t11 mh0 | t11 mh1)\n");
-        for (int w = 0; w < 8; ++w) {
-            fprintf(stderr, "wave %d:", w);
-            for (int i = 0; i < 32; ++i) {
-                if ((i & 7) == 7) { fprintf(stderr, " |"); continue; }
-                fprintf(stderr, " %6lld", (long long)(h[w * 64 + i] - base));
+        fprintf(stderr, "stamps of workgroup 8 (cycles since first): per tile [top, K-tile 0 landed, loop start, loop end, next prologue issued, epilogue issued]\n");
+        for (int w = 0; w < 8; w += 4) {
+            for (int t = 0; t < 8; ++t) {
+                if (!h[w * 64 + t * 8]) continue;
+                fprintf(stderr, "wave %d tile %d:", w, t);
+                for (int i = 0; i < 6; ++i) fprintf(stderr, " %7lld", (long long)(h[w * 64 + t * 8 + i] - base));
+                fprintf(stderr, "\n");
             }
-            fprintf(stderr, "\n");
         }
     }
     (void)hipEventDestroy(e0);

@@ -1,4 +1,8 @@
 #!/bin/bash
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
-timeout -k 10 900 python -m pytest tests/test_gpu_vit.py tests/test_gpu_gemm.py::test_forward_is_deterministic_and_batch_invariant tests/test_gpu_e2e.py -m gpu -x -q 2>&1 | tail -4 || exit 1
-for rep in 1 2; do for st in 2 1; do HIPTS_VIT_STREAMS=$st timeout -k 10 300 python bench.py --no-cpu-baseline --no-query 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('streams=$st', d['value'], d['ms_per_step'])"; done; done
+run() { env "$@" timeout -k 10 300 python bench.py --no-cpu-baseline --no-query 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'])"; }
+for rep in 1 2; do
+run HIPTS_VIT_STREAMS=2
+run HIPTS_VIT_STREAMS=2 HIPTS_GEMM_BM=256
+run HIPTS_VIT_STREAMS=3 HIPTS_GEMM_BM=256
+done
