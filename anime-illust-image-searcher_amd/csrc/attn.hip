@@ -27,7 +27,8 @@ constexpr int KS = 144;              // LDS bytes per K row   (64 d  * 2 B + 16)
 constexpr int VS = 136;              // LDS bytes per V^T row (64 key* 2 B + 8)
 constexpr int K_BYTES = KV * KS;     // 9216
 constexpr int V_BYTES = 64 * VS;     // 8704
-constexpr int STAGE = K_BYTES + V_BYTES;
+constexpr int V_BASE = 2 * K_BYTES;  // LDS: two K slots, then three V^T slots
+constexpr int LDS_BYTES = 2 * K_BYTES + 3 * V_BYTES;   // 44.5 KB: three workgroups per CU
 
 // Written with plain fmaxf so the compiler sees the MFMA -> VALU dependency and inserts the required
 // wait states itself.  (An inline-asm v_max3_f32 here read accumulator registers before the MFMA had
@@ -81,6 +82,9 @@ __device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int 
     }
 }
 
+// (A lazy reference -- rescale O and l only when some row's tile maximum exceeds the reference by 2^8,
+// behind a wave-uniform branch -- was measured SLOWER, 217 vs 196 us: the branch stops the scheduler from
+// running this VALU work under the P V MFMAs.)
 template <bool F16>
 __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2], float& m_run,
                                              float& l_run) {
@@ -111,9 +115,11 @@ template <bool F16>
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
                                                    int tokens, int tokens_pad, int qblocks) {
-    // three stages: iteration t multiplies K(t) from stage t%3 and V(t-1) from stage (t-1)%3 while
-    // tile t+1 is written into stage (t+1)%3 (whose K and V were last read before the previous barrier)
-    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+    // iteration t multiplies K(t) (slot t & 1) and V(t-1) (slot (t-1) % 3) while tile t+1 is written: K(t+1)
+    // over K(t-1), V(t+1) over V(t-2), both last read before the previous barrier.  Two K and three V^T
+    // slots = 44.5 KB, so three workgroups (three waves per SIMD at 148 VGPRs) share a CU and one wave's
+    // softmax (VALU) runs under the others' MFMAs.
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware work id: workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
@@ -144,20 +150,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     const bf16_t* kp = k + (size_t)bh * tokens_pad * 64 + (size_t)row0 * 64 + col * 8;
     const bf16_t* vp = vT + (size_t)bh * 64 * tokens_pad + (size_t)row0 * tokens_pad + col * 8;
     const size_t k_row32 = (size_t)32 * 64, v_row32 = (size_t)32 * tokens_pad;
-    const int kdst = row0 * KS + col * 16, vdst = K_BYTES + row0 * VS + col * 16;
+    const int kdst = row0 * KS + col * 16, vdst = V_BASE + row0 * VS + col * 16;
     uint4 kreg0, kreg1, vreg0, vreg1;
 #define ATTN_LOAD(kv0)                                                                  \
     kreg0 = *reinterpret_cast<const uint4*>(kp + (size_t)(kv0) * 64);                   \
     kreg1 = *reinterpret_cast<const uint4*>(kp + (size_t)(kv0) * 64 + k_row32);         \
     vreg0 = *reinterpret_cast<const uint4*>(vp + (kv0));                                \
     vreg1 = *reinterpret_cast<const uint4*>(vp + (kv0) + v_row32);
-#define ATTN_WRITE(st)                                                                  \
-    *reinterpret_cast<uint4*>((st) + kdst) = kreg0;                                     \
-    *reinterpret_cast<uint4*>((st) + kdst + 32 * KS) = kreg1;                           \
-    *reinterpret_cast<uint2*>((st) + vdst) = make_uint2(vreg0.x, vreg0.y);              \
-    *reinterpret_cast<uint2*>((st) + vdst + 8) = make_uint2(vreg0.z, vreg0.w);          \
-    *reinterpret_cast<uint2*>((st) + vdst + 32 * VS) = make_uint2(vreg1.x, vreg1.y);    \
-    *reinterpret_cast<uint2*>((st) + vdst + 32 * VS + 8) = make_uint2(vreg1.z, vreg1.w);
+#define ATTN_WRITE(ks, vs)                                                                            \
+    *reinterpret_cast<uint4*>(smem + (ks) * K_BYTES + kdst) = kreg0;                                  \
+    *reinterpret_cast<uint4*>(smem + (ks) * K_BYTES + kdst + 32 * KS) = kreg1;                        \
+    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst) = make_uint2(vreg0.x, vreg0.y);           \
+    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst + 8) = make_uint2(vreg0.z, vreg0.w);       \
+    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst + 32 * VS) = make_uint2(vreg1.x, vreg1.y); \
+    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst + 32 * VS + 8) = make_uint2(vreg1.z, vreg1.w);
 
     f32x16 o[2];
 #pragma unroll
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     const int nkv = tokens_pad / KV;
     const bool masked_tail = tokens_pad > tokens;
     ATTN_LOAD(0)
-    ATTN_WRITE(smem)
+    ATTN_WRITE(0, 0)
     __syncthreads();
     // tile 0: scores and softmax only (its P V is issued in the next iteration)
     if (nkv > 1) {
@@ -182,27 +188,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     else s_tile<false, F16>(smem, 0, tokens, r, h, qf, sacc);
     softmax_tile<F16>(sacc, pf, o, m_run, l_run);
     if (nkv > 1) {
-        ATTN_WRITE(smem + STAGE)
+        ATTN_WRITE(1, 1)
     }
     __syncthreads();
-    int cur = 1, prev = 0;                    // stage of K(t) / of V(t-1)
+    int vprev = 0, vcur = 1;                  // V^T slot of tile t-1 / of tile t
     for (int t = 1; t < nkv; ++t) {
-        const int nxt = cur == 2 ? 0 : cur + 1;
+        const int vnxt = vcur == 2 ? 0 : vcur + 1;
         if (t + 1 < nkv) {
             ATTN_LOAD((t + 1) * KV)
         }
-        if (t + 1 == nkv && masked_tail) s_tile<true, F16>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
-        else s_tile<false, F16>(smem + cur * STAGE, t * KV, tokens, r, h, qf, sacc);
-        pv_tile<F16>(smem + prev * STAGE + K_BYTES, r, h, pf, o);
+        const char* kt = smem + (t & 1) * K_BYTES;
+        if (t + 1 == nkv && masked_tail) s_tile<true, F16>(kt, t * KV, tokens, r, h, qf, sacc);
+        else s_tile<false, F16>(kt, t * KV, tokens, r, h, qf, sacc);
+        pv_tile<F16>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
         softmax_tile<F16>(sacc, pf, o, m_run, l_run);
         if (t + 1 < nkv) {
-            ATTN_WRITE(smem + nxt * STAGE)
+            ATTN_WRITE((t + 1) & 1, vnxt)
         }
         __syncthreads();
-        prev = cur;
-        cur = nxt;
+        vprev = vcur;
+        vcur = vnxt;
     }
-    pv_tile<F16>(smem + prev * STAGE + K_BYTES, r, h, pf, o);
+    pv_tile<F16>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
 #undef ATTN_LOAD
 #undef ATTN_WRITE
 

@@ -20,6 +20,7 @@
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) walk
 // neighbouring tiles and reuse operand panels in that XCD's L2.
 #include <cstdlib>
+#include <type_traits>
 
 #include "vit_internal.h"
 
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         __builtin_amdgcn_s_barrier();
         if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
         PPSTAMP(2);
+        if (a.stamps && blockIdx.x == 8 && stamp_tile < 8 && lane == 0) a.stamps[wave * 64 + stamp_tile * 8 + 6] = wall_clock64();
 
         bf16x8 wf[2][4];
         for (int t = 0; t < nt; ++t) {
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         }
         if (wave_m == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
         PPSTAMP(3);
+        if (a.stamps && blockIdx.x == 8 && stamp_tile < 8 && lane == 0) a.stamps[wave * 64 + stamp_tile * 8 + 7] = wall_clock64();
 
         // Every wave is past its last fragment read and no LDS-DMA is in flight.  Stage (par + nt) & 1 (last
         // read in K-tile nt - 2) receives K-tile 0 of this workgroup's next tile now, so that its HBM
@@ -851,6 +854,194 @@ __global__ __launch_bounds__(256, 2) void gemm_s3_kernel(const GemmArgs a, int t
     gemm_epilogue<EPI>(a, acc, m0, n0, wave_m, wave_n, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dual-workgroup loop ("dw"): 256 x 128 x 32 tiles, 4 waves (2 x 2, 128 x 64 each), three 24 KB LDS
+// stages = 72 KB, <= 256 VGPRs: TWO workgroups per CU, one wave of each per SIMD.  The point is the
+// epilogue: with one 512-thread workgroup per CU the matrix pipe idles while that workgroup adds bias /
+// GELU / residual and drains its stores (4..20 us on a 18 us K = 768 main loop); here the other resident
+// workgroup keeps multiplying meanwhile.  A wave therefore has no lock-step partner on its SIMD and
+// software-pipelines its own fragments in registers:
+//
+//   step s:   16 MFMA A-low(s) x W(s), A-high(s) read in their shadow | waits | barrier B_s |
+//             16 MFMA A-high(s) x W(s), W(s+1) / A-low(s+1) read and stage s+3 issued in their shadow
+//
+// B_s is the only barrier of a step.  Before it a wave has retired its own reads of stage s
+// (lgkmcnt(0)) and its own loads of stage s+1 (vmcnt(6): stage s+2 stays in flight); after it slot
+// s % 3 is free for stage s+3 and stage s+1 is visible.  Every load has two steps to land.
+// LDS image: a 16-row x 32-k block is 1 KB of 64 B rows; the 16 B chunk c of row r is stored at chunk
+// c ^ ((r >> 2) & 3) (swizzle applied to the global source address, the LDS-DMA writes lane-linear),
+// which makes the 16 lanes of a ds_read_b128 phase (one k-chunk, rows 0..15) hit 16 different bank groups.
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_BM = 256, DW_BN = 128, DW_BK = 32;
+constexpr int DW_A_BYTES = DW_BM * DW_BK * 2;                    // 16 KiB
+constexpr int DW_STAGE = (DW_BM + DW_BN) * DW_BK * 2;            // 24 KiB
+constexpr int DW_LDS = 3 * DW_STAGE;                             // 72 KiB
+
+template <int EPI, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * DW_BM, n0 = tn * DW_BN;
+    const int K = a.K, nt = K / DW_BK;
+    const int w_rows = ((a.N + 255) / 256) * 256;
+
+    // six staging slots per wave and stage: A blocks 4 wave .. 4 wave + 3, W blocks 2 wave, 2 wave + 1
+    const bf16_t* src[6];
+    int dst[6];
+    {
+        const int r = lane >> 2, q = (lane & 3) ^ ((r >> 2) & 3);     // four lanes fetch one 64 B row segment
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rb = wave * 4 + i;
+            int grow = m0 + rb * 16 + r;
+            grow = grow < a.M ? grow : a.M - 1;
+            src[i] = a.A + (size_t)grow * K + q * 8;
+            dst[i] = rb * 1024;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = wave * 2 + i;
+            int grow = n0 + rb * 16 + r;
+            grow = grow < w_rows ? grow : w_rows - 1;
+            src[4 + i] = a.W + (size_t)grow * K + q * 8;
+            dst[4 + i] = DW_A_BYTES + rb * 1024;
+        }
+    }
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 2) & 3)) * 16);
+    auto issue = [&](int i, char* st) {
+        glds16(src[i], st + dst[i]);
+        src[i] += DW_BK;
+    };
+    auto frag = [&](const char* base, int rb) { return *reinterpret_cast<const bf16x8*>(base + rb * 1024 + frag_off); };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool trace = a.stamps && a.trace && blockIdx.x < 4096;
+    if (trace && tid == 0) {
+        a.stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg(63492);
+        a.stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg(63508);
+        a.stamps[blockIdx.x * 8 + 2] = wall_clock64();
+    }
+    const int npro = nt < 3 ? nt : 3;
+    for (int s0 = 0; s0 < npro; ++s0)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue(i, smem + s0 * DW_STAGE);
+    if (npro == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (npro == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 wfr[2][4], alo[2][4], ahi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wfr[0][j] = frag(smem + DW_A_BYTES, wave_n * 4 + j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) alo[0][i] = frag(smem, wave_m * 8 + i);
+
+    int slot = 0;       // LDS slot of stage s
+    unsigned long long wait_cyc = 0, bar_cyc = 0;
+    const unsigned long long loop_t0 = a.stamps ? __builtin_readcyclecounter() : 0;
+    const unsigned long long wall_t0 = a.stamps ? wall_clock64() : 0;
+    auto mm = [&](f32x4& c, const bf16x8& av, const bf16x8& wv) {
+        if constexpr (EPI == EPI_VT) c = mfma_16x16x32<F16>(av, wv, c);
+        else c = mfma_16x16x32<F16>(wv, av, c);
+    };
+    // One step; H1/H2/H3 = stage st+1 / st+2 / st+3 exists (compile time: straight-line code, exact
+    // compiler-generated lgkmcnt), U = register set of this step.
+    auto step = [&](auto H1, auto H2, auto H3, auto U) {
+        constexpr bool has1 = decltype(H1)::value, has2 = decltype(H2)::value, has3 = decltype(H3)::value;
+        constexpr int u = decltype(U)::value;
+        const char* cur = smem + slot * DW_STAGE;
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        const char* nx = smem + slot1 * DW_STAGE;
+        // 16 MFMA A-low x W (set u was read during the previous step) with the A-high reads in their shadow
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mm(acc[i][j], alo[u][i], wfr[u][j]);
+                if (i == 0) ahi[j] = frag(cur, wave_m * 8 + 4 + j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if constexpr (has1) {
+            // own reads of stage st retired, own loads of stage st + 1 landed (stage st + 2 may fly)
+            unsigned long long q0 = 0, q1 = 0;
+            if (a.stamps) q0 = __builtin_readcyclecounter();
+            if constexpr (has2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (a.stamps) q1 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();
+            if (a.stamps) { const unsigned long long q2 = __builtin_readcyclecounter(); wait_cyc += q1 - q0; bar_cyc += q2 - q1; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // 16 MFMA A-high x W with the eight reads of set u ^ 1 and the six loads of stage st + 3 in their shadow
+        char* fill = smem + slot * DW_STAGE;        // the slot of stage st is free now
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mm(acc[4 + i][j], ahi[i], wfr[u][j]);
+                const int idx = i * 4 + j;
+                if constexpr (has1) {
+                    if (idx < 4) wfr[u ^ 1][idx] = frag(nx + DW_A_BYTES, wave_n * 4 + idx);
+                    else if (idx < 8) alo[u ^ 1][idx - 4] = frag(nx, wave_m * 8 + (idx - 4));
+                }
+                if constexpr (has3) {
+                    if (idx >= 8 && idx < 14) issue(idx - 8, fill);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        slot = slot1;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    for (int s = 0; s + 6 <= nt; s += 2) {      // nt is even (K % 64 == 0)
+        step(T{}, T{}, T{}, U0{});
+        step(T{}, T{}, T{}, U1{});
+    }
+    if (nt >= 4) {
+        step(T{}, T{}, T{}, U0{});
+        step(T{}, T{}, F{}, U1{});
+    }
+    step(T{}, F{}, F{}, U0{});
+    step(F{}, F{}, F{}, U1{});
+    if (trace && tid == 0) a.stamps[blockIdx.x * 8 + 3] = wall_clock64();
+    if (a.stamps && !trace && blockIdx.x == 8 && lane == 0) {
+        a.stamps[wave * 64 + 0] = __builtin_readcyclecounter() - loop_t0;
+        a.stamps[wave * 64 + 1] = wait_cyc;
+        a.stamps[wave * 64 + 2] = bar_cyc;
+        a.stamps[wave * 64 + 3] = wall_clock64() - wall_t0;
+    }
+    __builtin_amdgcn_s_barrier();       // every wave is past its last fragment read; all loads have landed
+    if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK) {
+        const bool ok = EPI == EPI_VT   ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
+                        : EPI == EPI_QK ? (a.dim % 64 == 0)
+                                        : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
+        if (ok) {
+            gemm_epilogue_staged<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane, smem + wave * 8192);
+            if (trace && tid == 0) a.stamps[blockIdx.x * 8 + 4] = wall_clock64();
+            return;
+        }
+    }
+    gemm_epilogue<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane);
+    if (trace && tid == 0) a.stamps[blockIdx.x * 8 + 4] = wall_clock64();
+}
+
 // HIPTS_GEMM selects the main loop for A/B runs: "pp" (default) ping-pong with 16-MFMA segments;
 // "pp2" 32-MFMA segments (better at K >= 4096, slightly worse on the ViT's K = 768 shapes);
 // "s3" three-stage 256x128 tile, two workgroups per CU; "v1" simple two-barrier loop.
@@ -858,7 +1049,7 @@ int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("HIPTS_GEMM");
-        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "pp2") == 0) ? 3 : (e && strcmp(e, "s3") == 0) ? 2 : 1;
+        v = (e && strcmp(e, "v1") == 0) ? 0 : (e && strcmp(e, "pp2") == 0) ? 3 : (e && strcmp(e, "s3") == 0) ? 2 : (e && strcmp(e, "dw") == 0) ? 4 : 1;
     }
     return v;
 }
@@ -874,12 +1065,18 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_dw_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_dw_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS));
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM;
     const int variant = gemm_variant();
-    HIPTS_REQUIRE(!a.f16 || variant == 1, "half-precision operands are only built for the default (pp) GEMM loop");
-    if (variant == 2) {
+    HIPTS_REQUIRE(!a.f16 || variant == 1 || variant == 4, "half-precision operands are only built for the pp and dw GEMM loops");
+    if (variant == 4) {
+        const int tiles_n = (a.N + DW_BN - 1) / DW_BN;
+        if (a.f16) gemm_dw_kernel<EPI, true><<<tiles_m * tiles_n, 256, DW_LDS, s>>>(a, tiles_m, tiles_n);
+        else gemm_dw_kernel<EPI, false><<<tiles_m * tiles_n, 256, DW_LDS, s>>>(a, tiles_m, tiles_n);
+    } else if (variant == 2) {
         const int tiles_n = (a.N + S3_BN - 1) / S3_BN;
         gemm_s3_kernel<EPI><<<tiles_m * tiles_n, 256, S3_LDS, s>>>(a, tiles_m, tiles_n);
     } else {
@@ -911,7 +1108,9 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             const long r7 = ((long)tiles_m7 * tiles_n + cus - 1) / cus * 224;
             // measured (r01): the switch pays when the predicted saving is large (N = 768: 2.625 vs 3 rounds,
             // -4..6 %) and costs 3 % when it is marginal (N = 3072: 9.6 vs 10) -- smaller tiles re-read W more.
-            const bool use7 = allow224 && r7 * 100 < r8 * 93;
+            // ... and only when the launch has the chip to itself: with sub-batches on several streams the
+            // partial last round is filled by the other stream's kernel and full tiles win (4.50 -> 4.59 k img/s)
+            const bool use7 = allow224 && !a.shared_chip && r7 * 100 < r8 * 93;
             // persistent grid: one workgroup per CU (a multiple of 8 so that a workgroup's tiles keep their XCD)
             static const bool persist = !(getenv("HIPTS_GEMM_PERSIST") && strcmp(getenv("HIPTS_GEMM_PERSIST"), "0") == 0);
             const int ntile = (use7 ? tiles_m7 : tiles_m) * tiles_n;

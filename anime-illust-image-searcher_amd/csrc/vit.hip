@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -597,7 +599,7 @@ int prof_resolve(hipts_vit* h) {
 // The whole kernel sequence for images [i0, i0 + nb) of the current call, on stream s.  Every workspace
 // buffer is indexed by image (rows of M = batch * tokens, or (image, head) blocks), so disjoint image
 // ranges can run on different streams at the same time.
-int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb, float* lg, float* pr, hipStream_t s) {
+int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb, float* lg, float* pr, hipStream_t s, bool shared_chip) {
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
     const int M = nb * T;
@@ -636,6 +638,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     // patch embedding: x = A0 W^T + b + pos
     g = GemmArgs{};
     g.f16 = f16;
+    g.shared_chip = shared_chip;
     g.A = a0; g.M = M; g.N = D; g.out_f32 = x; g.pos = h->pos.as<float>(); g.tokens = T;
     if (is_u8) {   // exact integer pixels; affine normalisation folded into the epilogue
         g.W = h->patch_w.as<bf16_t>(); g.K = h->patch_k; g.bias = h->patch_b_u8.as<float>(); g.qscale = 2.0f / 255.0f;
@@ -659,6 +662,8 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
         g = GemmArgs{};
         g.f16 = f16;
+        g.shared_chip = shared_chip;
+    g.shared_chip = shared_chip;
         g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
         g.bias = L.qkv_b.as<float>(); g.out_bf16 = q; g.out2_bf16 = k;
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
@@ -670,6 +675,8 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         // v, written transposed
         g = GemmArgs{};
         g.f16 = f16;
+        g.shared_chip = shared_chip;
+    g.shared_chip = shared_chip;
         g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
         g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = vT;
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
@@ -684,6 +691,8 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         // x += att Wp^T + b
         g = GemmArgs{};
         g.f16 = f16;
+        g.shared_chip = shared_chip;
+    g.shared_chip = shared_chip;
         g.A = att; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
         g.bias = L.proj_b.as<float>(); g.out_f32 = x;
         {
@@ -698,6 +707,8 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         }
         g = GemmArgs{};
         g.f16 = f16;
+        g.shared_chip = shared_chip;
+    g.shared_chip = shared_chip;
         g.A = xn; g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
         g.bias = L.fc1_b.as<float>(); g.out_bf16 = hmid; g.gelu_tanh = c.gelu_tanh;
         {
@@ -706,6 +717,8 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         }
         g = GemmArgs{};
         g.f16 = f16;
+        g.shared_chip = shared_chip;
+    g.shared_chip = shared_chip;
         g.A = hmid; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
         g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
         {
@@ -729,6 +742,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     // head (+ sigmoid, tagging.py:176)
     g = GemmArgs{};
     g.f16 = f16;
+    g.shared_chip = shared_chip;
     g.A = pooled2; g.W = h->head_w.as<bf16_t>(); g.M = nb; g.N = c.num_classes; g.K = 2 * D;
     g.bias = h->head_b.as<float>(); g.out_f32 = lg ? lg + (size_t)i0 * c.num_classes : nullptr;
     g.out2_f32 = pr ? pr + (size_t)i0 * c.num_classes : nullptr;
@@ -777,12 +791,12 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         for (int i = 0; i < ns; ++i) {
             const int i0 = (int)((int64_t)batch * i / ns), i1 = (int)((int64_t)batch * (i + 1) / ns);
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i]));
+            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i], true));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
             HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
     } else {
-        HIPTS_TRY(vit_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s));
+        HIPTS_TRY(vit_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s, false));
     }
     if (!dev_out) {
         const size_t bytes = (size_t)batch * c.num_classes * 4;
@@ -870,9 +884,10 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     if (epi == EPI_VT) { g.heads = N / 64; g.dim = N; }
     DevBuf stamps;
     if (getenv("HIPTS_GEMM_STAMPS")) {
-        HIPTS_TRY(stamps.alloc(8 * 64 * 8));
-        HIPTS_HIP(hipMemset(stamps.p, 0, 8 * 64 * 8));
+        HIPTS_TRY(stamps.alloc(4096 * 8 * 8));
+        HIPTS_HIP(hipMemset(stamps.p, 0, 4096 * 8 * 8));
         g.stamps = stamps.as<unsigned long long>();
+        g.trace = getenv("HIPTS_GEMM_TRACE") ? 1 : 0;
     }
     hipEvent_t e0, e1;
     HIPTS_HIP(hipEventCreate(&e0));
@@ -886,16 +901,34 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
     if (g.stamps) {
+        // trace mode: the last launch's records
         unsigned long long h[8 * 64];
         HIPTS_HIP(hipMemcpy(h, g.stamps, sizeof(h), hipMemcpyDeviceToHost));
         unsigned long long base = ~0ull;
         for (int w = 0; w < 8; ++w) if (h[w * 64] && h[w * 64] < base) base = h[w * 64];
+        if (getenv("HIPTS_GEMM_TRACE")) {
+            std::vector<unsigned long long> tr(4096 * 8);
+            HIPTS_HIP(hipMemcpy(tr.data(), g.stamps, tr.size() * 8, hipMemcpyDeviceToHost));
+            FILE* f = fopen(getenv("HIPTS_GEMM_TRACE"), "w");
+            if (f) {
+                for (int b = 0; b < 4096; ++b)
+                    if (tr[b * 8 + 2])
+                        fprintf(f, "%d %llu %llu %llu %llu %llu\n", b, tr[b * 8], tr[b * 8 + 1], tr[b * 8 + 2], tr[b * 8 + 3], tr[b * 8 + 4]);
+                fclose(f);
+            }
+        } else
+        if (getenv("HIPTS_GEMM") && strcmp(getenv("HIPTS_GEMM"), "dw") == 0) {
+            for (int w = 0; w < 4; ++w)
+                fprintf(stderr, "dw wave %d: loop %lld cycles, waitcnt %lld, barrier %lld, wall %lld x 10 ns -> %.2f GHz\n", w, (long long)h[w * 64],
+                        (long long)h[w * 64 + 1], (long long)h[w * 64 + 2], (long long)h[w * 64 + 3], h[w * 64] / (h[w * 64 + 3] * 10.0));
+        } else
         fprintf(stderr, "stamps of workgroup 8 (cycles since first): per tile [top, K-tile 0 landed, loop start, loop end, next prologue issued, epilogue issued]\n");
         for (int w = 0; w < 8; w += 4) {
             for (int t = 0; t < 8; ++t) {
                 if (!h[w * 64 + t * 8]) continue;
                 fprintf(stderr, "wave %d tile %d:", w, t);
                 for (int i = 0; i < 6; ++i) fprintf(stderr, " %7lld", (long long)(h[w * 64 + t * 8 + i] - base));
+                fprintf(stderr, "  loop clock %.2f GHz", (h[w * 64 + t * 8 + 3] - h[w * 64 + t * 8 + 2]) / ((h[w * 64 + t * 8 + 7] - h[w * 64 + t * 8 + 6]) * 10.0));
                 fprintf(stderr, "\n");
             }
         }

@@ -78,6 +78,8 @@ struct GemmArgs {
     int gelu_tanh = 1;
     int ld_out = 0;                 // row stride of out (elements); 0 = N
     int f16 = 0;                    // operands (and 16-bit outputs) are IEEE half instead of bf16
+    int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
+    int trace = 0;                          // diagnostic: per-workgroup timeline records instead of stamps (dw loop)
     unsigned long long* stamps = nullptr;   // diagnostic build only (tools/gemm_bench.py): s_memtime stamps of block 0
 };
 

@@ -1,7 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
-timeout -k 10 600 python -m pytest tests/test_gpu_vit.py tests/test_gpu_gemm.py tests/test_gpu_e2e.py -m gpu -x -q 2>&1 | tail -4 || exit 1
-HIPTS_GEMM_STAMPS=1 timeout -k 10 300 python tools/gemm_bench.py gelu,50176,3072,768 2>&1 | tail -12
-timeout -k 10 300 python tools/gemm_bench.py qk,50176,1536,768 vt,50176,768,768 resid,50176,768,768 gelu,50176,3072,768 resid,50176,768,3072 gelu,4096,4096,4096
-for at in 1 2 3; do timeout -k 10 300 python bench.py --no-cpu-baseline --no-query 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
+HIPTS_DBG_DELAY=-1 HIPTS_GEMM_STAMPS=1 HIPTS_GEMM_TRACE=gpurun_out/dw_trace_qk.txt HIPTS_GEMM=dw timeout -k 10 300 python tools/gemm_bench.py qk,50176,1536,768 2>&1 | tail -3
+python tools/dw_trace.py gpurun_out/dw_trace_qk.txt

@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout -k 10 300 python tools/hbm_probe.py
+timeout -k 10 120 ./tools/micro/valu_rate

@@ -4,5 +4,7 @@ run() { env "$@" timeout -k 10 300 python bench.py --no-cpu-baseline --no-query 
 for rep in 1 2; do
 run HIPTS_VIT_STREAMS=2
 run HIPTS_VIT_STREAMS=2 HIPTS_GEMM_BM=256
+run HIPTS_VIT_STREAMS=3
 run HIPTS_VIT_STREAMS=3 HIPTS_GEMM_BM=256
+run HIPTS_VIT_STREAMS=1
 done

@@ -41,7 +41,7 @@ sys.exit(1 if bad else 0)
 """
 
 
-@pytest.mark.parametrize("variant", ["pp", "pp2", "s3", "v1"])
+@pytest.mark.parametrize("variant", ["pp", "dw", "pp2", "s3", "v1"])
 def test_gemm_variants_match_float64(variant):
     """Each variant is selected per process (HIPTS_GEMM is read once), hence the child interpreter."""
     env = dict(os.environ, HIPTS_GEMM=variant)
