@@ -88,23 +88,47 @@ __device__ __forceinline__ f32x4 gelu_f4(f32x4 x, int tanh_form) {
     return f32x4{gelu_f(x[0], 0), gelu_f(x[1], 0), gelu_f(x[2], 0), gelu_f(x[3], 0)};
 }
 
+// The bias values an epilogue needs, in its accumulator layout (V^T: one column per lane and 16-column
+// block, in [j][0]; otherwise four consecutive columns).  The persistent loop issues these loads before
+// the next tile's prologue so that their latency is not the first thing the epilogue waits for.
+template <int EPI>
+__device__ __forceinline__ void load_bias(const GemmArgs& a, int n0, int wave_n, int lane, f32x4 (&bv)[4]) {
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (EPI == EPI_VT) {
+            const int n = n0 + wave_n * 64 + j * 16 + lr;
+            bv[j] = f32x4{n < a.N ? a.bias[n] : 0.f, 0.f, 0.f, 0.f};
+        } else if constexpr (EPI == EPI_HEAD) {
+            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const int nc = n0 + wave_n * 64 + j * 16 + 4 * lq;
+            bv[j] = nc < a.N ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // Epilogue shared by both main-loop variants.  acc[i][j]: 16 x 16 tile (i: 16-row block of the
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
 // latencies overlap instead of forming a chain of 32 dependent round trips.
 template <int EPI, int MR = 8, bool F16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                              int lane) {
+                                              int lane, const f32x4* bias_pre = nullptr) {
     const int lr = lane & 15, lq = lane >> 4;
     const int ld = a.ld_out ? a.ld_out : a.N;
+    f32x4 bias_v[4];
+    if (bias_pre) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias_v[j] = bias_pre[j];
+    } else {
+        load_bias<EPI>(a, n0, wave_n, lane, bias_v);
+    }
     if constexpr (EPI == EPI_VT) {
         // natural order: lane = column n, registers = 4 consecutive rows (tokens)
         float bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wave_n * 64 + j * 16 + lr;
-            bv[j] = n < a.N ? a.bias[n] : 0.f;
-        }
+        for (int j = 0; j < 4; ++j) bv[j] = bias_v[j][0];
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
             const int m = m0 + wave_m * (MR * 16) + i * 16 + 4 * lq;
@@ -147,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
         for (int j = 0; j < 4; ++j) {
             nc[j] = n0 + wave_n * 64 + j * 16 + 4 * lq;
             nv[j] = nc[j] < a.N;
-            bv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.bias + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[j] = bias_v[j];
         }
         if constexpr (EPI == EPI_RESID) {
             // read-modify-write of the fp32 residual stream: RB x 4 loads of 16 B per lane in flight before the
@@ -227,7 +251,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 // Wave-private image: no workgroup barrier, LDS operations of one wave execute in order.
 template <int EPI, int MR, bool F16>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                                     int lane, char* region) {
+                                                     int lane, char* region, const f32x4* bias_pre = nullptr) {
+    f32x4 bias_v[4];
+    if (bias_pre) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias_v[j] = bias_pre[j];
+    } else {
+        load_bias<EPI>(a, n0, wave_n, lane, bias_v);
+    }
     static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK, "staged epilogue: half-precision outputs only");
     const int lr = lane & 15, lq = lane >> 4;
     const int ncol0 = n0 + wave_n * 64;
@@ -237,10 +268,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         // acc[i][j][e] = (token mrow0 + 16 i + 4 lq + e, column ncol0 + 16 j + lr); image [64 columns][128 B = 64 tokens]
         float bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol0 + j * 16 + lr;
-            bv[j] = n < a.N ? a.bias[n] : 0.f;
-        }
+        for (int j = 0; j < 4; ++j) bv[j] = bias_v[j][0];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (pass) __builtin_amdgcn_wave_barrier();
@@ -276,10 +304,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         // acc[i][j][e] = (row mrow0 + 16 i + lr, column ncol0 + 16 j + 4 lq + e); image [64 rows][128 B = 64 columns]
         f32x4 bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nc = ncol0 + j * 16 + 4 * lq;
-            bv[j] = nc < a.N ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < 4; ++j) bv[j] = bias_v[j];
         const int which = (EPI == EPI_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
         const float sc = (EPI == EPI_QK && !which) ? a.qscale : 1.0f;
         const bool nvl = ncol0 + lc * 8 < a.N;
@@ -289,6 +314,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         if constexpr (EPI == EPI_QK) {
             qk_base = which ? a.out2_bf16 : a.out_bf16;
             head = (ncol0 - which * a.dim) >> 6;
+        }
+        // (image, token) of this lane's first output row; later rows advance by 8 without dividing again
+        int qb = 0, qt = 0;
+        if constexpr (EPI == EPI_QK) {
+            qb = (mrow0 + lrow) / a.tokens;
+            qt = (mrow0 + lrow) - qb * a.tokens;
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -318,12 +349,19 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                 const int row = r8 * 8 + lrow;
                 const int m = mrow0 + pass * 64 + row;
                 const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+                const int qb_now = qb, qt_now = qt;
+                if constexpr (EPI == EPI_QK) {
+                    qt += 8;
+                    while (qt >= a.tokens) {      // at most once unless an image has fewer than 8 tokens
+                        qt -= a.tokens;
+                        ++qb;
+                    }
+                }
                 if (pass * 64 + row >= MR * 16 || m >= a.M || !nvl) continue;
                 if constexpr (EPI == EPI_GELU) {
                     *reinterpret_cast<uint4*>(a.out_bf16 + (size_t)m * ld + ncol0 + lc * 8) = v;
                 } else {
-                    const int b = m / a.tokens, t = m - b * a.tokens;
-                    *reinterpret_cast<uint4*>(qk_base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + lc * 8) = v;
+                    *reinterpret_cast<uint4*>(qk_base + ((size_t)(qb_now * a.heads + head) * a.tokens_pad + qt_now) * 64 + lc * 8) = v;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -576,6 +614,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         // Every wave is past its last fragment read and no LDS-DMA is in flight.  Stage (par + nt) & 1 (last
         // read in K-tile nt - 2) receives K-tile 0 of this workgroup's next tile now, so that its HBM
         // latency is covered by the epilogue; the stage of the last K-tile is the epilogue's scratch.
+        f32x4 bias_pre[4];
+        load_bias<EPI>(a, n0, wave_n, lane, bias_pre);      // in flight while the next prologue is issued
         const int next = tile + gridDim.x;
         const bool has_next = next < nwg;
         int m0n = 0, n0n = 0;
@@ -594,11 +634,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                                             : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
             if (ok) {
                 gemm_epilogue_staged<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane,
-                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192);
+                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192, bias_pre);
                 staged = true;
             }
         }
-        if (!staged) gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane);
+        if (!staged) gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre);
         PPSTAMP(5);
         ++stamp_tile;
         if (!has_next) break;
