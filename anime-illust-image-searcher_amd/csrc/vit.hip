@@ -108,6 +108,7 @@ struct hipts_vit {
     DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs;
     int pool_splits = 1;
     static constexpr int kMaxSub = 4;
+    int want_sub = 0;                             // hipts_vit_set_sub_batches; 0 = default
     hipStream_t sub[kMaxSub] = {};                // internal streams of the sub-batches
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
 };
@@ -779,7 +780,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     // Two half-batches on two internal streams: a GEMM grid's partial last round, an epilogue that is
     // waiting on HBM and every kernel boundary of one half are filled with work of the other half.
     static const int want_streams = getenv("HIPTS_VIT_STREAMS") ? atoi(getenv("HIPTS_VIT_STREAMS")) : 2;
-    const int ns = std::min({want_streams, (int)hipts_vit::kMaxSub, batch / 8});
+    const int ns = std::min({h->want_sub > 0 ? h->want_sub : want_streams, (int)hipts_vit::kMaxSub, batch / 8});
     if (ns >= 2) {
         if (!h->ev_fork) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < ns; ++i)
@@ -810,6 +811,13 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
 }  // namespace
 
 extern "C" {
+
+int hipts_vit_set_sub_batches(hipts_vit_t* h, int n) {
+    HIPTS_REQUIRE(h, "null handle");
+    HIPTS_REQUIRE(n >= 0 && n <= hipts_vit::kMaxSub, "hipts_vit_set_sub_batches: n must be 0 .. %d", (int)hipts_vit::kMaxSub);
+    h->want_sub = n;
+    return HIPTS_OK;
+}
 
 int hipts_vit_profile_enable(hipts_vit_t* h, int enable) {
     HIPTS_REQUIRE(h, "null handle");

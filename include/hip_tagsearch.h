@@ -99,6 +99,12 @@ int hipts_vit_profile_enable(hipts_vit_t* h, int enable);
 int hipts_vit_profile_read(hipts_vit_t* h, int category, double* total_ms, int64_t* launches,
                            double* total_flops, double* total_bytes);
 int hipts_vit_profile_name(int category, char* buf, size_t n);
+/* How many sub-batches a forward() call is split into, each on its own internal HIP stream (forked from
+ * and joined to the caller's stream with events): 0 = default (2, or HIPTS_VIT_STREAMS), 1 = the whole
+ * batch as one sequence of launches on the caller's stream, up to 4.  A kernel of one sub-batch then
+ * fills the partial last round and the epilogue bubbles of the other's.  Results do not depend on it
+ * (every image is computed by the same instruction sequence). */
+int hipts_vit_set_sub_batches(hipts_vit_t* h, int n);
 /* algorithmic FLOPs of one image's forward (2*M*N*K of every contraction), for roofline use */
 int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops);
 
