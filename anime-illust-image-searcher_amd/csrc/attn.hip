@@ -23,12 +23,16 @@ namespace hipts {
 namespace {
 
 constexpr int KV = 64;               // keys per tile
-constexpr int KS = 144;              // LDS bytes per K row   (64 d  * 2 B + 16)
 constexpr int VS = 136;              // LDS bytes per V^T row (64 key* 2 B + 8)
-constexpr int K_BYTES = KV * KS;     // 9216
-constexpr int V_BYTES = 64 * VS;     // 8704
-constexpr int V_BASE = 2 * K_BYTES;  // LDS: two K slots, then three V^T slots
-constexpr int LDS_BYTES = 2 * K_BYTES + 3 * V_BYTES;   // 44.5 KB: three workgroups per CU
+// head_dim HD = 64 (ViT) or 32 (CAFormer): K rows are HD * 2 B + 16 (144 / 80 B: both conflict free for the
+// b128 fragment reads), the V^T tile has HD rows.
+template <int HD> struct Geo {
+    static constexpr int KS = HD * 2 + 16;          // LDS bytes per K row
+    static constexpr int K_BYTES = KV * KS;         // 9216 / 5120
+    static constexpr int V_BYTES = HD * VS;         // 8704 / 4352
+    static constexpr int V_BASE = 2 * K_BYTES;      // LDS: two K slots, then three V^T slots
+    static constexpr int LDS_BYTES = 2 * K_BYTES + 3 * V_BYTES;   // 44.5 KB (HD 64): three workgroups per CU
+};
 
 // Written with plain fmaxf so the compiler sees the MFMA -> VALU dependency and inserts the required
 // wait states itself.  (An inline-asm v_max3_f32 here read accumulator registers before the MFMA had
@@ -46,9 +50,10 @@ __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (re
 // softmax wants to rescale O, the P V product it must include has retired.
 // q is pre-scaled by head_dim^-0.5 * log2(e) in the QK GEMM epilogue: scores are in the base-2 domain.
 // MASK (last tile only): keys >= tokens start their accumulator at -inf, which the MFMA carries through.
-template <bool MASK, bool F16>
-__device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[4],
+template <bool MASK, bool F16, int HD>
+__device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[HD / 16],
                                        f32x16 (&sacc)[2]) {
+    constexpr int KS = Geo<HD>::KS;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -57,17 +62,17 @@ __device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int
             else sacc[g][i] = 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < HD / 16; ++s) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
             sacc[g] = mfma_32x32x16<F16>(kf, qf[s], sacc[g]);
         }
     }
 }
 
-template <bool F16>
-__device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int h, const bf16x8 (&pf)[2][2], f32x16 (&o)[2]) {
+template <bool F16, int HD>
+__device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int h, const bf16x8 (&pf)[2][2], f32x16 (&o)[HD / 32]) {
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
+    for (int blk = 0; blk < HD / 32; ++blk) {
         const char* vrow = vt + (blk * 32 + r) * VS;
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -85,8 +90,8 @@ __device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int 
 // (A lazy reference -- rescale O and l only when some row's tile maximum exceeds the reference by 2^8,
 // behind a wave-uniform branch -- was measured SLOWER, 217 vs 196 us: the branch stops the scheduler from
 // running this VALU work under the P V MFMAs.)
-template <bool F16>
-__device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2], float& m_run,
+template <bool F16, int HD>
+__device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[HD / 32], float& m_run,
                                              float& l_run) {
     float mx = max3f(sacc[0][0], sacc[1][0], m_run);
 #pragma unroll
@@ -106,20 +111,22 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
     m_run = m_new;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {       // O already holds every tile before this one (incl. the P V just issued)
-        o[0][i] *= alpha;
-        o[1][i] *= alpha;
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; ++blk) o[blk][i] *= alpha;
     }
 }
 
-template <bool F16>
+template <bool F16, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
                                                    int tokens, int tokens_pad, int qblocks) {
+    using G = Geo<HD>;
+    constexpr int KS = G::KS, K_BYTES = G::K_BYTES, V_BYTES = G::V_BYTES, V_BASE = G::V_BASE;
     // iteration t multiplies K(t) (slot t & 1) and V(t-1) (slot (t-1) % 3) while tile t+1 is written: K(t+1)
     // over K(t-1), V(t+1) over V(t-2), both last read before the previous barrier.  Two K and three V^T
     // slots = 44.5 KB, so three workgroups (three waves per SIMD at 148 VGPRs) share a CU and one wave's
     // softmax (VALU) runs under the others' MFMAs.
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware work id: workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
@@ -138,89 +145,98 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
 
     // Q^T fragments (B operand): lane (q = r, half h), k-step s: d = 16 s + 8 h .. + 7
-    bf16x8 qf[4];
+    bf16x8 qf[HD / 16];
     {
-        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * 64 + 8 * h;
+        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        for (int s = 0; s < HD / 16; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
 
-    // staging: K tile = 64 rows x 8 chunks of 16 B, V^T tile likewise; two chunks of each per thread
-    const int row0 = tid >> 3, col = tid & 7;            // chunk tid and tid + 256 (row + 32)
-    const bf16_t* kp = k + (size_t)bh * tokens_pad * 64 + (size_t)row0 * 64 + col * 8;
-    const bf16_t* vp = vT + (size_t)bh * 64 * tokens_pad + (size_t)row0 * tokens_pad + col * 8;
-    const size_t k_row32 = (size_t)32 * 64, v_row32 = (size_t)32 * tokens_pad;
-    const int kdst = row0 * KS + col * 16, vdst = V_BASE + row0 * VS + col * 16;
-    uint4 kreg0, kreg1, vreg0, vreg1;
-#define ATTN_LOAD(kv0)                                                                  \
-    kreg0 = *reinterpret_cast<const uint4*>(kp + (size_t)(kv0) * 64);                   \
-    kreg1 = *reinterpret_cast<const uint4*>(kp + (size_t)(kv0) * 64 + k_row32);         \
-    vreg0 = *reinterpret_cast<const uint4*>(vp + (kv0));                                \
-    vreg1 = *reinterpret_cast<const uint4*>(vp + (kv0) + v_row32);
-#define ATTN_WRITE(ks, vs)                                                                            \
-    *reinterpret_cast<uint4*>(smem + (ks) * K_BYTES + kdst) = kreg0;                                  \
-    *reinterpret_cast<uint4*>(smem + (ks) * K_BYTES + kdst + 32 * KS) = kreg1;                        \
-    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst) = make_uint2(vreg0.x, vreg0.y);           \
-    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst + 8) = make_uint2(vreg0.z, vreg0.w);       \
-    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst + 32 * VS) = make_uint2(vreg1.x, vreg1.y); \
-    *reinterpret_cast<uint2*>(smem + (vs) * V_BYTES + vdst + 32 * VS + 8) = make_uint2(vreg1.z, vreg1.w);
+    // staging: K tile = 64 rows x HD/8 chunks of 16 B, V^T tile = HD rows x 8 chunks; one (HD 32) or two (HD 64)
+    // chunks of each per thread.  Plain scalars, no arrays: a per-thread array here is "promoted" to LDS by
+    // the compiler (8 KB) and costs the third workgroup per CU.
+    constexpr int KCH = HD / 8;
+    constexpr bool TWO = HD == 64;
+    const int kc0 = tid, kc1 = tid + 256;
+    const bf16_t* kp0 = k + (size_t)bh * tokens_pad * HD + (size_t)(kc0 / KCH) * HD + (kc0 % KCH) * 8;
+    const bf16_t* kp1 = k + (size_t)bh * tokens_pad * HD + (size_t)(kc1 / KCH) * HD + (kc1 % KCH) * 8;
+    const bf16_t* vp0 = vT + (size_t)bh * HD * tokens_pad + (size_t)(kc0 >> 3) * tokens_pad + (kc0 & 7) * 8;
+    const bf16_t* vp1 = vT + (size_t)bh * HD * tokens_pad + (size_t)(kc1 >> 3) * tokens_pad + (kc1 & 7) * 8;
+    const int kdst0 = (kc0 / KCH) * KS + (kc0 % KCH) * 16, kdst1 = (kc1 / KCH) * KS + (kc1 % KCH) * 16;
+    const int vdst0 = V_BASE + (kc0 >> 3) * VS + (kc0 & 7) * 16, vdst1 = V_BASE + (kc1 >> 3) * VS + (kc1 & 7) * 16;
+    uint4 kreg0, kreg1 = {}, vreg0, vreg1 = {};
+    auto attn_load = [&](int kv0) {
+        kreg0 = *reinterpret_cast<const uint4*>(kp0 + (size_t)kv0 * HD);
+        vreg0 = *reinterpret_cast<const uint4*>(vp0 + kv0);
+        if constexpr (TWO) {
+            kreg1 = *reinterpret_cast<const uint4*>(kp1 + (size_t)kv0 * HD);
+            vreg1 = *reinterpret_cast<const uint4*>(vp1 + kv0);
+        }
+    };
+    auto attn_write = [&](int ks, int vs) {
+        *reinterpret_cast<uint4*>(smem + ks * K_BYTES + kdst0) = kreg0;
+        *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst0) = make_uint2(vreg0.x, vreg0.y);
+        *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst0 + 8) = make_uint2(vreg0.z, vreg0.w);
+        if constexpr (TWO) {
+            *reinterpret_cast<uint4*>(smem + ks * K_BYTES + kdst1) = kreg1;
+            *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst1) = make_uint2(vreg1.x, vreg1.y);
+            *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst1 + 8) = make_uint2(vreg1.z, vreg1.w);
+        }
+    };
 
-    f32x16 o[2];
+    f32x16 o[HD / 32];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        o[0][i] = 0.f;
-        o[1][i] = 0.f;
-    }
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; ++blk) o[blk][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 sacc[2];
     bf16x8 pf[2][2];
 
     const int nkv = tokens_pad / KV;
     const bool masked_tail = tokens_pad > tokens;
-    ATTN_LOAD(0)
-    ATTN_WRITE(0, 0)
+    attn_load(0);
+    attn_write(0, 0);
     __syncthreads();
     // tile 0: scores and softmax only (its P V is issued in the next iteration)
     if (nkv > 1) {
-        ATTN_LOAD(KV)
+        attn_load(KV);
     }
-    if (nkv == 1 && masked_tail) s_tile<true, F16>(smem, 0, tokens, r, h, qf, sacc);
-    else s_tile<false, F16>(smem, 0, tokens, r, h, qf, sacc);
-    softmax_tile<F16>(sacc, pf, o, m_run, l_run);
+    if (nkv == 1 && masked_tail) s_tile<true, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
+    else s_tile<false, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
+    softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
     if (nkv > 1) {
-        ATTN_WRITE(1, 1)
+        attn_write(1, 1);
     }
     __syncthreads();
     int vprev = 0, vcur = 1;                  // V^T slot of tile t-1 / of tile t
     for (int t = 1; t < nkv; ++t) {
         const int vnxt = vcur == 2 ? 0 : vcur + 1;
         if (t + 1 < nkv) {
-            ATTN_LOAD((t + 1) * KV)
+            attn_load((t + 1) * KV);
         }
         const char* kt = smem + (t & 1) * K_BYTES;
-        if (t + 1 == nkv && masked_tail) s_tile<true, F16>(kt, t * KV, tokens, r, h, qf, sacc);
-        else s_tile<false, F16>(kt, t * KV, tokens, r, h, qf, sacc);
-        pv_tile<F16>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
-        softmax_tile<F16>(sacc, pf, o, m_run, l_run);
+        if (t + 1 == nkv && masked_tail) s_tile<true, F16, HD>(kt, t * KV, tokens, r, h, qf, sacc);
+        else s_tile<false, F16, HD>(kt, t * KV, tokens, r, h, qf, sacc);
+        pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+        softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
         if (t + 1 < nkv) {
-            ATTN_WRITE((t + 1) & 1, vnxt)
+            attn_write((t + 1) & 1, vnxt);
         }
         __syncthreads();
         vprev = vcur;
         vcur = vnxt;
     }
-    pv_tile<F16>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
-#undef ATTN_LOAD
-#undef ATTN_WRITE
+    pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
 
-    // ---- normalise and store: out[(b*tokens + q)][head*64 + d], 4 consecutive d per register group
+    // ---- normalise and store: out[(b*tokens + q)][head*HD + d], 4 consecutive d per register group
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + r;
     if (qi < tokens) {
-        bf16_t* op = out + ((size_t)b * tokens + qi) * (heads * 64) + head * 64;
+        bf16_t* op = out + ((size_t)b * tokens + qi) * (heads * HD) + head * HD;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < HD / 32; ++blk)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) =
@@ -232,12 +248,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
 }  // namespace
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
-                     int tokens_pad, bool f16, hipStream_t s) {
+                     int tokens_pad, bool f16, hipStream_t s, int head_dim) {
     HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens, "attention: tokens_pad must be a multiple of %d", KV);
+    HIPTS_REQUIRE(head_dim == 64 || head_dim == 32, "attention: head_dim must be 64 or 32");
     const int qtiles = (tokens + 31) / 32;
     const int qblocks = (qtiles + 3) / 4;
-    if (f16) attn_kernel<true><<<batch * heads * qblocks, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
-    else attn_kernel<false><<<batch * heads * qblocks, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+    const int grid = batch * heads * qblocks;
+    if (head_dim == 64) {
+        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+    } else {
+        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+    }
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }

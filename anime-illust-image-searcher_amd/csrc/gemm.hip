@@ -108,6 +108,12 @@ __device__ __forceinline__ void load_bias(const GemmArgs& a, int n0, int wave_n,
     }
 }
 
+// StarReLU (MetaFormer): s * relu(x)^2 + b with scalar s, b.
+__device__ __forceinline__ f32x4 star_relu4(f32x4 x, float s, float b) {
+    const f32x4 r = __builtin_elementwise_max(x, f32x4{0.f, 0.f, 0.f, 0.f});
+    return r * r * s + b;
+}
+
 // Epilogue shared by both main-loop variants.  acc[i][j]: 16 x 16 tile (i: 16-row block of the
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
@@ -139,9 +145,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 const int n = n0 + wave_n * 64 + j * 16 + lr;
                 if (n >= a.N) continue;
                 const f32x4 c = acc[i][j];
-                const int head = n >> 6, d = n & 63;
+                const int head = n >> a.hd_log2, d = n & ((1 << a.hd_log2) - 1);
                 const bf16x4 o = pack4<F16>(c[0] + bv[j], c[1] + bv[j], c[2] + bv[j], c[3] + bv[j]);
-                *reinterpret_cast<bf16x4*>(a.out_bf16 + ((size_t)(b * a.heads + head) * 64 + d) * a.tokens_pad + t) = o;
+                *reinterpret_cast<bf16x4*>(a.out_bf16 + ((((size_t)(b * a.heads + head)) << a.hd_log2) + d) * a.tokens_pad + t) = o;
             }
         }
     } else if constexpr (EPI == EPI_HEAD) {
@@ -173,7 +179,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             nv[j] = nc[j] < a.N;
             bv[j] = bias_v[j];
         }
-        if constexpr (EPI == EPI_RESID) {
+        if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE) {
+            f32x4 rs[4];
+            if constexpr (EPI == EPI_RESCALE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.res_scale + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             // read-modify-write of the fp32 residual stream: RB x 4 loads of 16 B per lane in flight before the
             // first dependent add (RB 16-row blocks; the fragment registers of the main loop are free here),
             // so a CU keeps RB x 32 KB outstanding -- the epilogue is bound by HBM latency x bytes in flight.
@@ -196,8 +207,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     if (m >= a.M) continue;
                     float* row = a.out_f32 + (size_t)m * ld;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (nv[j]) *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + (acc[i2 + u][j] + bv[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (!nv[j]) continue;
+                        if constexpr (EPI == EPI_RESCALE)
+                            *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] * rs[j] + (acc[i2 + u][j] + bv[j]);
+                        else
+                            *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + (acc[i2 + u][j] + bv[j]);
+                    }
                 }
             }
             return;
@@ -215,6 +231,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (nv[j]) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] * a.qscale + bv[j] + pv[j];
+            } else if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (nv[j]) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] + bv[j];
+            } else if constexpr (EPI == EPI_STAR) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!nv[j]) continue;
+                    const f32x4 v = star_relu4(acc[i][j] + bv[j], a.star_scale, a.star_bias);
+                    *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = pack4<F16>(v[0], v[1], v[2], v[3]);
+                }
             } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -231,12 +258,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     if (!nv[j]) continue;
                     const int which = nc[j] >= a.dim ? 1 : 0;
                     const int nn = nc[j] - which * a.dim;
-                    const int head = nn >> 6, d = nn & 63;
+                    const int head = nn >> a.hd_log2, d = nn & ((1 << a.hd_log2) - 1);
                     const float sc = which ? 1.0f : a.qscale;
                     const f32x4 v = acc[i][j] + bv[j];
                     const bf16x4 o = pack4<F16>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
                     bf16_t* base = which ? a.out2_bf16 : a.out_bf16;
-                    *reinterpret_cast<bf16x4*>(base + ((size_t)(b * a.heads + head) * a.tokens_pad + t) * 64 + d) = o;
+                    *reinterpret_cast<bf16x4*>(base + ((((size_t)(b * a.heads + head) * a.tokens_pad + t)) << a.hd_log2) + d) = o;
                 }
             }
         }
@@ -259,7 +286,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
     } else {
         load_bias<EPI>(a, n0, wave_n, lane, bias_v);
     }
-    static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK, "staged epilogue: half-precision outputs only");
+    static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK, "staged epilogue: half-precision outputs only");
     const int lr = lane & 15, lq = lane >> 4;
     const int ncol0 = n0 + wave_n * 64;
     const int mrow0 = m0 + wave_m * (MR * 16);
@@ -296,7 +323,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                 const int n = ncol0 + d;
                 const uint4 v = *reinterpret_cast<const uint4*>(region + d * 128 + ((lc ^ ((d >> 1) & 7)) * 16));
                 if (mv && n < a.N)
-                    *reinterpret_cast<uint4*>(a.out_bf16 + ((size_t)(b * a.heads + (n >> 6)) * 64 + (n & 63)) * a.tokens_pad + t) = v;
+                    *reinterpret_cast<uint4*>(a.out_bf16 +
+                                              ((((size_t)(b * a.heads + (n >> a.hd_log2))) << a.hd_log2) + (n & ((1 << a.hd_log2) - 1))) * a.tokens_pad + t) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
@@ -310,10 +338,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         const bool nvl = ncol0 + lc * 8 < a.N;
         const int ld = a.ld_out ? a.ld_out : a.N;
         bf16_t* qk_base = nullptr;
-        int head = 0;
+        int head = 0, hd_off = 0;          // this lane's 8 columns: head and offset inside the head
         if constexpr (EPI == EPI_QK) {
             qk_base = which ? a.out2_bf16 : a.out_bf16;
-            head = (ncol0 - which * a.dim) >> 6;
+            const int col = ncol0 - which * a.dim + lc * 8;
+            head = col >> a.hd_log2;
+            hd_off = col & ((1 << a.hd_log2) - 1);
         }
         // (image, token) of this lane's first output row; later rows advance by 8 without dividing again
         int qb = 0, qt = 0;
@@ -337,6 +367,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                     if constexpr (EPI == EPI_GELU) {
                         const f32x4 gv = gelu_f4(v, a.gelu_tanh);
                         o = pack4<F16>(gv[0], gv[1], gv[2], gv[3]);
+                    } else if constexpr (EPI == EPI_STAR) {
+                        const f32x4 gv = star_relu4(v, a.star_scale, a.star_bias);
+                        o = pack4<F16>(gv[0], gv[1], gv[2], gv[3]);
                     } else
                         o = pack4<F16>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
                     *reinterpret_cast<bf16x4*>(region + row * 128 + pc * 16 + (lq & 1) * 8) = o;
@@ -358,10 +391,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                     }
                 }
                 if (pass * 64 + row >= MR * 16 || m >= a.M || !nvl) continue;
-                if constexpr (EPI == EPI_GELU) {
+                if constexpr (EPI == EPI_GELU || EPI == EPI_STAR) {
                     *reinterpret_cast<uint4*>(a.out_bf16 + (size_t)m * ld + ncol0 + lc * 8) = v;
                 } else {
-                    *reinterpret_cast<uint4*>(qk_base + ((size_t)(qb_now * a.heads + head) * a.tokens_pad + qt_now) * 64 + lc * 8) = v;
+                    *reinterpret_cast<uint4*>(qk_base + ((((size_t)(qb_now * a.heads + head) * a.tokens_pad + qt_now)) << a.hd_log2) + hd_off) = v;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -628,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         }
         PPSTAMP(4);
         bool staged = false;
-        if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK) {
+        if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK) {
             const bool ok = EPI == EPI_VT   ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
                             : EPI == EPI_QK ? (a.dim % 64 == 0)
                                             : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
@@ -1068,7 +1101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmArgs a, int t
         a.stamps[wave * 64 + 3] = wall_clock64() - wall_t0;
     }
     __builtin_amdgcn_s_barrier();       // every wave is past its last fragment read; all loads have landed
-    if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_QK) {
+    if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK) {
         const bool ok = EPI == EPI_VT   ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
                         : EPI == EPI_QK ? (a.dim % 64 == 0)
                                         : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
@@ -1178,6 +1211,8 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     HIPTS_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
     if (epi != EPI_HEAD) HIPTS_REQUIRE(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);
     if (epi == EPI_VT) HIPTS_REQUIRE(a.M % 4 == 0 && a.tokens % 4 == 0, "gemm: V^T epilogue needs tokens %% 4 == 0");
+    if (epi == EPI_QK || epi == EPI_VT) HIPTS_REQUIRE(a.hd_log2 == 5 || a.hd_log2 == 6, "gemm: head_dim must be 32 or 64");
+    if (epi == EPI_RESCALE) HIPTS_REQUIRE(a.res_scale != nullptr, "gemm: RESCALE epilogue needs res_scale");
     switch (epi) {
         case EPI_PATCH: return launch_t<EPI_PATCH>(a, s);
         case EPI_QK: return launch_t<EPI_QK>(a, s);
@@ -1185,6 +1220,9 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
         case EPI_RESID: return launch_t<EPI_RESID>(a, s);
         case EPI_GELU: return launch_t<EPI_GELU>(a, s);
         case EPI_HEAD: return launch_t<EPI_HEAD>(a, s);
+        case EPI_STAR: return launch_t<EPI_STAR>(a, s);
+        case EPI_RESCALE: return launch_t<EPI_RESCALE>(a, s);
+        case EPI_BIAS: return launch_t<EPI_BIAS>(a, s);
     }
     return set_error(HIPTS_ERR_INVALID, "gemm: unknown epilogue");
 }

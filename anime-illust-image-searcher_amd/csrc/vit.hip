@@ -27,52 +27,6 @@ struct Layer {
     DevBuf qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b;
 };
 
-inline uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-
-// float -> IEEE half bits, round to nearest even (subnormals kept)
-inline uint16_t f32_to_f16_rne(float f) {
-    uint32_t x;
-    memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    x &= 0x7fffffffu;
-    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
-    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                     // rounds to >= 65520 -> inf
-    if (x < 0x38800000u) {                                                       // below the smallest normal half
-        if (x < 0x33000000u) return (uint16_t)sign;                              // < 2^-25 -> 0
-        const int shift = 126 - (int)(x >> 23);                                  // 14..24: value = mant24 * 2^-24 >> shift
-        uint32_t mant = (x & 0x7fffffu) | 0x800000u;
-        const uint32_t round = (1u << (shift - 1)) - 1 + ((mant >> shift) & 1u);
-        mant += round;
-        return (uint16_t)(sign | (mant >> shift));
-    }
-    const uint32_t round = 0xfffu + ((x >> 13) & 1u);
-    x += round;
-    return (uint16_t)(sign | ((x - 0x38000000u) >> 13));
-}
-inline float f16_bits_to_f32(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, out;
-    if (e == 0) {
-        if (m == 0) out = sign;
-        else {
-            int sh = 0;
-            while (!(m & 0x400u)) { m <<= 1; ++sh; }
-            out = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
-        }
-    } else if (e == 31) out = sign | 0x7f800000u | (m << 13);
-    else out = sign | ((e + 112) << 23) | (m << 13);
-    float f;
-    memcpy(&f, &out, 4);
-    return f;
-}
-
-inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
@@ -224,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
         if (c < nvec) {
-            const float4 gg = gr[c], bb = br[c];
+            const float4 gg = gr[c], bb = bta ? br[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<bf16x4*>(out + row * D + 4 * c) =
                 pack4<F16>((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
                            (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
@@ -809,6 +763,18 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
 }
 
 }  // namespace
+
+namespace hipts {
+int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,
+                     hipStream_t s) {
+    HIPTS_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d must be a multiple of 4, at most 1024", D);
+    const int blocks = (int)((rows + 3) / 4);
+    if (f16) layernorm_kernel<true><<<blocks, 256, 0, s>>>(x, g, b, out, rows, D, eps);
+    else layernorm_kernel<false><<<blocks, 256, 0, s>>>(x, g, b, out, rows, D, eps);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+}  // namespace hipts
 
 extern "C" {
 

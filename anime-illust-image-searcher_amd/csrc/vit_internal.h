@@ -1,5 +1,8 @@
 // vit_internal.h -- shared declarations of the ViT forward kernels (gemm.hip, attn.hip, vit.hip).
 #pragma once
+#include <cstring>
+#include <vector>
+
 #include "common.h"
 
 namespace hipts {
@@ -48,6 +51,63 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- host-side operand conversion (weights are converted once at upload) ----
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// float -> IEEE half bits, round to nearest even (subnormals kept)
+inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                     // rounds to >= 65520 -> inf
+    if (x < 0x38800000u) {                                                       // below the smallest normal half
+        if (x < 0x33000000u) return (uint16_t)sign;                              // < 2^-25 -> 0
+        const int shift = 126 - (int)(x >> 23);                                  // 14..24: value = mant24 * 2^-24 >> shift
+        uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t round = (1u << (shift - 1)) - 1 + ((mant >> shift) & 1u);
+        mant += round;
+        return (uint16_t)(sign | (mant >> shift));
+    }
+    const uint32_t round = 0xfffu + ((x >> 13) & 1u);
+    x += round;
+    return (uint16_t)(sign | ((x - 0x38000000u) >> 13));
+}
+inline float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, out;
+    if (e == 0) {
+        if (m == 0) out = sign;
+        else {
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            out = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) out = sign | 0x7f800000u | (m << 13);
+    else out = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &out, 4);
+    return f;
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// rows x cols float matrix -> bf16 / half bits, zero padded to rows_pad rows, uploaded into buf
+inline int upload_matrix16(DevBuf& buf, const float* data, int rows, int cols, int rows_pad, bool f16) {
+    std::vector<uint16_t> h((size_t)rows_pad * cols, 0);
+    if (f16) for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_f16_rne(data[i]);
+    else for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_bf16_rne(data[i]);
+    HIPTS_TRY(buf.alloc(h.size() * 2));
+    return upload(buf.p, h.data(), h.size() * 2);
+}
+
 // GEMM  C[M,N] = A[M,K] (bf16, row-major) x W[N,K]^T (bf16, row-major: torch Linear layout), fp32
 // accumulate on MFMA, fused epilogue.  K % 64 == 0; W must be allocated (zero padded) up to a
 // multiple of 256 rows; A rows beyond M are never read (row index clamped), stores are masked.
@@ -57,7 +117,11 @@ enum GemmEpilogue {
     EPI_VT = 2,      // vT[b][h][d][t] = bf16(acc + bias[dim2 + n])                      (n in [0, dim))
     EPI_RESID = 3,   // x[m][n] += acc + bias[n]                                        (fp32 in/out)
     EPI_GELU = 4,    // out[m][n] = bf16(gelu(acc + bias[n]))
-    EPI_HEAD = 5     // logits[m][n] = acc + bias[n]; probs[m][n] = sigmoid(logits)     (fp32 out, n < N)
+    EPI_HEAD = 5,    // logits[m][n] = acc + bias[n]; probs[m][n] = sigmoid(logits)     (fp32 out, n < N)
+    // MetaFormer (CCIP encoder) epilogues
+    EPI_STAR = 6,    // out[m][n] = bf16(star_scale * relu(acc + bias[n])^2 + star_bias)  (StarReLU)
+    EPI_RESCALE = 7, // x[m][n] = x[m][n] * res_scale[n] + acc + bias[n]                (fp32 in/out)
+    EPI_BIAS = 8     // x[m][n] = acc + bias[n]                                         (fp32 out)
 };
 
 struct GemmArgs {
@@ -74,6 +138,9 @@ struct GemmArgs {
     int tokens = 0;                 // tokens per image (PATCH, QK, VT)
     int tokens_pad = 0;             // padded token count of the q/k/vT layouts
     int heads = 0, dim = 0;         // QK / VT
+    int hd_log2 = 6;                // QK / VT: log2(head_dim), 6 (ViT) or 5 (CAFormer)
+    const float* res_scale = nullptr;   // RESCALE: per-column scale of the residual
+    float star_scale = 1.0f, star_bias = 0.0f;   // STAR
     float qscale = 1.0f;
     int gelu_tanh = 1;
     int ld_out = 0;                 // row stride of out (elements); 0 = N
@@ -88,6 +155,10 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 // softmax(Q K^T) V for every (image, head): q,k [B*H][tokens_pad][64] bf16 (q pre-scaled by
 // head_dim^-0.5), vT [B*H][64][tokens_pad] bf16, out [B*tokens][H*64] bf16.
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
-                     int tokens_pad, bool f16, hipStream_t s);
+                     int tokens_pad, bool f16, hipStream_t s, int head_dim = 64);
+
+// out[row][:] = bf16((x[row][:] - mean) * rstd * g + b)  (b may be null: bias-free LayerNorm); D % 4 == 0, D <= 1024
+int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,
+                     hipStream_t s);
 
 }  // namespace hipts
