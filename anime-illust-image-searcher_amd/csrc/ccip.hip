@@ -1,0 +1,607 @@
+// ccip.hip -- CCIP character-feature encoder (gen_cfeatures.py:112-118,133-159): a CAFormer (timm
+// MetaFormer) forward behind hipts_ccip_*.
+//
+// Reference call being replaced: `self.embed_model.run(['output'], {'input': x})` with x float32
+// [B,3,384,384] (gen_cfeatures.py:158).  The ONNX graph itself is not in /root/reference; the layer
+// algebra below is timm 1.0.9 `models/metaformer.py` -- see oracle/ccip.py, which
+// restates the same definition on the CPU and is what the parity tests compare against.
+//
+// Data layout: activations are token-major NHWC throughout -- the residual stream x is float32
+// [B*H*W][C], GEMM operands are bf16 [rows][K] -- so every 1x1 convolution / Linear is the same
+// persistent MFMA GEMM as in the ViT (gemm.hip) with a fused epilogue:
+//   pwconv1 / fc1      -> EPI_STAR     bf16(s * relu(.)^2 + b)        (StarReLU)
+//   pwconv2 / fc2 / proj -> EPI_RESID / EPI_RESCALE   x = rs * x + .  (float32 read-modify-write)
+//   qkv                -> EPI_QK + EPI_VT with head_dim 32 layouts, then attn.hip<HD = 32>
+//   stem 7x7 s4, downsample 3x3 s2 -> im2col kernel + GEMM with EPI_BIAS
+// The stem's patch matrix is stored as bf16 hi | lo halves against [W | W] (K = 2 * 160), so the
+// normalised pixels enter the MFMA with 16 mantissa bits (same device as the ViT float input path).
+// Memory-bound pieces are plain HIP kernels here: depthwise 7x7 (NHWC, 8 channels = 16 B per thread),
+// im2col gathers, bias-free LayerNorm, pooled LayerNorm head.
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "vit_internal.h"
+
+using namespace hipts;
+
+namespace {
+
+struct Block {
+    bool attn = false;
+    DevBuf n1, n2;                 // LayerNorm gammas (no beta)
+    DevBuf w_in, w_out;            // SepConv: pwconv1 [2C,C], pwconv2 [C,2C]; attention: qkv [3C,C], proj [C,C]
+    DevBuf dw;                     // SepConv: depthwise weights as [49][2C] float32
+    DevBuf fc1, fc2;               // [4C,C], [C,4C]
+    DevBuf rs1, rs2;               // optional res_scale vectors
+    bool has_rs1 = false, has_rs2 = false;
+    float s1 = 1.f, b1 = 0.f;      // token-mixer StarReLU
+    float s2 = 1.f, b2 = 0.f;      // MLP StarReLU
+};
+
+struct Stage {
+    int C = 0, H = 0, T = 0, Tp = 0;       // width, spatial side, tokens = H*H, padded tokens
+    DevBuf ds_norm, ds_w, ds_b;            // downsample (stage > 0): LN gamma [Cprev], conv as [C][9*Cprev], bias [C]
+    std::vector<Block> blocks;
+};
+
+constexpr int STEM_KH = 160;               // 7*7*3 = 147 taps padded to 160; K = hi | lo = 320
+constexpr int STEM_K = 2 * STEM_KH;
+
+}  // namespace
+
+struct hipts_ccip {
+    int device = 0;
+    hipts_ccip_config_t cfg{};
+    Stage st[4];
+    DevBuf stem_w, stem_b, stem_norm, head_g, head_b, zeros;
+    std::vector<std::string> missing;
+    // workspace (sized for cfg.max_batch)
+    DevBuf img_in, a0, x, xn, h1, h2, m1, col, q, k, vT, feat;
+    double flops_per_image = 0.0;
+};
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem patch matrix.  A0[m][(ky*7 + kx)*3 + c] = hi, A0[m][160 + ...] = lo of the normalised pixel at
+// (4 oy - 2 + ky, 4 ox - 2 + kx), zero outside the image (Conv2d padding = 2 pads the NORMALISED input).
+// U8: images uint8 NHWC RGB; /255 in float32, (x - mean) / std in float64, cast (gen_cfeatures.py:100-110,156).
+// One thread per (token, ky): 21 values.
+// ---------------------------------------------------------------------------------------------
+template <bool U8, bool F16>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict__ img, bf16_t* __restrict__ a0, int batch, int S,
+                                                          int H0) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * H0 * H0 * 7;
+    if (idx >= total) return;
+    const int ky = (int)(idx % 7);
+    const int64_t m = idx / 7;
+    const int ox = (int)(m % H0), oy = (int)((m / H0) % H0), b = (int)(m / ((int64_t)H0 * H0));
+    const int iy = 4 * oy - 2 + ky;
+    bf16_t* row = a0 + m * STEM_K + ky * 21;
+    const double mean[3] = {0.48145466, 0.4578275, 0.40821073}, stdv[3] = {0.26862954, 0.26130258, 0.27577711};
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+        const int ix = 4 * ox - 2 + kx;
+        const bool in = iy >= 0 && iy < S && ix >= 0 && ix < S;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = 0.f;
+            if (in) {
+                if constexpr (U8) {
+                    const uint8_t u = reinterpret_cast<const uint8_t*>(img)[(((int64_t)b * S + iy) * S + ix) * 3 + c];
+                    v = (float)(((double)((float)u / 255.0f) - mean[c]) / stdv[c]);
+                } else {
+                    v = reinterpret_cast<const float*>(img)[(((int64_t)b * 3 + c) * S + iy) * S + ix];
+                }
+            }
+            const float hi = from_op<F16>(to_op<F16>(v));
+            row[kx * 3 + c] = to_op<F16>(v);
+            row[STEM_KH + kx * 3 + c] = to_op<F16>(v - hi);
+        }
+    }
+}
+
+// Bias-free LayerNorm of float32 rows, in place (the stem's norm: its output IS the residual stream).
+__global__ __launch_bounds__(256) void ln_inplace_kernel(float* __restrict__ x, const float* __restrict__ g, int64_t rows, int D,
+                                                         float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = D >> 2;
+    float4* xr = reinterpret_cast<float4*>(x + row * D);
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum_f(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < nvec) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + b * b) + (c * c + d * d);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum_f(ss) / (float)D + eps);
+    const float4* gr = reinterpret_cast<const float4*>(g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            const float4 gg = gr[c];
+            xr[c] = make_float4((v[i].x - mean) * rstd * gg.x, (v[i].y - mean) * rstd * gg.y, (v[i].z - mean) * rstd * gg.z,
+                                (v[i].w - mean) * rstd * gg.w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise 7x7, padding 3, NHWC: out[b][y][x][c] = sum_{ky,kx} in[b][y+ky-3][x+kx-3][c] * w[ky*7+kx][c].
+// One thread = one pixel x 8 channels (one 16 B load per tap, coalesced along the channel axis; the 49
+// neighbours of adjacent pixels overlap, so the tile is served from L1 / L2).  float32 accumulation.
+// HBM-bound by design: algorithmic traffic = read + write of the [B,H,W,C] tensor once.
+// ---------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void dwconv7_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
+                                                      bf16_t* __restrict__ out, int batch, int H, int C) {
+    const int cg = C >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * H * H * cg;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const int64_t p = idx / cg;
+    const int x = (int)(p % H), y = (int)((p / H) % H);
+    const int64_t img0 = (p / ((int64_t)H * H)) * H * H;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+        const int iy = y + ky - 3;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = x + kx - 3;
+            if (ix < 0 || ix >= H) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + ((img0 + (int64_t)iy * H + ix) * C + g * 8));
+            const float4 w0 = *reinterpret_cast<const float4*>(w + (ky * 7 + kx) * C + g * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(w + (ky * 7 + kx) * C + g * 8 + 4);
+            acc[0] = fmaf(from_op<F16>(v[0]), w0.x, acc[0]);
+            acc[1] = fmaf(from_op<F16>(v[1]), w0.y, acc[1]);
+            acc[2] = fmaf(from_op<F16>(v[2]), w0.z, acc[2]);
+            acc[3] = fmaf(from_op<F16>(v[3]), w0.w, acc[3]);
+            acc[4] = fmaf(from_op<F16>(v[4]), w1.x, acc[4]);
+            acc[5] = fmaf(from_op<F16>(v[5]), w1.y, acc[5]);
+            acc[6] = fmaf(from_op<F16>(v[6]), w1.z, acc[6]);
+            acc[7] = fmaf(from_op<F16>(v[7]), w1.w, acc[7]);
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = to_op<F16>(acc[e]);
+    *reinterpret_cast<bf16x8*>(out + (p * C + g * 8)) = o;
+}
+
+// Downsampling patch matrix: col[m'][(ky*3 + kx)*C + c] = xn[b][2 oy - 1 + ky][2 ox - 1 + kx][c] (zero outside).
+// One thread = one 16 B chunk.
+__global__ __launch_bounds__(256) void ds_im2col_kernel(const bf16_t* __restrict__ xn, bf16_t* __restrict__ col, int batch, int H,
+                                                        int C) {
+    const int Ho = H >> 1, cg = C >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * Ho * Ho * 9 * cg;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const int tap = (int)((idx / cg) % 9);
+    const int64_t m = idx / ((int64_t)cg * 9);
+    const int ox = (int)(m % Ho), oy = (int)((m / Ho) % Ho);
+    const int64_t b = m / ((int64_t)Ho * Ho);
+    const int iy = 2 * oy - 1 + tap / 3, ix = 2 * ox - 1 + tap % 3;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < H) v = *reinterpret_cast<const uint4*>(xn + (((b * H + iy) * H + ix) * C + g * 8));
+    *reinterpret_cast<uint4*>(col + (m * 9 + tap) * C + g * 8) = v;
+}
+
+// Head: out[b][:] = LN(mean over the T tokens of x[b])  (with bias).  One workgroup per image.
+__global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ bta, float* __restrict__ out, int T, int C, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (int64_t)b * T * C;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < T; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            if (c < C) m[u] += xb[(int64_t)r * C + c];
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        m[u] /= (float)T;
+        if (tid + 256 * u < C) s += m[u];
+    }
+    s = wave_sum_f(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    __syncthreads();
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (tid + 256 * u < C) ss += (m[u] - mean) * (m[u] - mean);
+    ss = wave_sum_f(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)C + eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        if (c < C) out[(int64_t)b * C + c] = (m[u] - mean) * rstd * g[c] + bta[c];
+    }
+}
+
+int upload_f32(DevBuf& buf, const float* data, size_t n) {
+    HIPTS_TRY(buf.alloc(n * 4));
+    return upload(buf.p, data, n * 4);
+}
+
+// y = act(A W^T) helpers over the shared persistent GEMM
+int gemm(GemmEpilogue epi, GemmArgs& g, hipStream_t s) { return launch_gemm(epi, g, s); }
+
+int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is_u8, int batch, float* out, int out_memspace,
+                      hipStream_t s) {
+    HIPTS_REQUIRE(h && input && out && batch >= 1, "hipts_ccip_forward: bad arguments");
+    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
+    if (!h->missing.empty())
+        return set_error(HIPTS_ERR_STATE, "hipts_ccip_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
+                         h->missing[0].c_str());
+    HIPTS_TRY(use_device(h->device));
+    const auto& c = h->cfg;
+    const int S = c.image_size;
+    const bool f16 = c.operand_f16 != 0;
+    const float* zeros = h->zeros.as<float>();
+
+    const void* in_dev = input;
+    if (in_memspace != HIPTS_DEVICE) {
+        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
+        HIPTS_TRY(h->img_in.reserve(bytes));
+        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
+        in_dev = h->img_in.p;
+    }
+    float* x = h->x.as<float>();
+    bf16_t* xn = h->xn.as<bf16_t>();
+    GemmArgs g;
+
+    // ---- stem: conv 7x7 s4 p2 (+bias) -> bias-free LN = residual stream of stage 0
+    {
+        const Stage& S0 = h->st[0];
+        const int64_t M = (int64_t)batch * S0.T;
+        const int blocks = ceil_div(M * 7, 256);
+        bf16_t* a0 = h->a0.as<bf16_t>();
+        if (is_u8) {
+            if (f16) stem_im2col_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
+            else stem_im2col_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
+        } else {
+            if (f16) stem_im2col_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
+            else stem_im2col_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
+        }
+        HIPTS_LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = a0; g.W = h->stem_w.as<bf16_t>(); g.M = (int)M; g.N = S0.C; g.K = STEM_K;
+        g.bias = h->stem_b.as<float>(); g.out_f32 = x;
+        HIPTS_TRY(gemm(EPI_BIAS, g, s));
+        ln_inplace_kernel<<<ceil_div(M, 4), 256, 0, s>>>(x, h->stem_norm.as<float>(), M, S0.C, c.ln_eps);
+        HIPTS_LAUNCH_CHECK();
+    }
+
+    for (int si = 0; si < 4; ++si) {
+        Stage& St = h->st[si];
+        const int C = St.C, H = St.H, T = St.T, Tp = St.Tp;
+        const int M = batch * T;
+        if (si > 0) {
+            // downsample: LN(x) -> 3x3 s2 p1 conv (+bias) -> x
+            const Stage& Pv = h->st[si - 1];
+            HIPTS_TRY(launch_layernorm(x, St.ds_norm.as<float>(), nullptr, xn, (int64_t)batch * Pv.T, Pv.C, c.ln_eps, f16, s));
+            const int64_t chunks = (int64_t)M * 9 * (Pv.C / 8);
+            ds_im2col_kernel<<<ceil_div(chunks, 256), 256, 0, s>>>(xn, h->col.as<bf16_t>(), batch, Pv.H, Pv.C);
+            HIPTS_LAUNCH_CHECK();
+            g = GemmArgs{};
+            g.f16 = f16;
+            g.A = h->col.as<bf16_t>(); g.W = St.ds_w.as<bf16_t>(); g.M = M; g.N = C; g.K = 9 * Pv.C;
+            g.bias = St.ds_b.as<float>(); g.out_f32 = x;
+            HIPTS_TRY(gemm(EPI_BIAS, g, s));
+        }
+        for (Block& B : St.blocks) {
+            HIPTS_TRY(launch_layernorm(x, B.n1.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
+            if (!B.attn) {
+                // SepConv: 1x1 (C -> 2C) + StarReLU -> depthwise 7x7 -> 1x1 (2C -> C) + residual
+                g = GemmArgs{};
+                g.f16 = f16;
+                g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
+                g.out_bf16 = h->h1.as<bf16_t>(); g.star_scale = B.s1; g.star_bias = B.b1;
+                HIPTS_TRY(gemm(EPI_STAR, g, s));
+                const int64_t thr = (int64_t)M * (2 * C / 8);
+                if (f16) dwconv7_kernel<true><<<ceil_div(thr, 256), 256, 0, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), batch, H, 2 * C);
+                else dwconv7_kernel<false><<<ceil_div(thr, 256), 256, 0, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), batch, H, 2 * C);
+                HIPTS_LAUNCH_CHECK();
+                g = GemmArgs{};
+                g.f16 = f16;
+                g.A = h->h2.as<bf16_t>(); g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = 2 * C; g.bias = zeros; g.out_f32 = x;
+                if (B.has_rs1) {
+                    g.res_scale = B.rs1.as<float>();
+                    HIPTS_TRY(gemm(EPI_RESCALE, g, s));
+                } else {
+                    HIPTS_TRY(gemm(EPI_RESID, g, s));
+                }
+            } else {
+                const int heads = C / c.head_dim;
+                g = GemmArgs{};
+                g.f16 = f16;
+                g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
+                g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
+                g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
+                g.qscale = 0.17677669529663687f * 1.4426950408889634f;      // 32^-0.5 * log2(e): attention works in base 2
+                HIPTS_TRY(gemm(EPI_QK, g, s));
+                g = GemmArgs{};
+                g.f16 = f16;
+                g.A = xn; g.W = B.w_in.as<bf16_t>() + (size_t)2 * C * C; g.M = M; g.N = C; g.K = C; g.bias = zeros;
+                g.out_bf16 = h->vT.as<bf16_t>();
+                g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
+                HIPTS_TRY(gemm(EPI_VT, g, s));
+                HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->h1.as<bf16_t>(), batch, heads, T, Tp,
+                                           f16, s, 32));
+                g = GemmArgs{};
+                g.f16 = f16;
+                g.A = h->h1.as<bf16_t>(); g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = C; g.bias = zeros; g.out_f32 = x;
+                if (B.has_rs1) {
+                    g.res_scale = B.rs1.as<float>();
+                    HIPTS_TRY(gemm(EPI_RESCALE, g, s));
+                } else {
+                    HIPTS_TRY(gemm(EPI_RESID, g, s));
+                }
+            }
+            // MLP: fc1 + StarReLU, fc2 + residual
+            HIPTS_TRY(launch_layernorm(x, B.n2.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
+            g = GemmArgs{};
+            g.f16 = f16;
+            g.A = xn; g.W = B.fc1.as<bf16_t>(); g.M = M; g.N = 4 * C; g.K = C; g.bias = zeros;
+            g.out_bf16 = h->m1.as<bf16_t>(); g.star_scale = B.s2; g.star_bias = B.b2;
+            HIPTS_TRY(gemm(EPI_STAR, g, s));
+            g = GemmArgs{};
+            g.f16 = f16;
+            g.A = h->m1.as<bf16_t>(); g.W = B.fc2.as<bf16_t>(); g.M = M; g.N = C; g.K = 4 * C; g.bias = zeros; g.out_f32 = x;
+            if (B.has_rs2) {
+                g.res_scale = B.rs2.as<float>();
+                HIPTS_TRY(gemm(EPI_RESCALE, g, s));
+            } else {
+                HIPTS_TRY(gemm(EPI_RESID, g, s));
+            }
+        }
+    }
+    // ---- head: global average pool -> LayerNorm
+    const Stage& L = h->st[3];
+    const bool dev_out = out_memspace == HIPTS_DEVICE;
+    float* f_dev = dev_out ? out : h->feat.as<float>();
+    pool_ln_kernel<<<batch, 256, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev, L.T, L.C, c.ln_eps);
+    HIPTS_LAUNCH_CHECK();
+    if (!dev_out) {
+        HIPTS_HIP(hipMemcpyAsync(out, f_dev, (size_t)batch * L.C * 4, hipMemcpyDeviceToHost, s));
+        HIPTS_HIP(hipStreamSynchronize(s));
+    }
+    return HIPTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t** out) {
+    HIPTS_REQUIRE(cfg && out, "hipts_ccip_create: null argument");
+    HIPTS_REQUIRE(cfg->image_size >= 32 && cfg->image_size % 32 == 0, "image_size %d must be a multiple of 32", cfg->image_size);
+    HIPTS_REQUIRE(cfg->head_dim == 32, "head_dim %d: only 32 is built", cfg->head_dim);
+    HIPTS_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
+    HIPTS_REQUIRE(cfg->attn_from_stage >= 0 && cfg->attn_from_stage <= 4, "attn_from_stage must be 0 .. 4");
+    for (int s = 0; s < 4; ++s) {
+        HIPTS_REQUIRE(cfg->dims[s] >= 64 && cfg->dims[s] % 64 == 0 && cfg->dims[s] <= 1024, "dims[%d] = %d must be a multiple of 64, at most 1024",
+                      s, cfg->dims[s]);
+        HIPTS_REQUIRE(cfg->depths[s] >= 1, "depths[%d] must be >= 1", s);
+    }
+    HIPTS_TRY(use_device(device));
+    auto* h = new hipts_ccip();
+    h->device = device;
+    h->cfg = *cfg;
+    const int B = cfg->max_batch;
+    size_t max_x = 0, max_2c = 0, max_4c = 0, max_col = 16, max_qk = 16;
+    double flops = 0.0;
+    int H = cfg->image_size / 4;
+    flops += 2.0 * H * H * cfg->dims[0] * 147.0;
+    for (int s = 0; s < 4; ++s) {
+        Stage& St = h->st[s];
+        if (s > 0) H /= 2;
+        St.C = cfg->dims[s];
+        St.H = H;
+        St.T = H * H;
+        St.Tp = round_up(St.T, 64);
+        St.blocks.resize(cfg->depths[s]);
+        const double T = St.T, C = St.C;
+        if (s > 0) flops += 2.0 * T * C * 9.0 * cfg->dims[s - 1];
+        for (int i = 0; i < cfg->depths[s]; ++i) {
+            Block& Bk = St.blocks[i];
+            Bk.attn = s >= cfg->attn_from_stage;
+            if (Bk.attn) flops += 2.0 * T * 3 * C * C + 4.0 * T * T * C + 2.0 * T * C * C;
+            else flops += 2.0 * T * 2 * C * C * 2 + 2.0 * 49.0 * T * 2 * C;
+            flops += 2.0 * T * 4 * C * C * 2;
+        }
+        max_x = std::max(max_x, (size_t)B * St.T * St.C);
+        max_2c = std::max(max_2c, (size_t)B * St.T * 2 * St.C);
+        max_4c = std::max(max_4c, (size_t)B * St.T * 4 * St.C);
+        if (s > 0) max_col = std::max(max_col, (size_t)B * St.T * 9 * cfg->dims[s - 1]);
+        if (s >= cfg->attn_from_stage) max_qk = std::max(max_qk, (size_t)B * St.Tp * St.C);
+    }
+    h->flops_per_image = flops;
+    int st = 0;
+    std::vector<float> z(4096, 0.f);
+    if ((st = upload_f32(h->zeros, z.data(), z.size())) || (st = h->a0.alloc((size_t)B * h->st[0].T * STEM_K * 2)) ||
+        (st = h->x.alloc(max_x * 4)) || (st = h->xn.alloc(max_x * 2)) || (st = h->h1.alloc(max_2c * 2)) || (st = h->h2.alloc(max_2c * 2)) ||
+        (st = h->m1.alloc(max_4c * 2)) || (st = h->col.alloc(max_col * 2)) || (st = h->q.alloc(max_qk * 2)) || (st = h->k.alloc(max_qk * 2)) ||
+        (st = h->vT.alloc(max_qk * 2)) || (st = h->feat.alloc((size_t)B * cfg->dims[3] * 4))) {
+        delete h;
+        return st;
+    }
+    // pad columns of the stem patch matrix and the padded token rows of q / k / v^T stay zero for ever
+    hipError_t e = hipMemset(h->a0.p, 0, h->a0.bytes);
+    if (e == hipSuccess) e = hipMemset(h->q.p, 0, h->q.bytes);
+    if (e == hipSuccess) e = hipMemset(h->k.p, 0, h->k.bytes);
+    if (e == hipSuccess) e = hipMemset(h->vT.p, 0, h->vT.bytes);
+    if (e != hipSuccess) {
+        delete h;
+        return set_error(HIPTS_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    auto need = [&](const std::string& k) { h->missing.push_back(k); };
+    need("stem.conv.weight"); need("stem.conv.bias"); need("stem.norm.weight"); need("head.norm.weight"); need("head.norm.bias");
+    for (int s = 0; s < 4; ++s) {
+        const std::string sp = "stages." + std::to_string(s) + ".";
+        if (s > 0) { need(sp + "downsample.norm.weight"); need(sp + "downsample.conv.weight"); need(sp + "downsample.conv.bias"); }
+        for (int i = 0; i < cfg->depths[s]; ++i) {
+            const std::string p = sp + "blocks." + std::to_string(i) + ".";
+            need(p + "norm1.weight"); need(p + "norm2.weight");
+            if (s >= cfg->attn_from_stage) { need(p + "token_mixer.qkv.weight"); need(p + "token_mixer.proj.weight"); }
+            else {
+                need(p + "token_mixer.pwconv1.weight"); need(p + "token_mixer.act1.scale"); need(p + "token_mixer.act1.bias");
+                need(p + "token_mixer.dwconv.weight"); need(p + "token_mixer.pwconv2.weight");
+            }
+            need(p + "mlp.fc1.weight"); need(p + "mlp.act.scale"); need(p + "mlp.act.bias"); need(p + "mlp.fc2.weight");
+        }
+    }
+    *out = h;
+    return HIPTS_OK;
+}
+
+int hipts_ccip_destroy(hipts_ccip_t* h) {
+    if (h) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        delete h;
+    }
+    return HIPTS_OK;
+}
+
+int hipts_ccip_set_tensor(hipts_ccip_t* h, const char* key_c, const float* data, int64_t numel) {
+    HIPTS_REQUIRE(h && key_c && data, "hipts_ccip_set_tensor: null argument");
+    HIPTS_TRY(use_device(h->device));
+    const std::string key(key_c);
+    const bool f16 = h->cfg.operand_f16 != 0;
+    int st = HIPTS_OK;
+#define EXPECT(n)                                                                                                         \
+    do {                                                                                                                  \
+        if (numel != (int64_t)(n)) return set_error(HIPTS_ERR_INVALID, "tensor %s: %lld elements, expected %lld", key_c, (long long)numel, (long long)(n)); \
+    } while (0)
+    const int C0 = h->cfg.dims[0], C3 = h->cfg.dims[3];
+    if (key == "stem.conv.weight") {
+        EXPECT((int64_t)C0 * 147);
+        // [n][c][ky][kx] -> [n][(ky*7 + kx)*3 + c], duplicated for the hi | lo halves of the patch matrix
+        std::vector<float> w2((size_t)C0 * STEM_K, 0.f);
+        for (int n = 0; n < C0; ++n)
+            for (int c = 0; c < 3; ++c)
+                for (int t = 0; t < 49; ++t) {
+                    const float v = data[((size_t)n * 3 + c) * 49 + t];
+                    w2[(size_t)n * STEM_K + t * 3 + c] = v;
+                    w2[(size_t)n * STEM_K + STEM_KH + t * 3 + c] = v;
+                }
+        st = upload_matrix16(h->stem_w, w2.data(), C0, STEM_K, round_up(C0, 256), f16);
+    } else if (key == "stem.conv.bias") { EXPECT(C0); st = upload_f32(h->stem_b, data, C0); }
+    else if (key == "stem.norm.weight") { EXPECT(C0); st = upload_f32(h->stem_norm, data, C0); }
+    else if (key == "head.norm.weight") { EXPECT(C3); st = upload_f32(h->head_g, data, C3); }
+    else if (key == "head.norm.bias") { EXPECT(C3); st = upload_f32(h->head_b, data, C3); }
+    else if (key.rfind("stages.", 0) == 0) {
+        const size_t d1 = key.find('.', 7);
+        if (d1 == std::string::npos) return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+        const int s = atoi(key.substr(7, d1 - 7).c_str());
+        if (s < 0 || s > 3) return set_error(HIPTS_ERR_INVALID, "tensor %s: stage out of range", key_c);
+        Stage& St = h->st[s];
+        const int C = St.C;
+        std::string sub = key.substr(d1 + 1);
+        if (sub.rfind("downsample.", 0) == 0) {
+            if (s == 0) return set_error(HIPTS_ERR_INVALID, "tensor %s: stage 0 has no downsample", key_c);
+            const int Cp = h->cfg.dims[s - 1];
+            if (sub == "downsample.norm.weight") { EXPECT(Cp); st = upload_f32(St.ds_norm, data, Cp); }
+            else if (sub == "downsample.conv.bias") { EXPECT(C); st = upload_f32(St.ds_b, data, C); }
+            else if (sub == "downsample.conv.weight") {
+                EXPECT((int64_t)C * Cp * 9);
+                std::vector<float> w2((size_t)C * 9 * Cp);          // [n][c][tap] -> [n][tap*Cp + c]
+                for (int n = 0; n < C; ++n)
+                    for (int cc = 0; cc < Cp; ++cc)
+                        for (int t = 0; t < 9; ++t) w2[((size_t)n * 9 + t) * Cp + cc] = data[((size_t)n * Cp + cc) * 9 + t];
+                st = upload_matrix16(St.ds_w, w2.data(), C, 9 * Cp, round_up(C, 256), f16);
+            } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+        } else if (sub.rfind("blocks.", 0) == 0) {
+            const size_t d2 = sub.find('.', 7);
+            if (d2 == std::string::npos) return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+            const int bi = atoi(sub.substr(7, d2 - 7).c_str());
+            if (bi < 0 || bi >= (int)St.blocks.size()) return set_error(HIPTS_ERR_INVALID, "tensor %s: block out of range", key_c);
+            Block& B = St.blocks[bi];
+            const std::string t = sub.substr(d2 + 1);
+            if (t == "norm1.weight") { EXPECT(C); st = upload_f32(B.n1, data, C); }
+            else if (t == "norm2.weight") { EXPECT(C); st = upload_f32(B.n2, data, C); }
+            else if (t == "res_scale1.scale") { EXPECT(C); st = upload_f32(B.rs1, data, C); B.has_rs1 = true; }
+            else if (t == "res_scale2.scale") { EXPECT(C); st = upload_f32(B.rs2, data, C); B.has_rs2 = true; }
+            else if (t == "mlp.fc1.weight") { EXPECT((int64_t)4 * C * C); st = upload_matrix16(B.fc1, data, 4 * C, C, round_up(4 * C, 256), f16); }
+            else if (t == "mlp.fc2.weight") { EXPECT((int64_t)4 * C * C); st = upload_matrix16(B.fc2, data, C, 4 * C, round_up(C, 256), f16); }
+            else if (t == "mlp.act.scale") { EXPECT(1); B.s2 = data[0]; }
+            else if (t == "mlp.act.bias") { EXPECT(1); B.b2 = data[0]; }
+            else if (!B.attn && t == "token_mixer.pwconv1.weight") { EXPECT((int64_t)2 * C * C); st = upload_matrix16(B.w_in, data, 2 * C, C, round_up(2 * C, 256), f16); }
+            else if (!B.attn && t == "token_mixer.pwconv2.weight") { EXPECT((int64_t)2 * C * C); st = upload_matrix16(B.w_out, data, C, 2 * C, round_up(C, 256), f16); }
+            else if (!B.attn && t == "token_mixer.act1.scale") { EXPECT(1); B.s1 = data[0]; }
+            else if (!B.attn && t == "token_mixer.act1.bias") { EXPECT(1); B.b1 = data[0]; }
+            else if (!B.attn && t == "token_mixer.dwconv.weight") {
+                EXPECT((int64_t)2 * C * 49);
+                std::vector<float> w2((size_t)49 * 2 * C);          // [c][tap] -> [tap][c]
+                for (int cc = 0; cc < 2 * C; ++cc)
+                    for (int tp = 0; tp < 49; ++tp) w2[(size_t)tp * 2 * C + cc] = data[(size_t)cc * 49 + tp];
+                st = upload_f32(B.dw, w2.data(), w2.size());
+            }
+            else if (B.attn && t == "token_mixer.qkv.weight") {
+                EXPECT((int64_t)3 * C * C);
+                // q|k rows and the v rows are read by separate launches whose last tile may run past its
+                // own rows: pad behind the v rows as well
+                st = upload_matrix16(B.w_in, data, 3 * C, C, round_up(2 * C, 256) + round_up(C, 256) + 256, f16);
+            }
+            else if (B.attn && t == "token_mixer.proj.weight") { EXPECT((int64_t)C * C); st = upload_matrix16(B.w_out, data, C, C, round_up(C, 256), f16); }
+            else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+        } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+    } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+#undef EXPECT
+    if (st) return st;
+    auto it = std::find(h->missing.begin(), h->missing.end(), key);
+    if (it != h->missing.end()) h->missing.erase(it);
+    return HIPTS_OK;
+}
+
+int hipts_ccip_forward_u8(hipts_ccip_t* h, const uint8_t* images, int images_memspace, int batch, float* features_out,
+                          int out_memspace, void* stream) {
+    return ccip_forward_impl(h, images, images_memspace, true, batch, features_out, out_memspace, (hipStream_t)stream);
+}
+
+int hipts_ccip_forward_f32(hipts_ccip_t* h, const float* x, int x_memspace, int batch, float* features_out, int out_memspace,
+                           void* stream) {
+    return ccip_forward_impl(h, x, x_memspace, false, batch, features_out, out_memspace, (hipStream_t)stream);
+}
+
+int hipts_ccip_flops_per_image(const hipts_ccip_t* h, double* flops) {
+    HIPTS_REQUIRE(h && flops, "null argument");
+    *flops = h->flops_per_image;
+    return HIPTS_OK;
+}
+
+}  // extern "C"

@@ -4,9 +4,11 @@
   write_vecs_to_index                                     gen_cfeatures.py:307-315         (index.Similarity)
   character-oriented rerank                               webui.py:255-342, restated per BASELINE.json
                                                           configs[4] as cosine over the feature index
-The CCIP encoder itself (an ONNX graph fetched from the HF hub, gen_cfeatures.py:112-118) cannot be
-obtained in this environment: `encoder` is a pluggable callable float32[B,3,384,384] -> float32[B,768]
-(DESIGN.md section 6).  The metric model (gen_cfeatures.py:124-130) is likewise opaque; BASELINE.json
+  CCIPEncoder                                             gen_cfeatures.py:112-118,133-159 (hipts_ccip_*)
+The CCIP encoder's ONNX file (fetched from the HF hub, gen_cfeatures.py:112-118) cannot be obtained in
+this environment; CCIPEncoder runs the CAFormer graph it contains (oracle/ccip.py) on the
+device from a timm-layout state_dict and offers the onnxruntime call shape `run(['output'], {'input': x})`,
+so it plugs in as `encoder`.  The metric model (gen_cfeatures.py:124-130) is likewise opaque; BASELINE.json
 restates the rerank as cosine similarity, which is what runs on the device here:
 difference := 1 - cos(feature, query).
 """
@@ -50,6 +52,76 @@ def gen_image_ndarray(file_path: str) -> Optional[np.ndarray]:
     except Exception as e:
         print('%s: %s' % (type(e), str(e)))
         return None
+
+
+class CCIPEncoder:
+    """Device-resident CCIP feature encoder (CAFormer forward, libhip_tagsearch `hipts_ccip_*`).
+
+    Stands where gen_cfeatures.py:112-118 opens the onnxruntime session: `run(['output'], {'input': x})`
+    (gen_cfeatures.py:158) and plain calls `encoder(x)` both take float32 [B,3,S,S] normalised images and
+    return float32 [B, dims[3]] features.  `weights`: timm MetaFormer state_dict keys -> float32 arrays."""
+
+    def __init__(self, cfg: Dict, weights: Dict[str, np.ndarray], max_batch: int = BATCH_SIZE, device: int = 0):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        self.cfg = dict(cfg)
+        self.max_batch = max_batch
+        self.out_dim = int(cfg["dims"][3])
+        c = _lib.CcipConfig(cfg["image_size"], (ctypes.c_int32 * 4)(*cfg["dims"]), (ctypes.c_int32 * 4)(*cfg["depths"]),
+                            cfg.get("head_dim", 32), cfg.get("attn_from_stage", 2), cfg.get("ln_eps", 1e-6), max_batch,
+                            cfg.get("operand_f16", 0))
+        self._h = ctypes.c_void_p()
+        _lib.call("hipts_ccip_create", ctypes.byref(c), device, ctypes.byref(self._h))
+        for key, val in weights.items():
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            _lib.call("hipts_ccip_set_tensor", self._h, key.encode(), _lib.ptr(arr), ctypes.c_int64(arr.size))
+
+    @classmethod
+    def from_safetensors(cls, path: str, cfg: Dict, **kw) -> "CCIPEncoder":
+        from safetensors.numpy import load_file
+        return cls(cfg, {k: v.astype(np.float32) for k, v in load_file(path).items()}, **kw)
+
+    def flops_per_image(self) -> float:
+        import ctypes
+        f = ctypes.c_double()
+        self._lib.call("hipts_ccip_flops_per_image", self._h, ctypes.byref(f))
+        return f.value
+
+    def _forward(self, fn: str, x, out):
+        _lib = self._lib
+        B = int(x.shape[0])
+        if out is None:
+            out = np.empty((B, self.out_dim), dtype=np.float32)
+        for s in range(0, B, self.max_batch):
+            xs, os_ = x[s:s + self.max_batch], out[s:s + self.max_batch]
+            _lib.call(fn, self._h, _lib.ptr(xs), _lib.memspace_of(xs), int(xs.shape[0]), _lib.ptr(os_), _lib.memspace_of(os_),
+                      _lib.current_stream_ptr())
+        return out
+
+    def __call__(self, x, out=None):
+        """x: float32 [B,3,S,S] (numpy or torch, host or device) -> float32 [B, out_dim]."""
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+        return self._forward("hipts_ccip_forward_f32", x, out)
+
+    def forward_u8(self, images, out=None):
+        """images: uint8 [B,S,S,3] RGB, already S x S: /255 and the CLIP normalisation run on the device."""
+        if isinstance(images, np.ndarray):
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+        return self._forward("hipts_ccip_forward_u8", images, out)
+
+    def run(self, output_names, feed):                                              # onnxruntime call shape, :158
+        assert list(output_names) == ["output"] and list(feed.keys()) == ["input"]
+        return [self(np.asarray(feed["input"], dtype=np.float32))]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.call("hipts_ccip_destroy", self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class CharacterFeatureIndex:

@@ -14,6 +14,9 @@ VIT_B16_448 = dict(image_size=448, patch=16, dim=768, depth=12, heads=12, mlp_di
                    ln_eps=1e-6, gelu_tanh=1, pool_then_norm=0)
 VIT_TINY = dict(image_size=64, patch=16, dim=128, depth=2, heads=2, mlp_dim=256, num_classes=200,
                 ln_eps=1e-6, gelu_tanh=1, pool_then_norm=0)
+# CCIP feature encoder (gen_cfeatures.py): CAFormer-B36 widths at 384 px, 768-d feature
+CCIP_B36_384 = dict(image_size=384, dims=(128, 256, 512, 768), depths=(3, 12, 18, 3), head_dim=32, ln_eps=1e-6)
+CCIP_TINY = dict(image_size=64, dims=(64, 64, 128, 128), depths=(1, 1, 2, 1), head_dim=32, ln_eps=1e-6)
 
 
 def round_to_bf16(x: np.ndarray) -> np.ndarray:
@@ -60,6 +63,55 @@ def vit_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[st
     w["norm.bias"] = _trunc_normal(rng, (D,), 0.02)
     w["head.weight"] = rb(_trunc_normal(rng, (C, D), 0.02))
     w["head.bias"] = _trunc_normal(rng, (C,), 0.02)
+    return w
+
+
+def ccip_weights(cfg: Dict, seed: int = 46, bf16_matrices: bool = True) -> Dict[str, np.ndarray]:
+    """Random-init CAFormer checkpoint with timm `MetaFormer` state_dict keys.  Linear / 1x1 weights
+    ~ N(0, 1/fan_in) truncated at 2 sigma (activations stay O(1) through the StarReLU blocks), StarReLU
+    (scale, bias) near the variance-preserving (0.8944, -0.4472), depthwise 7x7 ~ N(0, 1/49), LN gamma
+    ~ U(0.5,1.5), res_scale ~ U(0.8,1.2).  Matrices are bf16-representable with bf16_matrices (see vit_weights)."""
+    rng = np.random.default_rng(seed)
+    dims, depths = cfg["dims"], cfg["depths"]
+    rb = round_to_bf16 if bf16_matrices else (lambda a: a)
+    w: Dict[str, np.ndarray] = {}
+
+    def lin(out_f, in_f, shape=None):
+        m = rb(_trunc_normal(rng, (out_f, in_f), 1.0 / np.sqrt(in_f)))
+        return m.reshape(shape) if shape else m
+
+    w["stem.conv.weight"] = rb(_trunc_normal(rng, (dims[0], 3, 7, 7), 1.0 / np.sqrt(147.0)))
+    w["stem.conv.bias"] = _trunc_normal(rng, (dims[0],), 0.02)
+    w["stem.norm.weight"] = rng.uniform(0.5, 1.5, dims[0]).astype(np.float32)
+    for s in range(4):
+        C = dims[s]
+        if s > 0:
+            Cp = dims[s - 1]
+            w["stages.%d.downsample.norm.weight" % s] = rng.uniform(0.5, 1.5, Cp).astype(np.float32)
+            w["stages.%d.downsample.conv.weight" % s] = rb(_trunc_normal(rng, (C, Cp, 3, 3), 1.0 / np.sqrt(9.0 * Cp)))
+            w["stages.%d.downsample.conv.bias" % s] = _trunc_normal(rng, (C,), 0.02)
+        for i in range(depths[s]):
+            p = "stages.%d.blocks.%d." % (s, i)
+            w[p + "norm1.weight"] = rng.uniform(0.5, 1.5, C).astype(np.float32)
+            w[p + "norm2.weight"] = rng.uniform(0.5, 1.5, C).astype(np.float32)
+            if s < 2:
+                w[p + "token_mixer.pwconv1.weight"] = lin(2 * C, C, (2 * C, C, 1, 1))
+                w[p + "token_mixer.act1.scale"] = np.float32([0.8944 * rng.uniform(0.9, 1.1)])
+                w[p + "token_mixer.act1.bias"] = np.float32([-0.4472 + rng.normal(0, 0.02)])
+                w[p + "token_mixer.dwconv.weight"] = _trunc_normal(rng, (2 * C, 1, 7, 7), 1.0 / 7.0)
+                w[p + "token_mixer.pwconv2.weight"] = lin(C, 2 * C, (C, 2 * C, 1, 1))
+            else:
+                w[p + "token_mixer.qkv.weight"] = lin(3 * C, C)
+                w[p + "token_mixer.proj.weight"] = lin(C, C)
+                w[p + "res_scale1.scale"] = rng.uniform(0.8, 1.2, C).astype(np.float32)
+                w[p + "res_scale2.scale"] = rng.uniform(0.8, 1.2, C).astype(np.float32)
+            shape4 = s < 2
+            w[p + "mlp.fc1.weight"] = lin(4 * C, C, (4 * C, C, 1, 1) if shape4 else None)
+            w[p + "mlp.act.scale"] = np.float32([0.8944 * rng.uniform(0.9, 1.1)])
+            w[p + "mlp.act.bias"] = np.float32([-0.4472 + rng.normal(0, 0.02)])
+            w[p + "mlp.fc2.weight"] = lin(C, 4 * C, (C, 4 * C, 1, 1) if shape4 else None)
+    w["head.norm.weight"] = rng.uniform(0.5, 1.5, dims[3]).astype(np.float32)
+    w["head.norm.bias"] = _trunc_normal(rng, (dims[3],), 0.02)
     return w
 
 

@@ -109,6 +109,45 @@ int hipts_vit_set_sub_batches(hipts_vit_t* h, int n);
 int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops);
 
 /* ------------------------------------------------------------------------------------------
+ * CCIP feature encoder.   Replaces the onnxruntime session of gen_cfeatures.py:112-118 and its
+ * `session.run(['output'], {'input': x})` call (gen_cfeatures.py:158; batching :133-159).
+ * Graph: CAFormer (timm MetaFormer) -- stem conv 7x7 s4 + bias-free LN; four stages (3x3 s2 conv
+ * downsampling with pre-norm between them) of blocks x = rs1*x + mixer(LN(x)); x = rs2*x + MLP(LN(x));
+ * mixer = SepConv (1x1 -> StarReLU -> depthwise 7x7 -> 1x1) in the first stages, self-attention with
+ * head_dim 32 (no biases) from `attn_from_stage` on; MLP = fc1 -> StarReLU -> fc2 (x4, no biases);
+ * rs = per-channel res_scale (attention stages only); output = LN(global average pool), dims[3] wide.
+ * Matrix weights are bf16 MFMA operands; accumulation, residual stream, LayerNorm, softmax in float32.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_ccip hipts_ccip_t;
+
+typedef struct hipts_ccip_config {
+    int32_t image_size;       /* 384 (a multiple of 32)                                   */
+    int32_t dims[4];          /* 128, 256, 512, 768 (multiples of 64)                      */
+    int32_t depths[4];        /* 3, 12, 18, 3                                              */
+    int32_t head_dim;         /* 32                                                        */
+    int32_t attn_from_stage;  /* 2: stages 0,1 SepConv, stages 2,3 attention               */
+    float   ln_eps;           /* 1e-6                                                      */
+    int32_t max_batch;        /* workspace is sized for this many images per forward call  */
+    int32_t operand_f16;      /* as hipts_vit_config_t.operand_f16                         */
+} hipts_ccip_config_t;
+
+int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t** out);
+int hipts_ccip_destroy(hipts_ccip_t* h);
+/* One tensor by its timm MetaFormer state_dict key ("stem.conv.weight", "stages.1.downsample.conv.weight",
+ * "stages.0.blocks.2.token_mixer.dwconv.weight", "stages.2.blocks.0.res_scale1.scale", "head.norm.bias", ...);
+ * 1x1 convolutions may arrive as [out,in,1,1] or [out,in] (same element count). */
+int hipts_ccip_set_tensor(hipts_ccip_t* h, const char* key, const float* data, int64_t numel);
+/* images: uint8 [batch][S][S][3] RGB, already S x S (the resize of gen_cfeatures.py:101 done by the
+ * caller); the kernel applies /255 and the CLIP mean / std of gen_cfeatures.py:103-110 while forming
+ * the stem's patch matrix.  features_out: float32 [batch][dims[3]]. */
+int hipts_ccip_forward_u8(hipts_ccip_t* h, const uint8_t* images, int images_memspace, int batch, float* features_out,
+                          int out_memspace, void* stream);
+/* x: float32 [batch][3][S][S], already normalised -- exactly the `input` array of gen_cfeatures.py:158. */
+int hipts_ccip_forward_f32(hipts_ccip_t* h, const float* x, int x_memspace, int batch, float* features_out,
+                           int out_memspace, void* stream);
+int hipts_ccip_flops_per_image(const hipts_ccip_t* h, double* flops);
+
+/* ------------------------------------------------------------------------------------------
  * Tag selection.   Replaces the per-image numpy/Python post-processing   tagging.py:61-66,185-227
  * (float64 MCut threshold per category, strict '>' filter, stable descending order).
  * ---------------------------------------------------------------------------------------- */

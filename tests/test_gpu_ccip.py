@@ -1,0 +1,86 @@
+"""GPU parity: CCIP feature encoder (CAFormer forward, bf16 MFMA, fp32 accumulate) vs the float32 torch-CPU
+oracle (oracle/ccip.py; parity unpinned -- the reference's ONNX graph is not available, see its header).
+
+Tolerance: north_star states none for this path (1e-3 is for the ViT logits).  The output is a LayerNorm-ed
+feature (unit scale per component) that downstream code only uses through cosine similarity
+(webui.py:303-335 via the feature index).  Measured on the synthetic checkpoints (unit-variance activations
+through every StarReLU block, which squares and so doubles relative rounding errors): bf16 operands
+max |df| 3.5e-2 (tiny) / 6.9e-2 (B36), cosine 0.99988; IEEE-half operands 4e-3 / 9e-3, cosine 0.999998 --
+an 8x ratio, i.e. operand rounding only.  Bounds: bf16 max |df| <= 1e-1 and cosine >= 0.9995; half
+max |df| <= 2e-2 and cosine >= 0.99999."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: (1e-1, 0.9995), 1: (2e-2, 0.99999)}       # operand_f16 -> (max |df|, min cosine)
+
+
+def _oracle(cfg, w, images_u8):
+    from oracle import ccip as oc
+    x = oc.preprocess_u8_nhwc(images_u8)
+    f = oc.metaformer_forward(oc.to_torch(w), x, dims=cfg["dims"], depths=cfg["depths"], head_dim=cfg["head_dim"], eps=cfg["ln_eps"])
+    return f.numpy(), x.numpy()
+
+
+def _check(got, want, f16=0):
+    err = np.abs(got - want).max()
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    print("CCIP (operand_f16=%d) max |df| = %.3e, min cosine = %.6f" % (f16, err, cos.min()))
+    assert err <= TOL[f16][0], err
+    assert cos.min() >= TOL[f16][1], cos.min()
+
+
+@pytest.mark.parametrize("f16", [0, 1])
+def test_ccip_tiny_matches_oracle(f16):
+    from hiptagsearch import synth
+    from hiptagsearch.cfeatures import CCIPEncoder
+    cfg = dict(synth.CCIP_TINY, operand_f16=f16)
+    w = synth.ccip_weights(cfg, seed=3)
+    imgs = synth.images_u8(5, cfg["image_size"], seed=47)
+    want, x = _oracle(cfg, w, imgs)
+    enc = CCIPEncoder(cfg, w, max_batch=8)
+    got = enc.forward_u8(imgs)
+    _check(got, want, f16)
+    # float32 NCHW entry point: the `input` array of gen_cfeatures.py:158, and the onnxruntime call shape
+    got2 = enc.run(["output"], {"input": x})[0]
+    _check(got2, want, f16)
+    np.testing.assert_allclose(got2, got, atol=TOL[f16][0] / 4)
+    # device in / out, and a batch larger than max_batch is chunked
+    import torch
+    d = torch.empty((5, cfg["dims"][3]), dtype=torch.float32, device="cuda")
+    enc.forward_u8(torch.from_numpy(imgs).cuda(), out=d)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d.cpu().numpy(), got)
+    imgs12 = synth.images_u8(12, cfg["image_size"], seed=48)
+    np.testing.assert_array_equal(enc.forward_u8(imgs12)[:8], enc.forward_u8(imgs12[:8]))
+
+
+def test_ccip_without_res_scale_and_missing_tensor():
+    from hiptagsearch import synth, _lib
+    from hiptagsearch.cfeatures import CCIPEncoder
+    cfg = dict(synth.CCIP_TINY)
+    w = {k: v for k, v in synth.ccip_weights(cfg, seed=5).items() if "res_scale" not in k}      # res_scale tensors are optional
+    imgs = synth.images_u8(2, cfg["image_size"], seed=49)
+    want, _ = _oracle(cfg, w, imgs)
+    _check(CCIPEncoder(cfg, w, max_batch=2).forward_u8(imgs), want)
+    w.pop("stages.1.blocks.0.mlp.fc2.weight")
+    with pytest.raises(_lib.HipTagSearchError, match="not set"):
+        CCIPEncoder(cfg, w, max_batch=2).forward_u8(imgs)
+
+
+@pytest.mark.parametrize("f16", [0, 1])
+def test_ccip_b36_384_matches_oracle(f16):
+    """config[4] geometry: CAFormer-B36 widths at 384 px (9216 / 2304 / 576 / 144 tokens), 2 images."""
+    from hiptagsearch import synth
+    from hiptagsearch.cfeatures import CCIPEncoder
+    cfg = dict(synth.CCIP_B36_384, operand_f16=f16)
+    w = synth.ccip_weights(cfg, seed=46)
+    imgs = synth.images_u8(2, 384, seed=47)
+    want, _ = _oracle(cfg, w, imgs)
+    enc = CCIPEncoder(cfg, w, max_batch=2)
+    got = enc.forward_u8(imgs)
+    _check(got, want, f16)
+    # run to run identical (no atomics, fixed schedules)
+    np.testing.assert_array_equal(enc.forward_u8(imgs), got)
+    print("CCIP B36@384: %.2f GFLOP / image" % (enc.flops_per_image() / 1e9))
