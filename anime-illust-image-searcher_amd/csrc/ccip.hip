@@ -55,7 +55,7 @@ struct hipts_ccip {
     int device = 0;
     hipts_ccip_config_t cfg{};
     Stage st[4];
-    DevBuf stem_w, stem_b, stem_norm, head_g, head_b, zeros;
+    DevBuf stem_w, stem_b, stem_norm, head_g, head_b, zeros, lut;
     std::vector<std::string> missing;
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, h1, h2, m1, col, q, k, vT, feat;
@@ -73,12 +73,19 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // ---------------------------------------------------------------------------------------------
 // Stem patch matrix.  A0[m][(ky*7 + kx)*3 + c] = hi, A0[m][160 + ...] = lo of the normalised pixel at
 // (4 oy - 2 + ky, 4 ox - 2 + kx), zero outside the image (Conv2d padding = 2 pads the NORMALISED input).
-// U8: images uint8 NHWC RGB; /255 in float32, (x - mean) / std in float64, cast (gen_cfeatures.py:100-110,156).
+// U8: images uint8 NHWC RGB; /255 in float32, (x - mean) / std in float64, cast (gen_cfeatures.py:100-110,156) --
+// 3 x 256 possible values, tabulated once on the host with exactly that arithmetic.
 // One thread per (token, ky): 21 values.
 // ---------------------------------------------------------------------------------------------
 template <bool U8, bool F16>
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict__ img, bf16_t* __restrict__ a0, int batch, int S,
-                                                          int H0) {
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict__ img, const float* __restrict__ lut,
+                                                          bf16_t* __restrict__ a0, int batch, int S, int H0) {
+    // lut[c][u] = normalised value of byte u in channel c, built on the host with the reference's arithmetic
+    __shared__ float slut[3 * 256];
+    if constexpr (U8) {
+        for (int i = threadIdx.x; i < 3 * 256; i += 256) slut[i] = lut[i];
+        __syncthreads();
+    }
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)batch * H0 * H0 * 7;
     if (idx >= total) return;
@@ -87,25 +94,21 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
     const int ox = (int)(m % H0), oy = (int)((m / H0) % H0), b = (int)(m / ((int64_t)H0 * H0));
     const int iy = 4 * oy - 2 + ky;
     bf16_t* row = a0 + m * STEM_K + ky * 21;
-    const double mean[3] = {0.48145466, 0.4578275, 0.40821073}, stdv[3] = {0.26862954, 0.26130258, 0.27577711};
+    const bool iny = iy >= 0 && iy < S;
 #pragma unroll
     for (int kx = 0; kx < 7; ++kx) {
         const int ix = 4 * ox - 2 + kx;
-        const bool in = iy >= 0 && iy < S && ix >= 0 && ix < S;
+        const bool in = iny && ix >= 0 && ix < S;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = 0.f;
             if (in) {
-                if constexpr (U8) {
-                    const uint8_t u = reinterpret_cast<const uint8_t*>(img)[(((int64_t)b * S + iy) * S + ix) * 3 + c];
-                    v = (float)(((double)((float)u / 255.0f) - mean[c]) / stdv[c]);
-                } else {
-                    v = reinterpret_cast<const float*>(img)[(((int64_t)b * 3 + c) * S + iy) * S + ix];
-                }
+                if constexpr (U8) v = slut[c * 256 + reinterpret_cast<const uint8_t*>(img)[(((int64_t)b * S + iy) * S + ix) * 3 + c]];
+                else v = reinterpret_cast<const float*>(img)[(((int64_t)b * 3 + c) * S + iy) * S + ix];
             }
-            const float hi = from_op<F16>(to_op<F16>(v));
-            row[kx * 3 + c] = to_op<F16>(v);
-            row[STEM_KH + kx * 3 + c] = to_op<F16>(v - hi);
+            const bf16_t hi = to_op<F16>(v);
+            row[kx * 3 + c] = hi;
+            row[STEM_KH + kx * 3 + c] = to_op<F16>(v - from_op<F16>(hi));
         }
     }
 }
@@ -149,47 +152,95 @@ __global__ __launch_bounds__(256) void ln_inplace_kernel(float* __restrict__ x, 
 
 // ---------------------------------------------------------------------------------------------
 // Depthwise 7x7, padding 3, NHWC: out[b][y][x][c] = sum_{ky,kx} in[b][y+ky-3][x+kx-3][c] * w[ky*7+kx][c].
-// One thread = one pixel x 8 channels (one 16 B load per tap, coalesced along the channel axis; the 49
-// neighbours of adjacent pixels overlap, so the tile is served from L1 / L2).  float32 accumulation.
-// HBM-bound by design: algorithmic traffic = read + write of the [B,H,W,C] tensor once.
+// 49 float32 FMAs per output element make this VALU-bound (not HBM-bound), so the kernel is built to
+// spend its issue slots on FMAs: a workgroup stages an (8+6) x (16+6) pixel x 64 channel input tile and
+// the 49 x 64 weights in LDS once (zero padded at the image border), and every thread produces 4
+// horizontally adjacent pixels x 8 channels -- per kernel row it reads 10 input vectors for 4 x 7 taps
+// (2.8x fewer LDS reads than one pixel per thread) and converts each bf16 input once.
+// LDS pixel pitch 160 B: the 16 lanes of a ds_read_b128 phase (8 channel chunks x 2 pixel groups 4 pixels
+// apart) fall on disjoint bank halves.  float32 accumulation in (ky, kx) order.
 // ---------------------------------------------------------------------------------------------
+constexpr int DW_TH = 8, DW_TW = 16, DW_CS = 64;
+constexpr int DW_PH = DW_TH + 6, DW_PW = DW_TW + 6, DW_PITCH = 160;
+constexpr int DW_IN_BYTES = DW_PH * DW_PW * DW_PITCH;          // 49,280 B
+constexpr int DW_LDS_BYTES = DW_IN_BYTES + 49 * DW_CS * 4;     // + 12,544 B of weights
+
 template <bool F16>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
-                                                      bf16_t* __restrict__ out, int batch, int H, int C) {
-    const int cg = C >> 3;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)batch * H * H * cg;
-    if (idx >= total) return;
-    const int g = (int)(idx % cg);
-    const int64_t p = idx / cg;
-    const int x = (int)(p % H), y = (int)((p / H) % H);
-    const int64_t img0 = (p / ((int64_t)H * H)) * H * H;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                                      bf16_t* __restrict__ out, int H, int C, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem + DW_IN_BYTES);
+    const int tid = threadIdx.x;
+    const int slabs = C / DW_CS;
+    int bid = blockIdx.x;
+    const int slab = bid % slabs;
+    bid /= slabs;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int64_t img0 = (int64_t)(bid / tiles_y) * H * H;
+    const int y0 = ty * DW_TH, x0t = tx * DW_TW, c0 = slab * DW_CS;
+
+    // stage the input tile (zero outside the image) and the weight slab
+    for (int i = tid; i < DW_PH * DW_PW * 8; i += 256) {
+        const int g = i & 7, p = i >> 3;
+        const int py = p / DW_PW, px = p - py * DW_PW;
+        const int iy = y0 + py - 3, ix = x0t + px - 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < H) v = *reinterpret_cast<const uint4*>(in + ((img0 + (int64_t)iy * H + ix) * C + c0 + g * 8));
+        *reinterpret_cast<uint4*>(smem + p * DW_PITCH + g * 16) = v;
+    }
+    for (int i = tid; i < 49 * DW_CS / 4; i += 256) {
+        const int tap = i / (DW_CS / 4), q = i - tap * (DW_CS / 4);
+        *reinterpret_cast<float4*>(wl + tap * DW_CS + q * 4) = *reinterpret_cast<const float4*>(w + (size_t)tap * C + c0 + q * 4);
+    }
+    __syncthreads();
+
+    const int g = tid & 7, pt = tid >> 3;
+    const int r = pt >> 2, xo = (pt & 3) * 4;            // output row in the tile, first of 4 output columns
+    float acc[4][8];
 #pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
     for (int ky = 0; ky < 7; ++ky) {
-        const int iy = y + ky - 3;
-        if (iy < 0 || iy >= H) continue;
+        float wv[7][8];
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
-            const int ix = x + kx - 3;
-            if (ix < 0 || ix >= H) continue;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + ((img0 + (int64_t)iy * H + ix) * C + g * 8));
-            const float4 w0 = *reinterpret_cast<const float4*>(w + (ky * 7 + kx) * C + g * 8);
-            const float4 w1 = *reinterpret_cast<const float4*>(w + (ky * 7 + kx) * C + g * 8 + 4);
-            acc[0] = fmaf(from_op<F16>(v[0]), w0.x, acc[0]);
-            acc[1] = fmaf(from_op<F16>(v[1]), w0.y, acc[1]);
-            acc[2] = fmaf(from_op<F16>(v[2]), w0.z, acc[2]);
-            acc[3] = fmaf(from_op<F16>(v[3]), w0.w, acc[3]);
-            acc[4] = fmaf(from_op<F16>(v[4]), w1.x, acc[4]);
-            acc[5] = fmaf(from_op<F16>(v[5]), w1.y, acc[5]);
-            acc[6] = fmaf(from_op<F16>(v[6]), w1.z, acc[6]);
-            acc[7] = fmaf(from_op<F16>(v[7]), w1.w, acc[7]);
+            const float4 a = *reinterpret_cast<const float4*>(wl + (ky * 7 + kx) * DW_CS + g * 8);
+            const float4 b = *reinterpret_cast<const float4*>(wl + (ky * 7 + kx) * DW_CS + g * 8 + 4);
+            wv[kx][0] = a.x; wv[kx][1] = a.y; wv[kx][2] = a.z; wv[kx][3] = a.w;
+            wv[kx][4] = b.x; wv[kx][5] = b.y; wv[kx][6] = b.z; wv[kx][7] = b.w;
+        }
+        const char* rowp = smem + ((r + ky) * DW_PW + xo) * DW_PITCH + g * 16;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {                    // input column xo + j feeds output o = j - kx, kx = 0..6
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(rowp + j * DW_PITCH);
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = from_op<F16>(v[e]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int kx = j - o;
+                if (kx < 0 || kx > 6) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(f[e], wv[kx][e], acc[o][e]);
+            }
         }
     }
-    bf16x8 o;
+    const int oy = y0 + r;
+    if (oy < H) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = to_op<F16>(acc[e]);
-    *reinterpret_cast<bf16x8*>(out + (p * C + g * 8)) = o;
+        for (int o = 0; o < 4; ++o) {
+            const int ox = x0t + xo + o;
+            if (ox >= H) continue;
+            bf16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = to_op<F16>(acc[o][e]);
+            *reinterpret_cast<bf16x8*>(out + ((img0 + (int64_t)oy * H + ox) * C + c0 + g * 8)) = ov;
+        }
+    }
 }
 
 // Downsampling patch matrix: col[m'][(ky*3 + kx)*C + c] = xn[b][2 oy - 1 + ky][2 ox - 1 + kx][c] (zero outside).
@@ -218,7 +269,8 @@ __global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* xb = x + (int64_t)b * T * C;
     float m[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < T; ++r)
+#pragma unroll 8
+    for (int r = 0; r < T; ++r)            // 8 rows x 4 loads in flight: the loop is latency-bound otherwise
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = tid + 256 * u;
@@ -289,11 +341,11 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
         const int blocks = ceil_div(M * 7, 256);
         bf16_t* a0 = h->a0.as<bf16_t>();
         if (is_u8) {
-            if (f16) stem_im2col_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
-            else stem_im2col_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
+            if (f16) stem_im2col_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, h->lut.as<float>(), a0, batch, S, S0.H);
+            else stem_im2col_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, h->lut.as<float>(), a0, batch, S, S0.H);
         } else {
-            if (f16) stem_im2col_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
-            else stem_im2col_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, S0.H);
+            if (f16) stem_im2col_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, nullptr, a0, batch, S, S0.H);
+            else stem_im2col_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, nullptr, a0, batch, S, S0.H);
         }
         HIPTS_LAUNCH_CHECK();
         g = GemmArgs{};
@@ -331,9 +383,10 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
                 g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
                 g.out_bf16 = h->h1.as<bf16_t>(); g.star_scale = B.s1; g.star_bias = B.b1;
                 HIPTS_TRY(gemm(EPI_STAR, g, s));
-                const int64_t thr = (int64_t)M * (2 * C / 8);
-                if (f16) dwconv7_kernel<true><<<ceil_div(thr, 256), 256, 0, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), batch, H, 2 * C);
-                else dwconv7_kernel<false><<<ceil_div(thr, 256), 256, 0, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), batch, H, 2 * C);
+                const int tiles_x = ceil_div(H, DW_TW), tiles_y = ceil_div(H, DW_TH);
+                const int dw_grid = batch * tiles_y * tiles_x * (2 * C / DW_CS);
+                if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), H, 2 * C, tiles_x, tiles_y);
+                else dwconv7_kernel<false><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), H, 2 * C, tiles_x, tiles_y);
                 HIPTS_LAUNCH_CHECK();
                 g = GemmArgs{};
                 g.f16 = f16;
@@ -452,7 +505,13 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
     h->flops_per_image = flops;
     int st = 0;
     std::vector<float> z(4096, 0.f);
-    if ((st = upload_f32(h->zeros, z.data(), z.size())) || (st = h->a0.alloc((size_t)B * h->st[0].T * STEM_K * 2)) ||
+    std::vector<float> lut(3 * 256);
+    {
+        const double mean[3] = {0.48145466, 0.4578275, 0.40821073}, stdv[3] = {0.26862954, 0.26130258, 0.27577711};   // gen_cfeatures.py:103-104
+        for (int cc = 0; cc < 3; ++cc)
+            for (int u = 0; u < 256; ++u) lut[cc * 256 + u] = (float)(((double)((float)u / 255.0f) - mean[cc]) / stdv[cc]);
+    }
+    if ((st = upload_f32(h->zeros, z.data(), z.size())) || (st = upload_f32(h->lut, lut.data(), lut.size())) || (st = h->a0.alloc((size_t)B * h->st[0].T * STEM_K * 2)) ||
         (st = h->x.alloc(max_x * 4)) || (st = h->xn.alloc(max_x * 2)) || (st = h->h1.alloc(max_2c * 2)) || (st = h->h2.alloc(max_2c * 2)) ||
         (st = h->m1.alloc(max_4c * 2)) || (st = h->col.alloc(max_col * 2)) || (st = h->q.alloc(max_qk * 2)) || (st = h->k.alloc(max_qk * 2)) ||
         (st = h->vT.alloc(max_qk * 2)) || (st = h->feat.alloc((size_t)B * cfg->dims[3] * 4))) {
@@ -467,6 +526,12 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
     if (e != hipSuccess) {
         delete h;
         return set_error(HIPTS_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dwconv7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dwconv7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    if (e != hipSuccess) {
+        delete h;
+        return set_error(HIPTS_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     }
     auto need = [&](const std::string& k) { h->missing.push_back(k); };
     need("stem.conv.weight"); need("stem.conv.bias"); need("stem.norm.weight"); need("head.norm.weight"); need("head.norm.bias");

@@ -59,3 +59,39 @@ def test_tagging_genmodel_query_pipeline(tmp_path, monkeypatch):
     assert all(tag in docs[d] for d, _ in req)                     # required tag really required
     with pytest.raises(KeyError):
         search.find_similar_documents("definitely_not_a_tag", topn=5)   # webui.py:371 behaviour
+
+
+def test_gen_cfeatures_cli_builds_and_extends_the_feature_index(tmp_path, monkeypatch):
+    """gen_cfeatures.py --dir D [--after DATE]: paths csv + unit-normalised feature index, then an --after append."""
+    from PIL import Image
+    from hiptagsearch.index import Similarity
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("imgs/sub")
+    rng = np.random.default_rng(1)
+    for i in range(7):
+        Image.fromarray(rng.integers(0, 256, (50 + i, 70, 3), dtype=np.uint8)).save("imgs/%s%02d.png" % ("sub/" if i % 2 else "", i))
+    open("imgs/broken.png", "wb").write(b"not a png")                      # failed loads are skipped, not fatal
+    cli = os.path.join(PKG, "gen_cfeatures.py")
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--batch", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    paths = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
+    assert len(paths) == 7 and all(p.endswith(".png") and "broken" not in p for p in paths)
+    idx = Similarity.load("charactor-featues-idx")
+    assert len(idx) == 7 and idx.num_features == 768
+    m = idx.matrix()
+    np.testing.assert_allclose(np.linalg.norm(m, axis=1), 1.0, atol=1e-5)  # rows are unit vectors (gensim normalises on add)
+    sims = idx.query(m[3])[0]
+    assert int(np.argmax(sims)) == 3 and sims[3] == pytest.approx(1.0, abs=1e-5)
+    # the same image encodes to the same row whatever batch it was in
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "2000-01-01", "--batch", "8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    idx2 = Similarity.load("charactor-featues-idx")
+    assert len(idx2) == 14 and os.path.exists("charactor-featues-idx.bak")
+    m2 = idx2.matrix()
+    p2 = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
+    assert p2[:7] == paths
+    for i, p in enumerate(paths):
+        j = 7 + p2[7:].index(p)
+        np.testing.assert_allclose(m2[j], m[i], atol=1e-6)
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "not-a-date"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid date format" in r.stdout
