@@ -19,6 +19,7 @@
 // im2col gathers, bias-free LayerNorm, pooled LayerNorm head.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,9 @@ struct hipts_ccip {
     std::vector<std::string> missing;
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, h1, h2, m1, col, q, k, vT, feat;
+    size_t px = 0, p2c = 0, p4c = 0, pcol = 0, pqk = 0;   // per-image element strides of the workspace buffers (largest stage)
+    hipStream_t sub[2] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {};
     double flops_per_image = 0.0;
 };
 
@@ -310,28 +314,26 @@ int upload_f32(DevBuf& buf, const float* data, size_t n) {
 // y = act(A W^T) helpers over the shared persistent GEMM
 int gemm(GemmEpilogue epi, GemmArgs& g, hipStream_t s) { return launch_gemm(epi, g, s); }
 
-int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is_u8, int batch, float* out, int out_memspace,
-                      hipStream_t s) {
-    HIPTS_REQUIRE(h && input && out && batch >= 1, "hipts_ccip_forward: bad arguments");
-    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
-    if (!h->missing.empty())
-        return set_error(HIPTS_ERR_STATE, "hipts_ccip_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
-                         h->missing[0].c_str());
-    HIPTS_TRY(use_device(h->device));
+// The whole kernel sequence for images [i0, i0 + nb) on stream s.  Every workspace buffer is carved per image
+// with the stride of the LARGEST stage, so that sub-batches on different streams never share bytes even when
+// they are in different stages at the same time.
+int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int batch, float* f_dev, hipStream_t s, bool shared_chip) {
     const auto& c = h->cfg;
     const int S = c.image_size;
     const bool f16 = c.operand_f16 != 0;
     const float* zeros = h->zeros.as<float>();
-
-    const void* in_dev = input;
-    if (in_memspace != HIPTS_DEVICE) {
-        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
-        HIPTS_TRY(h->img_in.reserve(bytes));
-        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
-        in_dev = h->img_in.p;
-    }
-    float* x = h->x.as<float>();
-    bf16_t* xn = h->xn.as<bf16_t>();
+    const size_t img_bytes = (size_t)S * S * 3 * (is_u8 ? 1 : 4);
+    in_dev = (const char*)in_dev + (size_t)i0 * img_bytes;
+    float* x = h->x.as<float>() + (size_t)i0 * h->px;
+    bf16_t* xn = h->xn.as<bf16_t>() + (size_t)i0 * h->px;
+    bf16_t* h1 = h->h1.as<bf16_t>() + (size_t)i0 * h->p2c;
+    bf16_t* h2 = h->h2.as<bf16_t>() + (size_t)i0 * h->p2c;
+    bf16_t* m1 = h->m1.as<bf16_t>() + (size_t)i0 * h->p4c;
+    bf16_t* col = h->col.as<bf16_t>() + (size_t)i0 * h->pcol;
+    bf16_t* qb = h->q.as<bf16_t>() + (size_t)i0 * h->pqk;
+    bf16_t* kb = h->k.as<bf16_t>() + (size_t)i0 * h->pqk;
+    bf16_t* vb = h->vT.as<bf16_t>() + (size_t)i0 * h->pqk;
+    bf16_t* a0 = h->a0.as<bf16_t>() + (size_t)i0 * h->st[0].T * STEM_K;
     GemmArgs g;
 
     // ---- stem: conv 7x7 s4 p2 (+bias) -> bias-free LN = residual stream of stage 0
@@ -339,7 +341,6 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
         const Stage& S0 = h->st[0];
         const int64_t M = (int64_t)batch * S0.T;
         const int blocks = ceil_div(M * 7, 256);
-        bf16_t* a0 = h->a0.as<bf16_t>();
         if (is_u8) {
             if (f16) stem_im2col_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, h->lut.as<float>(), a0, batch, S, S0.H);
             else stem_im2col_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, h->lut.as<float>(), a0, batch, S, S0.H);
@@ -350,6 +351,7 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
         HIPTS_LAUNCH_CHECK();
         g = GemmArgs{};
         g.f16 = f16;
+        g.shared_chip = shared_chip;
         g.A = a0; g.W = h->stem_w.as<bf16_t>(); g.M = (int)M; g.N = S0.C; g.K = STEM_K;
         g.bias = h->stem_b.as<float>(); g.out_f32 = x;
         HIPTS_TRY(gemm(EPI_BIAS, g, s));
@@ -366,13 +368,23 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
             const Stage& Pv = h->st[si - 1];
             HIPTS_TRY(launch_layernorm(x, St.ds_norm.as<float>(), nullptr, xn, (int64_t)batch * Pv.T, Pv.C, c.ln_eps, f16, s));
             const int64_t chunks = (int64_t)M * 9 * (Pv.C / 8);
-            ds_im2col_kernel<<<ceil_div(chunks, 256), 256, 0, s>>>(xn, h->col.as<bf16_t>(), batch, Pv.H, Pv.C);
+            ds_im2col_kernel<<<ceil_div(chunks, 256), 256, 0, s>>>(xn, col, batch, Pv.H, Pv.C);
             HIPTS_LAUNCH_CHECK();
             g = GemmArgs{};
             g.f16 = f16;
-            g.A = h->col.as<bf16_t>(); g.W = St.ds_w.as<bf16_t>(); g.M = M; g.N = C; g.K = 9 * Pv.C;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
+            g.A = col; g.W = St.ds_w.as<bf16_t>(); g.M = M; g.N = C; g.K = 9 * Pv.C;
             g.bias = St.ds_b.as<float>(); g.out_f32 = x;
             HIPTS_TRY(gemm(EPI_BIAS, g, s));
+        }
+        if (si >= c.attn_from_stage && Tp != T) {
+            // the padded token rows of this stage's q / k / v^T layouts must be zero (finite at least): the
+            // same bytes held another stage's values before
+            const size_t bytes = (size_t)batch * Tp * C * 2;
+            HIPTS_HIP(hipMemsetAsync(qb, 0, bytes, s));
+            HIPTS_HIP(hipMemsetAsync(kb, 0, bytes, s));
+            HIPTS_HIP(hipMemsetAsync(vb, 0, bytes, s));
         }
         for (Block& B : St.blocks) {
             HIPTS_TRY(launch_layernorm(x, B.n1.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
@@ -380,17 +392,23 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
                 // SepConv: 1x1 (C -> 2C) + StarReLU -> depthwise 7x7 -> 1x1 (2C -> C) + residual
                 g = GemmArgs{};
                 g.f16 = f16;
+                g.shared_chip = shared_chip;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
                 g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
-                g.out_bf16 = h->h1.as<bf16_t>(); g.star_scale = B.s1; g.star_bias = B.b1;
+                g.out_bf16 = h1; g.star_scale = B.s1; g.star_bias = B.b1;
                 HIPTS_TRY(gemm(EPI_STAR, g, s));
                 const int tiles_x = ceil_div(H, DW_TW), tiles_y = ceil_div(H, DW_TH);
                 const int dw_grid = batch * tiles_y * tiles_x * (2 * C / DW_CS);
-                if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), H, 2 * C, tiles_x, tiles_y);
-                else dwconv7_kernel<false><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h->h1.as<bf16_t>(), B.dw.as<float>(), h->h2.as<bf16_t>(), H, 2 * C, tiles_x, tiles_y);
+                if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
+                else dwconv7_kernel<false><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
                 HIPTS_LAUNCH_CHECK();
                 g = GemmArgs{};
                 g.f16 = f16;
-                g.A = h->h2.as<bf16_t>(); g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = 2 * C; g.bias = zeros; g.out_f32 = x;
+                g.shared_chip = shared_chip;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
+                g.A = h2; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = 2 * C; g.bias = zeros; g.out_f32 = x;
                 if (B.has_rs1) {
                     g.res_scale = B.rs1.as<float>();
                     HIPTS_TRY(gemm(EPI_RESCALE, g, s));
@@ -401,22 +419,31 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
                 const int heads = C / c.head_dim;
                 g = GemmArgs{};
                 g.f16 = f16;
+                g.shared_chip = shared_chip;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
                 g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
-                g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
+                g.out_bf16 = qb; g.out2_bf16 = kb;
                 g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
                 g.qscale = 0.17677669529663687f * 1.4426950408889634f;      // 32^-0.5 * log2(e): attention works in base 2
                 HIPTS_TRY(gemm(EPI_QK, g, s));
                 g = GemmArgs{};
                 g.f16 = f16;
+                g.shared_chip = shared_chip;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
                 g.A = xn; g.W = B.w_in.as<bf16_t>() + (size_t)2 * C * C; g.M = M; g.N = C; g.K = C; g.bias = zeros;
-                g.out_bf16 = h->vT.as<bf16_t>();
+                g.out_bf16 = vb;
                 g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
                 HIPTS_TRY(gemm(EPI_VT, g, s));
-                HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->h1.as<bf16_t>(), batch, heads, T, Tp,
+                HIPTS_TRY(launch_attention(qb, kb, vb, h1, batch, heads, T, Tp,
                                            f16, s, 32));
                 g = GemmArgs{};
                 g.f16 = f16;
-                g.A = h->h1.as<bf16_t>(); g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = C; g.bias = zeros; g.out_f32 = x;
+                g.shared_chip = shared_chip;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
+                g.A = h1; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = C; g.bias = zeros; g.out_f32 = x;
                 if (B.has_rs1) {
                     g.res_scale = B.rs1.as<float>();
                     HIPTS_TRY(gemm(EPI_RESCALE, g, s));
@@ -428,12 +455,16 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
             HIPTS_TRY(launch_layernorm(x, B.n2.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
             g = GemmArgs{};
             g.f16 = f16;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
             g.A = xn; g.W = B.fc1.as<bf16_t>(); g.M = M; g.N = 4 * C; g.K = C; g.bias = zeros;
-            g.out_bf16 = h->m1.as<bf16_t>(); g.star_scale = B.s2; g.star_bias = B.b2;
+            g.out_bf16 = m1; g.star_scale = B.s2; g.star_bias = B.b2;
             HIPTS_TRY(gemm(EPI_STAR, g, s));
             g = GemmArgs{};
             g.f16 = f16;
-            g.A = h->m1.as<bf16_t>(); g.W = B.fc2.as<bf16_t>(); g.M = M; g.N = C; g.K = 4 * C; g.bias = zeros; g.out_f32 = x;
+            g.shared_chip = shared_chip;
+        g.shared_chip = shared_chip;
+            g.A = m1; g.W = B.fc2.as<bf16_t>(); g.M = M; g.N = C; g.K = 4 * C; g.bias = zeros; g.out_f32 = x;
             if (B.has_rs2) {
                 g.res_scale = B.rs2.as<float>();
                 HIPTS_TRY(gemm(EPI_RESCALE, g, s));
@@ -444,12 +475,57 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
     }
     // ---- head: global average pool -> LayerNorm
     const Stage& L = h->st[3];
+    pool_ln_kernel<<<batch, 256, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev + (size_t)i0 * L.C, L.T, L.C, c.ln_eps);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is_u8, int batch, float* out, int out_memspace,
+                      hipStream_t s) {
+    HIPTS_REQUIRE(h && input && out && batch >= 1, "hipts_ccip_forward: bad arguments");
+    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
+    if (!h->missing.empty())
+        return set_error(HIPTS_ERR_STATE, "hipts_ccip_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
+                         h->missing[0].c_str());
+    HIPTS_TRY(use_device(h->device));
+    const auto& c = h->cfg;
+    const int S = c.image_size;
+    const void* in_dev = input;
+    if (in_memspace != HIPTS_DEVICE) {
+        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
+        HIPTS_TRY(h->img_in.reserve(bytes));
+        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
+        in_dev = h->img_in.p;
+    }
     const bool dev_out = out_memspace == HIPTS_DEVICE;
     float* f_dev = dev_out ? out : h->feat.as<float>();
-    pool_ln_kernel<<<batch, 256, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev, L.T, L.C, c.ln_eps);
-    HIPTS_LAUNCH_CHECK();
+    // Two sub-batches on two internal streams (as in the ViT forward): the late stages have fewer output
+    // tiles than the chip has CUs, and a kernel of one half fills the CUs the other half leaves idle.
+    static const int want_streams = getenv("HIPTS_CCIP_STREAMS") ? atoi(getenv("HIPTS_CCIP_STREAMS")) : 2;
+    // (measured, B36 @384: batch 64 2567 -> 2809 images/s; at the reference's batch of 20 the halves are too small
+    // to gain and the doubled launch count costs, so small batches stay on the caller's stream)
+    const int ns = std::min({want_streams, 2, batch / 16});
+    if (ns >= 2) {
+        if (!h->ev_fork) {
+            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; ++i) {
+                HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking));
+                HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+            }
+        }
+        HIPTS_HIP(hipEventRecord(h->ev_fork, s));
+        const int nb0 = (batch + 1) / 2;
+        for (int i = 0; i < 2; ++i) {
+            HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+            HIPTS_TRY(ccip_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, f_dev, h->sub[i], true));
+            HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
+            HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        }
+    } else {
+        HIPTS_TRY(ccip_run_images(h, in_dev, is_u8, 0, batch, f_dev, s, false));
+    }
     if (!dev_out) {
-        HIPTS_HIP(hipMemcpyAsync(out, f_dev, (size_t)batch * L.C * 4, hipMemcpyDeviceToHost, s));
+        HIPTS_HIP(hipMemcpyAsync(out, f_dev, (size_t)batch * h->st[3].C * 4, hipMemcpyDeviceToHost, s));
         HIPTS_HIP(hipStreamSynchronize(s));
     }
     return HIPTS_OK;
@@ -496,12 +572,17 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
             else flops += 2.0 * T * 2 * C * C * 2 + 2.0 * 49.0 * T * 2 * C;
             flops += 2.0 * T * 4 * C * C * 2;
         }
-        max_x = std::max(max_x, (size_t)B * St.T * St.C);
-        max_2c = std::max(max_2c, (size_t)B * St.T * 2 * St.C);
-        max_4c = std::max(max_4c, (size_t)B * St.T * 4 * St.C);
-        if (s > 0) max_col = std::max(max_col, (size_t)B * St.T * 9 * cfg->dims[s - 1]);
-        if (s >= cfg->attn_from_stage) max_qk = std::max(max_qk, (size_t)B * St.Tp * St.C);
+        h->px = std::max(h->px, (size_t)St.T * St.C);
+        h->p2c = std::max(h->p2c, (size_t)St.T * 2 * St.C);
+        h->p4c = std::max(h->p4c, (size_t)St.T * 4 * St.C);
+        if (s > 0) h->pcol = std::max(h->pcol, (size_t)St.T * 9 * cfg->dims[s - 1]);
+        if (s >= cfg->attn_from_stage) h->pqk = std::max(h->pqk, (size_t)St.Tp * St.C);
     }
+    max_x = (size_t)B * h->px;
+    max_2c = (size_t)B * h->p2c;
+    max_4c = (size_t)B * h->p4c;
+    max_col = std::max(max_col, (size_t)B * h->pcol);
+    max_qk = std::max(max_qk, (size_t)B * h->pqk);
     h->flops_per_image = flops;
     int st = 0;
     std::vector<float> z(4096, 0.f);
@@ -557,6 +638,11 @@ int hipts_ccip_destroy(hipts_ccip_t* h) {
     if (h) {
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
+        for (int i = 0; i < 2; ++i) {
+            if (h->sub[i]) (void)hipStreamDestroy(h->sub[i]);
+            if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+        }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
         delete h;
     }
     return HIPTS_OK;

@@ -154,6 +154,71 @@ def query_section(device):
             "d2v_cpu_port_docs_per_s": d2v_cpu, "d2v_cpu_sample": "%d docs, C oracle, 1 thread (reference: workers=1)" % n_cpu}
 
 
+def ccip_section(device):
+    """BASELINE.json configs[4]: CCIP encoder images/sec (CAFormer-B36 widths @384, bf16 MFMA) + rerank
+    cosine queries/sec over 100k x 768 feature rows, with the CPU port of the encoder beside it."""
+    from hiptagsearch import synth
+    from hiptagsearch.cfeatures import CCIPEncoder
+    from hiptagsearch.index import Similarity
+    from oracle import ccip as occip
+    cfg = dict(synth.CCIP_B36_384)
+    w = synth.ccip_weights(cfg, seed=46)
+    out = {"metric": "CCIP encoder images/sec (CAFormer-B36 @384, bf16 MFMA) + rerank cosine queries/sec over 100k x 768"}
+    for B in (20, 64):                                   # 20 = the reference's batch (gen_cfeatures.py:50)
+        enc = CCIPEncoder(cfg, w, max_batch=B, device=device)
+        imgs = torch.randint(0, 256, (B, 384, 384, 3), dtype=torch.uint8, device="cuda")
+        feats = torch.empty((B, 768), dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            enc.forward_u8(imgs, out=feats)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            enc.forward_u8(imgs, out=feats)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        fl = enc.flops_per_image()
+        out["images_per_s_batch%d" % B] = B / dt
+        out["tflops_batch%d" % B] = B * fl / dt / 1e12
+        out["flops_per_image"] = fl
+        del enc
+    # CPU port: the float32 torch oracle on a bounded sample
+    threads = int(os.environ.get("HIPTS_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+    torch.set_num_threads(threads)
+    x = occip.preprocess_u8_nhwc(synth.images_u8(2, 384, seed=47))
+    tw = occip.to_torch(w)
+    occip.metaformer_forward(tw, x[:1], dims=cfg["dims"], depths=cfg["depths"])
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < 8.0:
+        occip.metaformer_forward(tw, x, dims=cfg["dims"], depths=cfg["depths"])
+        done += 2
+    out["cpu_port_images_per_s"] = done / (time.perf_counter() - t0)
+    out["cpu_port_sample"] = "%d images, torch-CPU float32 oracle, %d threads" % (done, threads)
+    # rerank: cosine of a query feature against 100k unit rows (webui.py:303-335 restated, configs[4])
+    D = 100_000
+    rng = np.random.default_rng(45)
+    rows = rng.standard_normal((D, 768)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    idx = Similarity("ccip-bench", None, 768, device, capacity=D)
+    idx.add_matrix(rows)
+    q = rows[:64].copy()
+    idx.query(q)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        sims = idx.query(q)
+    torch.cuda.synchronize()
+    out["rerank_queries_per_s_batch64"] = 640 / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for i in range(32):
+        idx.query(q[i])
+    out["rerank_queries_per_s_single"] = 32 / (time.perf_counter() - t0)
+    assert int(np.argmax(sims[5])) == 5
+    out["rerank_algorithmic_bytes_per_query"] = D * 768 * 4
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,6 +370,11 @@ def main():
             result["query"] = query_section(local_rank)
         except Exception as e:   # the headline line must still be printed
             result["query"] = {"error": repr(e)}
+    if world == 1 and not args.no_query:
+        try:
+            result["ccip"] = ccip_section(local_rank)
+        except Exception as e:
+            result["ccip"] = {"error": repr(e)}
     if world > 1:
         dist.destroy_process_group()
     print(json.dumps(result), flush=True)

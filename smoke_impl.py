@@ -43,4 +43,14 @@ def run():
     f = osearch.combine(b, osearch.similarity(rows, qv.astype(np.float32)))
     wi, wv = osearch.topk(f, 50)
     assert np.array_equal(gids[0], wi) and gvals[0].tobytes() == wv.tobytes(), "top-k differs from the oracle"
-    print("smoke ok: ViT max|dlogit| = %.2e, tag rows and top-50 identical to the oracle" % err)
+    # CCIP feature encoder (CAFormer): tiny geometry vs the oracle
+    from hiptagsearch.cfeatures import CCIPEncoder
+    from oracle import ccip as occip
+    ccfg = dict(synth.CCIP_TINY)
+    cw = synth.ccip_weights(ccfg, seed=3)
+    cimgs = synth.images_u8(2, ccfg["image_size"], seed=47)
+    feat = CCIPEncoder(ccfg, cw, max_batch=2).forward_u8(cimgs)
+    cwant = occip.metaformer_forward(occip.to_torch(cw), occip.preprocess_u8_nhwc(cimgs), dims=ccfg["dims"], depths=ccfg["depths"]).numpy()
+    cerr = float(np.abs(feat - cwant).max())
+    assert cerr <= 1e-1, "CCIP features differ from the oracle by %g" % cerr
+    print("smoke ok: ViT max|dlogit| = %.2e, tag rows and top-50 identical to the oracle, CCIP max|df| = %.2e" % (err, cerr))
