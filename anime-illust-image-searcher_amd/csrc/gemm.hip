@@ -1143,7 +1143,21 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int variant = gemm_variant();
+    int variant = gemm_variant();
+    if (variant == 1 && EPI != EPI_HEAD && !getenv("HIPTS_GEMM")) {
+        // A launch with fewer 256 x 256 tiles than CUs (the CAFormer's late stages: 11 520 tokens x 512 columns
+        // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
+        // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
+        static int cus0 = 0;
+        if (!cus0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            HIPTS_HIP(hipGetDevice(&dev));
+            HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
+            cus0 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM) variant = 4;
+    }
     HIPTS_REQUIRE(!a.f16 || variant == 1 || variant == 4, "half-precision operands are only built for the pp and dw GEMM loops");
     if (variant == 4) {
         const int tiles_n = (a.N + DW_BN - 1) / DW_BN;

@@ -1,6 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
-timeout -k 10 900 python -m pytest tests/test_gpu_ccip.py -m gpu -x -q 2>&1 | tail -4 || exit 1
-for st in 2 1; do echo "streams=$st"; HIPTS_CCIP_STREAMS=$st timeout -k 10 300 python tools/ccip_bench.py 2>&1 | tail -2; done
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout -k 10 900 python -m pytest tests/test_gpu_ccip.py tests/test_gpu_vit.py -m gpu -x -q 2>&1 | tail -3 || exit 1
+timeout -k 10 300 python tools/ccip_bench.py 2>&1 | tail -2
