@@ -659,6 +659,13 @@ int hipts_bm25_set_idf(hipts_bm25_t* h, const double* idf) {
     return upload(h->d_idf.p, h->h_idf.data(), (size_t)h->V * 8);
 }
 
+int hipts_bm25_set_avgdl(hipts_bm25_t* h, double avgdl) {
+    HIPTS_REQUIRE(h, "null argument");
+    HIPTS_REQUIRE(avgdl > 0.0, "hipts_bm25_set_avgdl: avgdl must be positive");
+    h->avgdl = avgdl;
+    return HIPTS_OK;
+}
+
 int hipts_bm25_score(hipts_bm25_t* h, const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr, int nq,
                      double* scores_out, int out_memspace, void* stream) {
     HIPTS_REQUIRE(h && q_ptr && scores_out && nq >= 1, "hipts_bm25_score: bad arguments");
@@ -780,6 +787,32 @@ int hipts_combine(const double* a, const float* b, int nq, int64_t n, double wa,
     }
     dim3 grid(ceil_div(n, 256), nq);
     combine_kernel<<<grid, 256, 0, s>>>(a, b, n, wa, (float)wb, norm_a ? ma : nullptr, norm_b ? mb : nullptr, nullptr, out);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+int hipts_rowmax(const double* a, const float* b, int nq, int64_t n, double* max_a_out, float* max_b_out, int device,
+                 void* stream) {
+    HIPTS_REQUIRE(nq >= 1 && n >= 1 && (!a || max_a_out) && (!b || max_b_out), "hipts_rowmax: bad arguments");
+    HIPTS_TRY(use_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    if (a) {
+        rowmax_kernel<double><<<nq, 1024, 0, s>>>(a, n, max_a_out);
+        HIPTS_LAUNCH_CHECK();
+    }
+    if (b) {
+        rowmax_kernel<float><<<nq, 1024, 0, s>>>(b, n, max_b_out);
+        HIPTS_LAUNCH_CHECK();
+    }
+    return HIPTS_OK;
+}
+
+int hipts_combine_with_max(const double* a, const float* b, int nq, int64_t n, double wa, double wb, const double* max_a,
+                           const float* max_b, double* out, int device, void* stream) {
+    HIPTS_REQUIRE(a && b && out && nq >= 1 && n >= 1, "hipts_combine_with_max: bad arguments");
+    HIPTS_TRY(use_device(device));
+    dim3 grid(ceil_div(n, 256), nq);
+    combine_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, b, n, wa, (float)wb, max_a, max_b, nullptr, out);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }

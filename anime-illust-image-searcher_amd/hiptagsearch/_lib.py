@@ -64,6 +64,7 @@ _SIGNATURES = {
     "hipts_bm25_info": [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_double)],
     "hipts_bm25_export": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "hipts_bm25_set_idf": [c_void_p, c_void_p],
+    "hipts_bm25_set_avgdl": [c_void_p, c_double],
     "hipts_bm25_score": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "hipts_index_create": [c_int, c_int64, c_int, POINTER(c_void_p)],
     "hipts_index_destroy": [c_void_p],
@@ -73,6 +74,8 @@ _SIGNATURES = {
     "hipts_index_data": [c_void_p, POINTER(c_void_p)],
     "hipts_index_query": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     "hipts_combine": [c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_int, c_int, c_void_p, c_int, c_void_p],
+    "hipts_rowmax": [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p],
+    "hipts_combine_with_max": [c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_topk": [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                      c_void_p, c_void_p, c_void_p, c_void_p],

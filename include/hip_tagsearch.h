@@ -193,6 +193,9 @@ int hipts_bm25_export(const hipts_bm25_t* h, int64_t* csr_ptr, int32_t* csr_term
  * (genmodel.py:81); a caller that holds the reference's own `bm25_idf` pickle, or wants
  * bit-identical pickles, sets those values here. */
 int hipts_bm25_set_idf(hipts_bm25_t* h, const double* idf);
+/* Replace avgdl (genmodel.py:76).  A handle built over one shard of the documents scores with the
+ * statistics of the WHOLE corpus: the caller installs the global idf table and the global avgdl. */
+int hipts_bm25_set_avgdl(hipts_bm25_t* h, double avgdl);
 /* nq queries; query i has terms q_terms[q_ptr[i]..q_ptr[i+1]) with weights q_weights[...] in the
  * iteration order of the reference's dict (webui.py:139).  weight < 0: exclude, weight > 1000:
  * required with weight-1000 (webui.py:154-170).  scores_out: float64 [nq][num_docs]. */
@@ -226,6 +229,14 @@ int hipts_index_query(hipts_index_t* h, const float* queries, int queries_memspa
  * max > 0 else a[q][d] (float64) and B likewise on the float32 b.  out may alias a. */
 int hipts_combine(const double* a, const float* b, int nq, int64_t n, double wa, double wb,
                   int norm_a, int norm_b, double* out, int device, void* stream);
+/* The same in two steps, for an index whose rows are sharded over ranks: every rank
+ * takes the row maxima of its shard (device pointers in and out; a or b may be NULL), the ranks
+ * all-reduce them with MAX, and combine_with_max normalises by the maxima it is GIVEN (NULL = do not
+ * normalise that operand), with exactly the arithmetic of hipts_combine. */
+int hipts_rowmax(const double* a, const float* b, int nq, int64_t n, double* max_a_out, float* max_b_out, int device,
+                 void* stream);
+int hipts_combine_with_max(const double* a, const float* b, int nq, int64_t n, double wa, double wb, const double* max_a,
+                           const float* max_b, double* out, int device, void* stream);
 /* per query the k best entries of vals[q][0..n): ids_out int32 [nq][k], vals_out float64
  * [nq][k], in rank order (value descending, ties by ascending index).  k <= 1024.
  * vals is device memory; outputs in out_memspace. */

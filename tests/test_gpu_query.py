@@ -276,3 +276,55 @@ def test_cfeatures_rerank_cosine():
     assert res[0] == (7, 0.9)
     assert set(ids) == {i for i in list(range(100, 140)) + [7] if i % 2 == 0}
     assert all(res[i][1] >= res[i + 1][1] for i in range(1, len(res) - 1))
+
+
+# ---------------------------------------------------------------- sharded index (query partitioning)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_query_is_bit_identical_to_unsharded(world):
+    """All shards on this one GPU, the collectives replaced by their definition (max over ranks, concatenation)."""
+    import torch
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from hiptagsearch.shard import ShardedSearchEngine, global_bm25_stats, merge_topk
+    V, D, K, k = 600, 4001, 300, 100
+    ptr, terms = synth.tag_corpus(D, V, seed=11)
+    rows = synth.index_vectors(D, K, seed=12)
+    qs = [dict(q) for q in synth.queries(40, V, seed=13)]
+    qv = np.random.default_rng(14).standard_normal((len(qs), K)).astype(np.float32)
+    stats = global_bm25_stats(ptr, terms, V)
+    shards = [ShardedSearchEngine(ptr, terms, V, rows, r, world, stats=stats) for r in range(world)]
+    local = [s.local_scores(qs, qv) for s in shards]
+    max_a = torch.stack([l[2] for l in local]).max(dim=0).values           # all-reduce(MAX)
+    max_b = torch.stack([l[3] for l in local]).max(dim=0).values
+    cands = [s.local_topk(l[0], l[1], max_a, max_b, k) for s, l in zip(shards, local)]
+    ids, vals = merge_topk([c[0] for c in cands], [c[1] for c in cands], k)   # all-gather + merge
+    bm = BM25Index(ptr, terms, V)
+    idx = Similarity("whole", None, K, capacity=D)
+    idx.add_matrix(rows)
+    wi, wv = SearchEngine(None, idx, {}, bm, []).score_topk(qs, qv, k)
+    assert np.array_equal(ids, wi.astype(np.int64))
+    assert vals.tobytes() == wv.tobytes()
+    # the shard handles really carry the global statistics
+    assert float(shards[-1].bm25.export()["idf"][5]).hex() == float(bm.export()["idf"][5]).hex()
+
+
+def test_sharded_query_two_processes_gloo():
+    """Two ranks (both on this GPU, gloo) through ShardedSearchEngine.score_topk with real collectives."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tools", "sharded_query_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    assert "identical to the unsharded engine" in outs[0]
