@@ -117,6 +117,68 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const void* __restrict
     }
 }
 
+// The uint8 entry point's version: a workgroup owns 64 adjacent output pixels of one output row.  It loads
+// the 7 x (64*4+3) x 3 input bytes they touch with coalesced byte loads into LDS, builds the 64 patch rows
+// (hi | lo halves, zero pad columns included) in LDS through the normalisation table, and writes them out
+// as ONE contiguous 40 KB block with 16 B stores (consecutive pixels are consecutive rows of A0).  The
+// one-thread-per-kernel-row version above spends its time on scattered byte loads and 2-byte stores
+// (628 us for 64 images).
+template <bool F16>
+__global__ __launch_bounds__(256) void stem_im2col_u8_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut,
+                                                             bf16_t* __restrict__ a0, int S, int H0, int xtiles) {
+    constexpr int TW = (64 * 4 + 3) * 3;        // 777 bytes per input row of the tile
+    __shared__ float slut[3 * 256];
+    __shared__ uint8_t tile[7][TW + 7];
+    __shared__ __attribute__((aligned(16))) bf16_t orow[64][STEM_K];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int xt = bid % xtiles;
+    bid /= xtiles;
+    const int oy = bid % H0;
+    const int64_t b = bid / H0;
+    const int ox0 = xt * 64, ix0 = 4 * ox0 - 2, iy0 = 4 * oy - 2;
+    for (int i = tid; i < 3 * 256; i += 256) slut[i] = lut[i];
+    for (int i = tid; i < 7 * TW; i += 256) {
+        const int ry = i / TW, c = i - ry * TW;
+        const int iy = iy0 + ry, ix = ix0 + c / 3;
+        tile[ry][c] = (iy >= 0 && iy < S && ix >= 0 && ix < S) ? img[((b * S + iy) * S + ix0) * 3 + c] : (uint8_t)0;
+    }
+    for (int i = tid; i < 64 * 2 * (STEM_KH - 147); i += 256) {        // the pad columns of both halves
+        const int t = i / (2 * (STEM_KH - 147)), r = i - t * (2 * (STEM_KH - 147));
+        const int half = r / (STEM_KH - 147), c = r - half * (STEM_KH - 147);
+        orow[t][half * STEM_KH + 147 + c] = to_op<F16>(0.f);
+    }
+    __syncthreads();
+    const int tok = tid & 63, part = tid >> 6;
+    const int ox = ox0 + tok;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ky = part + 4 * kk;
+        if (ky >= 7) break;
+        const int iy = iy0 + ky;
+        const bool iny = iy >= 0 && iy < S;
+        bf16_t* row = &orow[tok][ky * 21];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = 4 * ox - 2 + kx;
+            const bool in = iny && ix >= 0 && ix < S;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = in ? slut[c * 256 + tile[ky][(tok * 4 + kx) * 3 + c]] : 0.f;
+                const bf16_t hi = to_op<F16>(v);
+                row[kx * 3 + c] = hi;
+                row[STEM_KH + kx * 3 + c] = to_op<F16>(v - from_op<F16>(hi));
+            }
+        }
+    }
+    __syncthreads();
+    const int ntok = H0 - ox0 < 64 ? H0 - ox0 : 64;
+    const int64_t m0 = (b * H0 + oy) * H0 + ox0;
+    const uint4* src = reinterpret_cast<const uint4*>(&orow[0][0]);
+    uint4* dst = reinterpret_cast<uint4*>(a0 + m0 * STEM_K);
+    for (int i = tid; i < ntok * (STEM_K * 2 / 16); i += 256) dst[i] = src[i];
+}
+
 // Bias-free LayerNorm of float32 rows, in place (the stem's norm: its output IS the residual stream).
 __global__ __launch_bounds__(256) void ln_inplace_kernel(float* __restrict__ x, const float* __restrict__ g, int64_t rows, int D,
                                                          float eps) {
@@ -266,38 +328,51 @@ __global__ __launch_bounds__(256) void ds_im2col_kernel(const bf16_t* __restrict
     *reinterpret_cast<uint4*>(col + (m * 9 + tap) * C + g * 8) = v;
 }
 
-// Head: out[b][:] = LN(mean over the T tokens of x[b])  (with bias).  One workgroup per image.
-__global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                      const float* __restrict__ bta, float* __restrict__ out, int T, int C, float eps) {
+// Head: out[b][:] = LN(mean over the T tokens of x[b])  (with bias).  One 1024-thread workgroup per image:
+// four row groups x 256 channel threads sum a quarter of the tokens each (the loop is load-latency bound,
+// so more rows in flight is what matters), partial sums meet in LDS, the first 256 threads normalise.
+__global__ __launch_bounds__(1024) void pool_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ bta, float* __restrict__ out, int T, int C, float eps) {
+    __shared__ float part[4][1024];
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x & 255, rg = threadIdx.x >> 8;
     const float* xb = x + (int64_t)b * T * C;
     float m[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int r = 0; r < T; ++r)            // 8 rows x 4 loads in flight: the loop is latency-bound otherwise
+#pragma unroll 4
+    for (int r = rg; r < T; r += 4)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = tid + 256 * u;
             if (c < C) m[u] += xb[(int64_t)r * C + c];
         }
-    float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        m[u] /= (float)T;
-        if (tid + 256 * u < C) s += m[u];
+    for (int u = 0; u < 4; ++u) part[rg][tid + 256 * u] = m[u];
+    __syncthreads();
+    // (every thread keeps walking to the barriers; only row group 0 does the arithmetic)
+    float s = 0.f;
+    if (rg == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            m[u] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / (float)T;
+            if (c < C) s += m[u];
+        }
+        s = wave_sum_f(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
     }
-    s = wave_sum_f(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
     __syncthreads();
-    float ss = 0.f;
+    if (rg == 0) {
+        float ss = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (tid + 256 * u < C) ss += (m[u] - mean) * (m[u] - mean);
-    ss = wave_sum_f(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
+        for (int u = 0; u < 4; ++u)
+            if (tid + 256 * u < C) ss += (m[u] - mean) * (m[u] - mean);
+        ss = wave_sum_f(ss);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+    }
     __syncthreads();
+    if (rg != 0) return;
     const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)C + eps);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -342,8 +417,10 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         const int64_t M = (int64_t)batch * S0.T;
         const int blocks = ceil_div(M * 7, 256);
         if (is_u8) {
-            if (f16) stem_im2col_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, h->lut.as<float>(), a0, batch, S, S0.H);
-            else stem_im2col_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, h->lut.as<float>(), a0, batch, S, S0.H);
+            const int xtiles = ceil_div(S0.H, 64);
+            const int grid_u8 = batch * S0.H * xtiles;
+            if (f16) stem_im2col_u8_kernel<true><<<grid_u8, 256, 0, s>>>((const uint8_t*)in_dev, h->lut.as<float>(), a0, S, S0.H, xtiles);
+            else stem_im2col_u8_kernel<false><<<grid_u8, 256, 0, s>>>((const uint8_t*)in_dev, h->lut.as<float>(), a0, S, S0.H, xtiles);
         } else {
             if (f16) stem_im2col_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, nullptr, a0, batch, S, S0.H);
             else stem_im2col_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, nullptr, a0, batch, S, S0.H);
@@ -475,7 +552,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     }
     // ---- head: global average pool -> LayerNorm
     const Stage& L = h->st[3];
-    pool_ln_kernel<<<batch, 256, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev + (size_t)i0 * L.C, L.T, L.C, c.ln_eps);
+    pool_ln_kernel<<<batch, 1024, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev + (size_t)i0 * L.C, L.T, L.C, c.ln_eps);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
