@@ -410,6 +410,18 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     bf16_t* vb = h->vT.as<bf16_t>() + (size_t)i0 * h->pqk;
     bf16_t* a0 = h->a0.as<bf16_t>() + (size_t)i0 * h->st[0].T * STEM_K;
     GemmArgs g;
+    bool xn_ready = false;          // xn already holds the LayerNorm the next consumer needs
+    // x = rs * x + A W^T, optionally followed in the same epilogue by xn = LN(x) * gamma
+    auto residual = [&](GemmArgs& ga, const float* rs, const float* gamma) -> int {
+        ga.res_scale = rs;
+        if (gamma) {
+            ga.ln_gamma = gamma;
+            ga.ln_eps = c.ln_eps;
+            ga.out_bf16 = xn;
+            return launch_gemm(EPI_RESID_LN, ga, s);
+        }
+        return launch_gemm(rs ? EPI_RESCALE : EPI_RESID, ga, s);
+    };
 
     // ---- stem: conv 7x7 s4 p2 (+bias) -> bias-free LN = residual stream of stage 0
     {
@@ -443,14 +455,14 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         if (si > 0) {
             // downsample: LN(x) -> 3x3 s2 p1 conv (+bias) -> x
             const Stage& Pv = h->st[si - 1];
-            HIPTS_TRY(launch_layernorm(x, St.ds_norm.as<float>(), nullptr, xn, (int64_t)batch * Pv.T, Pv.C, c.ln_eps, f16, s));
+            if (!xn_ready) HIPTS_TRY(launch_layernorm(x, St.ds_norm.as<float>(), nullptr, xn, (int64_t)batch * Pv.T, Pv.C, c.ln_eps, f16, s));
+            xn_ready = false;
             const int64_t chunks = (int64_t)M * 9 * (Pv.C / 8);
             ds_im2col_kernel<<<ceil_div(chunks, 256), 256, 0, s>>>(xn, col, batch, Pv.H, Pv.C);
             HIPTS_LAUNCH_CHECK();
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
             g.A = col; g.W = St.ds_w.as<bf16_t>(); g.M = M; g.N = C; g.K = 9 * Pv.C;
             g.bias = St.ds_b.as<float>(); g.out_f32 = x;
             HIPTS_TRY(gemm(EPI_BIAS, g, s));
@@ -463,15 +475,22 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
             HIPTS_HIP(hipMemsetAsync(kb, 0, bytes, s));
             HIPTS_HIP(hipMemsetAsync(vb, 0, bytes, s));
         }
-        for (Block& B : St.blocks) {
-            HIPTS_TRY(launch_layernorm(x, B.n1.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
+        // A stage whose rows fit one 256-wide GEMM tile gets its LayerNorms from the epilogue of the residual GEMM
+        // that produces the row (EPI_RESID_LN): the separate pass over the fp32 stream is the largest HBM
+        // consumer of the wide early stages.
+        const bool fuse_ln = C <= 256 && !getenv("HIPTS_CCIP_NO_LN_FUSION");
+        for (size_t bi = 0; bi < St.blocks.size(); ++bi) {
+            Block& B = St.blocks[bi];
+            if (!xn_ready) HIPTS_TRY(launch_layernorm(x, B.n1.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
+            xn_ready = false;
+            // LayerNorm that follows this block's MLP: the next block's norm1, or the next stage's downsample norm
+            const float* next_gamma = bi + 1 < St.blocks.size() ? St.blocks[bi + 1].n1.as<float>()
+                                      : (si < 3 ? h->st[si + 1].ds_norm.as<float>() : nullptr);
             if (!B.attn) {
                 // SepConv: 1x1 (C -> 2C) + StarReLU -> depthwise 7x7 -> 1x1 (2C -> C) + residual
                 g = GemmArgs{};
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
-            g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
                 g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
                 g.out_bf16 = h1; g.star_scale = B.s1; g.star_bias = B.b1;
                 HIPTS_TRY(gemm(EPI_STAR, g, s));
@@ -483,22 +502,13 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g = GemmArgs{};
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
-            g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
                 g.A = h2; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = 2 * C; g.bias = zeros; g.out_f32 = x;
-                if (B.has_rs1) {
-                    g.res_scale = B.rs1.as<float>();
-                    HIPTS_TRY(gemm(EPI_RESCALE, g, s));
-                } else {
-                    HIPTS_TRY(gemm(EPI_RESID, g, s));
-                }
+                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr));
             } else {
                 const int heads = C / c.head_dim;
                 g = GemmArgs{};
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
-            g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
                 g.A = xn; g.W = B.w_in.as<bf16_t>(); g.M = M; g.N = 2 * C; g.K = C; g.bias = zeros;
                 g.out_bf16 = qb; g.out2_bf16 = kb;
                 g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
@@ -507,8 +517,6 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g = GemmArgs{};
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
-            g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
                 g.A = xn; g.W = B.w_in.as<bf16_t>() + (size_t)2 * C * C; g.M = M; g.N = C; g.K = C; g.bias = zeros;
                 g.out_bf16 = vb;
                 g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
@@ -518,36 +526,24 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g = GemmArgs{};
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
-            g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
                 g.A = h1; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = C; g.bias = zeros; g.out_f32 = x;
-                if (B.has_rs1) {
-                    g.res_scale = B.rs1.as<float>();
-                    HIPTS_TRY(gemm(EPI_RESCALE, g, s));
-                } else {
-                    HIPTS_TRY(gemm(EPI_RESID, g, s));
-                }
+                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr));
             }
             // MLP: fc1 + StarReLU, fc2 + residual
-            HIPTS_TRY(launch_layernorm(x, B.n2.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
+            if (!fuse_ln) HIPTS_TRY(launch_layernorm(x, B.n2.as<float>(), nullptr, xn, M, C, c.ln_eps, f16, s));
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
             g.A = xn; g.W = B.fc1.as<bf16_t>(); g.M = M; g.N = 4 * C; g.K = C; g.bias = zeros;
             g.out_bf16 = m1; g.star_scale = B.s2; g.star_bias = B.b2;
             HIPTS_TRY(gemm(EPI_STAR, g, s));
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
-        g.shared_chip = shared_chip;
             g.A = m1; g.W = B.fc2.as<bf16_t>(); g.M = M; g.N = C; g.K = 4 * C; g.bias = zeros; g.out_f32 = x;
-            if (B.has_rs2) {
-                g.res_scale = B.rs2.as<float>();
-                HIPTS_TRY(gemm(EPI_RESCALE, g, s));
-            } else {
-                HIPTS_TRY(gemm(EPI_RESID, g, s));
-            }
+            const bool fuse_next = fuse_ln && next_gamma != nullptr;
+            HIPTS_TRY(residual(g, B.has_rs2 ? B.rs2.as<float>() : nullptr, fuse_next ? next_gamma : nullptr));
+            xn_ready = fuse_next;
         }
     }
     // ---- head: global average pool -> LayerNorm

@@ -120,7 +120,7 @@ __device__ __forceinline__ f32x4 star_relu4(f32x4 x, float s, float b) {
 // latencies overlap instead of forming a chain of 32 dependent round trips.
 template <int EPI, int MR = 8, bool F16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                              int lane, const f32x4* bias_pre = nullptr) {
+                                              int lane, const f32x4* bias_pre = nullptr, char* scratch = nullptr) {
     const int lr = lane & 15, lq = lane >> 4;
     const int ld = a.ld_out ? a.ld_out : a.N;
     f32x4 bias_v[4];
@@ -178,6 +178,94 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             nc[j] = n0 + wave_n * 64 + j * 16 + 4 * lq;
             nv[j] = nc[j] < a.N;
             bv[j] = bias_v[j];
+        }
+        if constexpr (EPI == EPI_RESID_LN) {
+            // ---- pass 1: the residual read-modify-write; the new row values stay in acc
+            const bool scaled = a.res_scale != nullptr;
+            f32x4 rs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rs[j] = (scaled && nv[j]) ? *reinterpret_cast<const f32x4*>(a.res_scale + nc[j]) : f32x4{1.f, 1.f, 1.f, 1.f};
+            constexpr int RB = 2;       // (4 spills registers here: mean / rstd / gamma live on top of acc)
+#pragma unroll
+            for (int i2 = 0; i2 < MR; i2 += RB) {
+                f32x4 xv[RB][4];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (i2 + u >= MR) continue;
+                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
+                    const float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (i2 + u >= MR) continue;
+                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
+                    float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i2 + u][j] = nv[j] ? xv[u][j] * rs[j] + (acc[i2 + u][j] + bv[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(row + nc[j]) = acc[i2 + u][j];
+                    }
+                }
+            }
+            // ---- pass 2 / 3: row mean and variance.  A row's N <= 256 columns are spread over the four waves
+            // of a wave group (64 each) and, inside a wave, over the four lane quarters: butterfly over the
+            // quarters, then the wave partials meet in LDS (red[row][wave_n]).  Two passes like layernorm_kernel.
+            float* red = reinterpret_cast<float*>(scratch);
+            const float inv_n = 1.0f / (float)a.N;
+            float mean[MR], rstd[MR];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!nv[j]) continue;
+                        if (pass == 0) {
+                            sacc += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                        } else {
+                            const f32x4 d = acc[i][j] - mean[i];
+                            sacc += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                        }
+                    }
+                    sacc += __shfl_xor(sacc, 16);
+                    sacc += __shfl_xor(sacc, 32);
+                    if (lq == 0) red[(wave_m * (MR * 16) + i * 16 + lr) * 4 + wave_n] = sacc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(red + (wave_m * (MR * 16) + i * 16 + lr) * 4);
+                    const float t = ((p[0] + p[1]) + (p[2] + p[3])) * inv_n;
+                    if (pass == 0) mean[i] = t;
+                    else rstd[i] = 1.0f / sqrtf(t + a.ln_eps);
+                }
+                __builtin_amdgcn_s_barrier();       // red is rewritten by the next pass / the next tile
+            }
+            // ---- pass 4: normalise and store the bf16 operand of the next GEMM
+            f32x4 gv[4], bt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bt[j] = (a.ln_beta && nv[j]) ? *reinterpret_cast<const f32x4*>(a.ln_beta + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const int m = m0 + wave_m * (MR * 16) + i * 16 + lr;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!nv[j]) continue;
+                    const f32x4 v = (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j];
+                    *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = pack4<F16>(v[0], v[1], v[2], v[3]);
+                }
+            }
+            return;
         }
         if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE) {
             f32x4 rs[4];
@@ -671,7 +759,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                 staged = true;
             }
         }
-        if (!staged) gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre);
+        if (!staged) gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre, smem + ((par + nt + 1) & 1) * STAGE_BYTES);
         PPSTAMP(5);
         ++stamp_tile;
         if (!has_next) break;
@@ -1144,7 +1232,8 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
     }
     const int tiles_m = (a.M + BM - 1) / BM;
     int variant = gemm_variant();
-    if (variant == 1 && EPI != EPI_HEAD && !getenv("HIPTS_GEMM")) {
+    if (EPI == EPI_RESID_LN) variant = 1;      // the row reduction across waves uses the persistent loop's LDS scratch stage
+    if (variant == 1 && EPI != EPI_HEAD && EPI != EPI_RESID_LN && !getenv("HIPTS_GEMM")) {
         // A launch with fewer 256 x 256 tiles than CUs (the CAFormer's late stages: 11 520 tokens x 512 columns
         // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
@@ -1227,6 +1316,8 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_VT) HIPTS_REQUIRE(a.M % 4 == 0 && a.tokens % 4 == 0, "gemm: V^T epilogue needs tokens %% 4 == 0");
     if (epi == EPI_QK || epi == EPI_VT) HIPTS_REQUIRE(a.hd_log2 == 5 || a.hd_log2 == 6, "gemm: head_dim must be 32 or 64");
     if (epi == EPI_RESCALE) HIPTS_REQUIRE(a.res_scale != nullptr, "gemm: RESCALE epilogue needs res_scale");
+    if (epi == EPI_RESID_LN)
+        HIPTS_REQUIRE(a.N <= BN && a.ln_gamma && a.out_bf16 && a.out_f32, "gemm: RESID_LN needs the whole row in one tile (N <= %d), gamma and both outputs", BN);
     switch (epi) {
         case EPI_PATCH: return launch_t<EPI_PATCH>(a, s);
         case EPI_QK: return launch_t<EPI_QK>(a, s);
@@ -1237,6 +1328,7 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
         case EPI_STAR: return launch_t<EPI_STAR>(a, s);
         case EPI_RESCALE: return launch_t<EPI_RESCALE>(a, s);
         case EPI_BIAS: return launch_t<EPI_BIAS>(a, s);
+        case EPI_RESID_LN: return launch_t<EPI_RESID_LN>(a, s);
     }
     return set_error(HIPTS_ERR_INVALID, "gemm: unknown epilogue");
 }

@@ -121,7 +121,10 @@ enum GemmEpilogue {
     // MetaFormer (CCIP encoder) epilogues
     EPI_STAR = 6,    // out[m][n] = bf16(star_scale * relu(acc + bias[n])^2 + star_bias)  (StarReLU)
     EPI_RESCALE = 7, // x[m][n] = x[m][n] * res_scale[n] + acc + bias[n]                (fp32 in/out)
-    EPI_BIAS = 8     // x[m][n] = acc + bias[n]                                         (fp32 out)
+    EPI_BIAS = 8,    // x[m][n] = acc + bias[n]                                         (fp32 out)
+    EPI_RESID_LN = 9 // x[m][n] = x[m][n] * (res_scale ? res_scale[n] : 1) + acc + bias[n]  (fp32 in/out), AND the LayerNorm
+                     // of the new row: xn[m][n] = bf16((x - mean) * rstd * ln_gamma[n] (+ ln_beta[n])).  Needs the whole
+                     // row in one tile: N <= 256.  Saves the separate LayerNorm pass over x (HBM-bound).
 };
 
 struct GemmArgs {
@@ -139,7 +142,10 @@ struct GemmArgs {
     int tokens_pad = 0;             // padded token count of the q/k/vT layouts
     int heads = 0, dim = 0;         // QK / VT
     int hd_log2 = 6;                // QK / VT: log2(head_dim), 6 (ViT) or 5 (CAFormer)
-    const float* res_scale = nullptr;   // RESCALE: per-column scale of the residual
+    const float* res_scale = nullptr;   // RESCALE (required) / RESID_LN (optional): per-column scale of the residual
+    const float* ln_gamma = nullptr;    // RESID_LN
+    const float* ln_beta = nullptr;     // RESID_LN, optional
+    float ln_eps = 1e-6f;               // RESID_LN
     float star_scale = 1.0f, star_bias = 0.0f;   // STAR
     float qscale = 1.0f;
     int gelu_tanh = 1;
