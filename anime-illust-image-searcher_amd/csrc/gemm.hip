@@ -114,6 +114,43 @@ __device__ __forceinline__ f32x4 star_relu4(f32x4 x, float s, float b) {
     return r * r * s + b;
 }
 
+// Row-contiguous store of a wave's (16 MR) x 64 block of 16-bit values through a private 8 KB LDS image (the
+// mechanism of gemm_epilogue_staged, for epilogues that produce their values from a callback): lane layout
+// in = (row 16 i + lr, columns 16 j + 4 lq ..+3), out = 8 rows x 128 B per store instruction.
+template <int MR, bool F16, typename ValueOf>
+__device__ __forceinline__ void staged_store_rows(char* region, int lane, int mrow0, int M, bf16_t* out, int ld, int ncol0, int N,
+                                                  ValueOf value_of) {
+    const int lr = lane & 15, lq = lane >> 4, lc = lane & 7, lrow = lane >> 3;
+    const bool nvl = ncol0 + lc * 8 < N;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = pass * 4 + ii;
+            if (i >= MR) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = ii * 16 + lr;
+                const int pc = (j * 2 + (lq >> 1)) ^ ((row >> 1) & 7);
+                const f32x4 v = value_of(i, j);
+                *reinterpret_cast<bf16x4*>(region + row * 128 + pc * 16 + (lq & 1) * 8) = pack4<F16>(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int row = r8 * 8 + lrow;
+            const int m = mrow0 + pass * 64 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+            if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
+            *reinterpret_cast<uint4*>(out + (size_t)m * ld + ncol0 + lc * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // Epilogue shared by both main-loop variants.  acc[i][j]: 16 x 16 tile (i: 16-row block of the
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
@@ -254,17 +291,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 gv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 bt[j] = (a.ln_beta && nv[j]) ? *reinterpret_cast<const f32x4*>(a.ln_beta + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                const int m = m0 + wave_m * (MR * 16) + i * 16 + lr;
-                if (m >= a.M) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!nv[j]) continue;
-                    const f32x4 v = (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j];
-                    *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = pack4<F16>(v[0], v[1], v[2], v[3]);
-                }
-            }
+            // through the wave's private 8 KB LDS image (red is dead: every wave is past the last barrier), so that
+            // the stores are whole 128 B lines
+            const int wave_id = wave_m * 4 + wave_n;
+            staged_store_rows<MR, F16>(scratch + wave_id * 8192, lane, m0 + wave_m * (MR * 16), a.M, a.out_bf16, ld, n0 + wave_n * 64, a.N,
+                                       [&](int i, int j) { return (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j]; });
             return;
         }
         if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE) {
