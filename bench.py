@@ -263,11 +263,30 @@ def main():
     rows = torch.zeros((BATCH, ROW_WIDTH), dtype=torch.int32, device=dev)
     gathered = torch.empty((world * BATCH, ROW_WIDTH), dtype=torch.int32, device=dev) if world > 1 else None
 
+    # One step = forward + tag selection (+ all-gather).  The selection of step i (64 workgroups, ~0.25 ms, LDS sorts)
+    # runs on a side stream while the forward of step i+1 already occupies the main stream, as a tagging loop
+    # over many batches does; probabilities and rows are double-buffered and every hand-over is an event, so
+    # nothing is skipped: all K selections and gathers have completed at the final synchronize.
+    side = torch.cuda.Stream(device=dev)
+    probs2 = [probs, torch.empty_like(probs)]
+    rows2 = [rows, torch.zeros_like(rows)]
+    ev_fwd = [torch.cuda.Event(), torch.cuda.Event()]
+    ev_sel = [torch.cuda.Event(), torch.cuda.Event()]
+    counter = [0]
+
     def step():
-        model.forward_u8(images, probs=probs, want="probs")            # patchify ... head + sigmoid
-        selector.run_device(probs, rows)                               # MCut selection -> fixed-width tag rows
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rows)                # RCCL: rank order == file order
+        b = counter[0] & 1
+        counter[0] += 1
+        main = torch.cuda.current_stream()
+        main.wait_event(ev_sel[b])                                        # step i-2's selection has released buffer b
+        model.forward_u8(images, probs=probs2[b], want="probs")          # patchify ... head + sigmoid
+        ev_fwd[b].record(main)
+        with torch.cuda.stream(main if os.environ.get("HIPTS_BENCH_SERIAL_SELECT") else side):     # A/B switch
+            torch.cuda.current_stream().wait_event(ev_fwd[b])
+            selector.run_device(probs2[b], rows2[b])                      # MCut selection -> fixed-width tag rows
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, rows2[b])           # RCCL: rank order == file order
+            ev_sel[b].record(torch.cuda.current_stream())
 
     for _ in range(args.warmup):
         step()
