@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query", action="store_true")
+    ap.add_argument("--no-exclusive", action="store_true",
+                    help="skip the kernel-alone pass after the timed region (profiler runs: keeps per-launch averages to the timed launches)")
     ap.add_argument("--operands", choices=["bf16", "f16"], default="bf16",
                     help="16-bit MFMA operand type (bf16 = BASELINE.json configs[1]; f16 = same rate, 8x smaller rounding)")
     args = ap.parse_args()
@@ -327,7 +329,7 @@ def main():
     # one stream).  In the timed region two sub-batch streams run concurrently, so a launch's duration there
     # includes the time it shares CUs with the other stream's kernel; this pass gives the kernel-alone figure.
     excl = []
-    if rank == 0:
+    if rank == 0 and not args.no_exclusive:
         _lib.call("hipts_vit_set_sub_batches", model._h, 1)
         model.forward_u8(images, probs=probs, want="probs")      # forward only: no collective outside the timed region
         torch.cuda.synchronize()

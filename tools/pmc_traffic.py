@@ -23,7 +23,7 @@ for k in agg:
     res[k] = {"launches_fetch_pass": cnt[k].get("FETCH_SIZE", 0), "launches_write_pass": cnt[k].get("WRITE_SIZE", 0),
               "fetch_bytes_per_launch": 2.0 * 1024.0 * fetch / nf, "write_bytes_per_launch": 1024.0 * write / nw,
               "hbm_bytes_per_launch": 2.0 * 1024.0 * fetch / nf + 1024.0 * write / nw}
-json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-query`; "
+json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-query --no-exclusive` (per launch = one 32-image sub-batch); "
                      "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)", "kernels": res}, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:14]:
     print("%-40s fetch %8.1f MB  write %8.1f MB per launch" % (k[:40], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
