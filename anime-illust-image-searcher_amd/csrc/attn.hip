@@ -87,6 +87,9 @@ __device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int 
     }
 }
 
+// (Moving the row sums onto the matrix pipe -- a fifth 32 x 32 block with the constant A operand "row 0 = ones",
+// 4 more MFMAs per tile for 34 fewer v_add_f32 -- was measured slightly SLOWER, 209-212 vs 205 us, and costs
+// 20 VGPRs: the loop is not simply VALU-throughput bound.)
 // (A lazy reference -- rescale O and l only when some row's tile maximum exceeds the reference by 2^8,
 // behind a wave-uniform branch -- was measured SLOWER, 217 vs 196 us: the branch stops the scheduler from
 // running this VALU work under the P V MFMAs.)
