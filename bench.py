@@ -241,7 +241,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("HIPTS_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 control flow on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0                                            # every rank shares the one GPU
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
