@@ -50,6 +50,17 @@ def test_gemm_variants_match_float64(variant):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_gemm_default_dispatch_persistent_and_underfilled():
+    """No HIPTS_GEMM: the dispatch the product uses.  (70000, 768, 128) is 822 tiles on 256 persistent
+    workgroups (several tiles per workgroup, next-tile prefetch); (11520, 512, 512) has 90 tiles < CUs and
+    goes to the two-per-CU kernel; (300, 272, 128) stays a plain one-tile-per-workgroup launch."""
+    env = {k: v for k, v in os.environ.items() if k != "HIPTS_GEMM"}
+    code = _CHILD % {"pkg": os.path.join(ROOT, "anime-illust-image-searcher_amd"),
+                     "shapes": [(70000, 768, 128), (11520, 512, 512), (300, 272, 128), (50000, 208, 64)]}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_forward_is_deterministic_and_batch_invariant():
     from hiptagsearch import synth
     from hiptagsearch.tagger import ViTTagger
