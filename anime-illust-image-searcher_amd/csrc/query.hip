@@ -316,6 +316,32 @@ __device__ __forceinline__ int block_excl_scan(int x, int* scratch /*[17]*/, int
     return res;
 }
 
+// Monotone (non-decreasing) 12-bit digit of a score, uniform in VALUE over [-2, 2): the fast path of the
+// top-k histograms on it.  Everything below -2 (and NaN) is digit 0, everything from 2 up is 4095.
+__device__ __forceinline__ uint32_t value_digit(double x) {
+    const double t = (x + 2.0) * 1024.0;
+    return t >= 4095.0 ? 4095u : (t > 0.0 ? (uint32_t)t : 0u);
+}
+
+// Histogram increment that survives concentration: when many lanes of a wave hold the SAME digit (ties: every
+// document a required term excludes scores -inf; exponent digits of like-sized scores) plain LDS atomics
+// serialise on one address.  The lanes that share the first active lane's digit are counted with one ballot
+// and added once; the remaining lanes add individually.
+__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool active) {
+    const uint64_t act = __ballot(active);
+    if (act == 0) return;
+    const int leader = __ffsll((unsigned long long)act) - 1;
+    const uint32_t dl = __shfl(d, leader);
+    const uint64_t same = __ballot(active && d == dl);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], (uint32_t)__popcll(same));
+    else if (active && d != dl) atomicAdd(&hist[d], 1u);
+}
+
+// A workgroup streams its query's scores several times; each pass is bound by load latency x loads in flight,
+// so every thread keeps TOPK_U independent 8-byte loads outstanding (128 KB per workgroup).
+constexpr int TOPK_U = 16;
+constexpr int TOPK_SORT_TARGET = 256;
+
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
                                                     int32_t* __restrict__ ids_out, double* __restrict__ vals_out) {
     __shared__ uint32_t hist[4096];
@@ -326,20 +352,89 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     const int tid = threadIdx.x;
     const double* __restrict__ v = vals + (int64_t)blockIdx.x * n;
     if ((int64_t)k > n) k = (int)n;
+    // ---- fast path (measured: the exact radix select below spends ~200 us of a 233 us single-query call in the
+    // LDS atomics of its first histogram, 100 k of them).  Estimate the threshold from a 1/8 sample instead:
+    // histogram the sample over a VALUE-uniform 12-bit digit (scores are normalised sums in about [-1, 1], so
+    // the bins spread and the atomics do not pile up on a few exponents), pick the digit below which the sample
+    // holds ~k/8 + 3 sigma entries, and collect every score with digit >= that one.  The digit is monotone in
+    // the score, so the collected set is exactly "all scores >= a pivot": if it has at least k and at most CAP
+    // members it contains the top k and the sort below finishes the job; otherwise the exact path runs.
+    bool done_fast = false;
+    if (n >= 8192) {
+        for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+        if (tid == 0) sh_cnt = 0;
+        __syncthreads();
+        for (int64_t base = 0; base < n; base += 8192) {       // the first 1024 of every 8192 scores
+            const int64_t i = base + tid;
+            hist_add(hist, i < n ? value_digit(v[i]) : 0u, i < n);
+        }
+        __syncthreads();
+        const int want = k / 8 + 3 * (int)ceilf(sqrtf((float)k / 8.0f)) + 4;
+        int own[4], ssum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            own[j] = (int)hist[4095 - (4 * tid + j)];
+            ssum += own[j];
+        }
+        int total;
+        const int excl = block_excl_scan(ssum, scratch, &total);
+        if (tid == 0) sh_digit = 0;                              // fewer sampled entries than `want`: take everything
+        __syncthreads();
+        if (excl < want && want <= excl + ssum) {
+            int run = excl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (run < want && want <= run + own[j]) sh_digit = 4095 - (4 * tid + j);
+                run += own[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t dmin = (uint32_t)sh_digit;
+        for (int64_t i0 = 0; i0 < n; i0 += TOPK_U * 1024) {
+            double x[TOPK_U];
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = i0 + u * 1024 + tid;
+                x[u] = i < n ? v[i] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = i0 + u * 1024 + tid;
+                if (i < n && value_digit(x[u]) >= dmin) {
+                    const int slot = atomicAdd(&sh_cnt, 1);
+                    if (slot < TOPK_CAP) {
+                        ckey[slot] = order_key(x[u]);
+                        cid[slot] = (uint32_t)i;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        done_fast = sh_cnt >= k && sh_cnt <= TOPK_CAP;
+        __syncthreads();
+    }
     uint64_t prefix = 0;
     int pbits = 0;
     int need = k;            // how many of the keys matching `prefix` are still wanted
-    bool fits = false;
+    bool fits = done_fast;
     const int shifts[6] = {52, 40, 28, 16, 4, 0};
     for (int pass = 0; pass < 6 && !fits; ++pass) {
         const int shift = shifts[pass];
         const int dbits = pass == 5 ? 4 : 12;
         for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < n; i += 1024) {
-            const uint64_t key = order_key(v[i]);
-            if (pbits == 0 || (key >> (64 - pbits)) == prefix)
-                atomicAdd(&hist[(key >> shift) & ((1u << dbits) - 1)], 1u);
+        for (int64_t i0 = 0; i0 < n; i0 += TOPK_U * 1024) {
+            uint64_t key[TOPK_U];
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = i0 + u * 1024 + tid;
+                key[u] = i < n ? order_key(v[i]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = i0 + u * 1024 + tid;
+                hist_add(hist, (uint32_t)(key[u] >> shift) & ((1u << dbits) - 1), i < n && (pbits == 0 || (key[u] >> (64 - pbits)) == prefix));
+            }
         }
         __syncthreads();
         // walk bins from the top: thread t owns reversed bins 4t..4t+3
@@ -368,19 +463,68 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         pbits += dbits;
         const int above = k - sh_need;          // keys strictly above the chosen bin (all wanted)
         need = sh_need;
-        fits = above + sh_bin <= TOPK_CAP;
+        // stop refining once the candidate set is small enough to SORT cheaply: the final bitonic sort costs
+        // log^2 barriers (2048 candidates = 66 stages ~ 100 us, 256 = 36), a further pass over the scores ~15 us;
+        // past the last digit (64 bits) whatever fits the LDS buffers is taken
+        fits = above + sh_bin <= (pbits < 64 ? max(TOPK_SORT_TARGET, k + 64) : TOPK_CAP);
         __syncthreads();
+        if (pass == 0 && !fits && sh_bin > TOPK_CAP) {
+            // A first bin with more members than the buffers hold is usually one value repeated (every document
+            // a required term rules out scores -inf).  One pass decides: if the smallest and the largest key
+            // in the bin agree, the remaining five digit passes are known in advance.
+            uint64_t mn = ~0ull, mx = 0ull;
+            for (int64_t i = tid; i < n; i += 1024) {
+                const uint64_t key = order_key(v[i]);
+                if ((key >> (64 - pbits)) == prefix) {
+                    mn = key < mn ? key : mn;
+                    mx = key > mx ? key : mx;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint64_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+                mn = a < mn ? a : mn;
+                mx = b > mx ? b : mx;
+            }
+            if ((tid & 63) == 0) {
+                ckey[tid >> 6] = mn;
+                ckey[16 + (tid >> 6)] = mx;
+            }
+            __syncthreads();
+            mn = ckey[0];
+            mx = ckey[16];
+            for (int w = 1; w < 16; ++w) {
+                mn = ckey[w] < mn ? ckey[w] : mn;
+                mx = ckey[16 + w] > mx ? ckey[16 + w] : mx;
+            }
+            __syncthreads();
+            if (mn == mx) {
+                prefix = mn;
+                pbits = 64;
+                break;              // fits stays false: the ordered tie compaction below takes the `need` lowest indices
+            }
+        }
     }
     const uint64_t low = pbits == 64 ? prefix : (prefix << (64 - pbits));
+    if (!done_fast) {
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
     if (fits) {
-        for (int64_t i = tid; i < n; i += 1024) {
-            const uint64_t key = order_key(v[i]);
-            if (key >= low) {
-                const int slot = atomicAdd(&sh_cnt, 1);
-                ckey[slot] = key;
-                cid[slot] = (uint32_t)i;
+        for (int64_t i0 = 0; i0 < n; i0 += TOPK_U * 1024) {
+            uint64_t key[TOPK_U];
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = i0 + u * 1024 + tid;
+                key[u] = i < n ? order_key(v[i]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = i0 + u * 1024 + tid;
+                if (i < n && key[u] >= low) {
+                    const int slot = atomicAdd(&sh_cnt, 1);
+                    ckey[slot] = key[u];
+                    cid[slot] = (uint32_t)i;
+                }
             }
         }
         __syncthreads();
@@ -411,6 +555,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         __syncthreads();
         if (tid == 0) sh_cnt = base + (taken < need ? taken : need);
         __syncthreads();
+    }
     }
     const int cnt = sh_cnt;
     int np2 = 64;
