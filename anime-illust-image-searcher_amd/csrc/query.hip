@@ -223,6 +223,11 @@ __global__ __launch_bounds__(256) void combine_kernel(const double* __restrict__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
+// TILED: `index` is the tile-major copy of the rows, float4 tl[((T * K/4 + kq) * 32 + c)] = row[32 T + c][4 kq .. 4 kq + 3]:
+// the 32 lanes of a half-wave read 512 contiguous bytes per load.  With the plain row-major matrix every lane
+// walks its own 1200 B row -- 32 different cache lines per load instruction, each revisited four times -- and the
+// kernel ran at 2 TB/s of algorithmic traffic (61 us per pass over 100k x 300); K % 4 != 0 keeps that path.
+template <bool TILED>
 __global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__ index, int64_t D, int K, int64_t ld,
                                                        const float* __restrict__ q, int nq, float* __restrict__ out,
                                                        int64_t out_ld) {
@@ -240,14 +245,15 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__
         int64_t doc = tile * 32 + r;
         const int64_t docc = doc < D ? doc : D - 1;
         const float* __restrict__ row = index + docc * ld;
+        const float4* __restrict__ trow = reinterpret_cast<const float4*>(index) + tile * (K >> 2) * 32 + r;    // TILED
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         int k = 0;
 #pragma unroll 2
         for (; k + 8 <= K; k += 8) {
-            const float4 v0 = *reinterpret_cast<const float4*>(row + k);
-            const float4 v1 = *reinterpret_cast<const float4*>(row + k + 4);
+            const float4 v0 = TILED ? trow[(k >> 2) * 32] : *reinterpret_cast<const float4*>(row + k);
+            const float4 v1 = TILED ? trow[((k >> 2) + 1) * 32] : *reinterpret_cast<const float4*>(row + k + 4);
             const float b0 = h ? v0.y : v0.x, b1 = h ? v0.w : v0.z, b2 = h ? v1.y : v1.x, b3 = h ? v1.w : v1.z;
             const float* qk = qT + (k + h) * 32 + r;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[0], b0, acc, 0, 0, 0);
@@ -256,7 +262,14 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[192], b3, acc, 0, 0, 0);
         }
         for (; k + 2 <= K; k += 2) {   // K % 8 tail (K is even, checked on the host)
-            const float b0 = row[k + h];
+            float b0;
+            if (TILED) {
+                const float4 t4 = trow[(k >> 2) * 32];
+                const int e = (k & 3) + h;                      // k is even here: e in {0,1} or {2,3}
+                b0 = e == 0 ? t4.x : (e == 1 ? t4.y : (e == 2 ? t4.z : t4.w));
+            } else {
+                b0 = row[k + h];
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qT[(k + h) * 32 + r], b0, acc, 0, 0, 0);
         }
         // D layout: column = lane & 31 = document, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = query
@@ -268,6 +281,22 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__
             }
         }
     }
+}
+
+// (re)build tiles [t0, t1) of the tile-major copy from the row-major rows; rows >= len read as zero
+__global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ rows, float4* __restrict__ tl, int64_t len, int K,
+                                                     int64_t t0, int64_t t1) {
+    const int KQ = K >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (t1 - t0) * KQ * 32;
+    if (idx >= total) return;
+    const int c = (int)(idx & 31);
+    const int kq = (int)((idx >> 5) % KQ);
+    const int64_t T = t0 + (idx >> 5) / KQ;
+    const int64_t doc = T * 32 + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (doc < len) v = *reinterpret_cast<const float4*>(rows + doc * K + 4 * kq);
+    tl[(T * KQ + kq) * 32 + c] = v;
 }
 
 // =============================================================================================
@@ -618,26 +647,30 @@ struct hipts_index {
     int dim = 0;
     int64_t len = 0, cap = 0;
     DevBuf rows;      // float [cap][dim]
+    DevBuf tiled;     // tile-major copy for the query kernel (dim % 4 == 0): float4 [ceil(cap/32)][dim/4][32]
     DevBuf ws_q, ws_out;
 };
 
 namespace {
 
-int launch_sim(const float* index, int64_t D, int K, const float* q_dev, int nq, float* out_dev, int64_t out_ld,
+int launch_sim(const float* index, const float* tiled, int64_t D, int K, const float* q_dev, int nq, float* out_dev, int64_t out_ld,
                hipStream_t s) {
     const size_t lds = (size_t)K * 32 * sizeof(float);
     HIPTS_REQUIRE(lds <= 160 * 1024, "index dim %d too large for the query tile in LDS", K);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    static const bool use_tiled = !(getenv("HIPTS_SIM") && strcmp(getenv("HIPTS_SIM"), "rows") == 0);
     const int64_t ntiles = (D + 31) / 32;
     int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * 4);
     if (grid < 1) grid = 1;
     for (int q0 = 0; q0 < nq; q0 += 32) {
         const int n = std::min(32, nq - q0);
-        sim_mfma_kernel<<<grid, 256, lds, s>>>(index, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
+        if (tiled && use_tiled) sim_mfma_kernel<true><<<grid, 256, lds, s>>>(tiled, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
+        else sim_mfma_kernel<false><<<grid, 256, lds, s>>>(index, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
         HIPTS_LAUNCH_CHECK();
     }
     return HIPTS_OK;
@@ -868,7 +901,25 @@ int hipts_index_add(hipts_index_t* h, const float* rows, int64_t nrows, int rows
     }
     HIPTS_HIP(hipMemcpy(h->rows.as<float>() + h->len * h->dim, rows, (size_t)nrows * h->dim * 4,
                         rows_memspace == HIPTS_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    const int64_t old_len = h->len;
     h->len += nrows;
+    if (h->dim % 4 == 0 && nrows > 0) {
+        // the tile-major copy the product kernel reads: size it like `rows`, then rewrite the tiles the new rows touch
+        const size_t need = (size_t)((h->cap + 31) / 32) * 32 * h->dim * 4;
+        if (h->tiled.bytes < need) {
+            DevBuf nb;
+            HIPTS_TRY(nb.alloc(need));
+            if (h->tiled.p && old_len > 0)
+                HIPTS_HIP(hipMemcpy(nb.p, h->tiled.p, (size_t)((old_len + 31) / 32) * 32 * h->dim * 4, hipMemcpyDeviceToDevice));
+            std::swap(nb.p, h->tiled.p);
+            std::swap(nb.bytes, h->tiled.bytes);
+        }
+        const int64_t t0 = old_len / 32, t1 = (h->len + 31) / 32;
+        const int64_t total = (t1 - t0) * (h->dim / 4) * 32;
+        retile_kernel<<<ceil_div(total, 256), 256>>>(h->rows.as<float>(), h->tiled.as<float4>(), h->len, h->dim, t0, t1);
+        HIPTS_LAUNCH_CHECK();
+        HIPTS_HIP(hipDeviceSynchronize());
+    }
     return HIPTS_OK;
 }
 
@@ -908,7 +959,7 @@ int hipts_index_query(hipts_index_t* h, const float* queries, int queries_memspa
         HIPTS_TRY(h->ws_out.reserve((size_t)nq * h->len * 4));
         out_dev = h->ws_out.as<float>();
     }
-    HIPTS_TRY(launch_sim(h->rows.as<float>(), h->len, h->dim, q_dev, nq, out_dev, h->len, s));
+    HIPTS_TRY(launch_sim(h->rows.as<float>(), h->tiled.as<float>(), h->len, h->dim, q_dev, nq, out_dev, h->len, s));
     return copy_out(scores_out, out_dev, (size_t)nq * h->len * 4, out_memspace, s);
 }
 
@@ -1025,7 +1076,7 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     double* ma = bm25->ws_max.as<double>();
     float* mb = reinterpret_cast<float*>(ma + nq);
     HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
-    HIPTS_TRY(launch_sim(index->rows.as<float>(), D, index->dim, index->ws_q.as<float>(), nq, bm25->ws_sims.as<float>(), D, s));
+    HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, index->ws_q.as<float>(), nq, bm25->ws_sims.as<float>(), D, s));
     rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
     HIPTS_LAUNCH_CHECK();
     {
