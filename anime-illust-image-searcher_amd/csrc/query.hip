@@ -227,13 +227,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the 32 lanes of a half-wave read 512 contiguous bytes per load.  With the plain row-major matrix every lane
 // walks its own 1200 B row -- 32 different cache lines per load instruction, each revisited four times -- and the
 // kernel ran at 2 TB/s of algorithmic traffic (61 us per pass over 100k x 300); K % 4 != 0 keeps that path.
+constexpr int SIM_THREADS = 512;     // 8 waves share one LDS query tile: 3 workgroups = 6 dependent MFMA chains per SIMD
 template <bool TILED>
-__global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__ index, int64_t D, int K, int64_t ld,
+__global__ __launch_bounds__(SIM_THREADS) void sim_mfma_kernel(const float* __restrict__ index, int64_t D, int K, int64_t ld,
                                                        const float* __restrict__ q, int nq, float* __restrict__ out,
                                                        int64_t out_ld) {
     extern __shared__ __attribute__((aligned(16))) float qT[];   // [K][32]: qT[k*32 + j] = q[j][k]
     const int tid = threadIdx.x;
-    for (int i = tid; i < K * 32; i += 256) {
+    for (int i = tid; i < K * 32; i += SIM_THREADS) {
         const int k = i >> 5, j = i & 31;
         qT[i] = j < nq ? q[(int64_t)j * K + k] : 0.0f;
     }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void sim_mfma_kernel(const float* __restrict__
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t ntiles = (D + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * (SIM_THREADS / 64) + wave; tile < ntiles; tile += (int64_t)gridDim.x * (SIM_THREADS / 64)) {
         int64_t doc = tile * 32 + r;
         const int64_t docc = doc < D ? doc : D - 1;
         const float* __restrict__ row = index + docc * ld;
@@ -665,12 +666,13 @@ int launch_sim(const float* index, const float* tiled, int64_t D, int K, const f
     }
     static const bool use_tiled = !(getenv("HIPTS_SIM") && strcmp(getenv("HIPTS_SIM"), "rows") == 0);
     const int64_t ntiles = (D + 31) / 32;
-    int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 256 * 4);
+    constexpr int WPB = SIM_THREADS / 64;
+    int grid = (int)std::min<int64_t>((ntiles + WPB - 1) / WPB, 256 * 4);
     if (grid < 1) grid = 1;
     for (int q0 = 0; q0 < nq; q0 += 32) {
         const int n = std::min(32, nq - q0);
-        if (tiled && use_tiled) sim_mfma_kernel<true><<<grid, 256, lds, s>>>(tiled, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
-        else sim_mfma_kernel<false><<<grid, 256, lds, s>>>(index, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
+        if (tiled && use_tiled) sim_mfma_kernel<true><<<grid, SIM_THREADS, lds, s>>>(tiled, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
+        else sim_mfma_kernel<false><<<grid, SIM_THREADS, lds, s>>>(index, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
         HIPTS_LAUNCH_CHECK();
     }
     return HIPTS_OK;
