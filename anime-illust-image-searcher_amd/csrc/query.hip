@@ -109,6 +109,7 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
         if (w > REQUIRE_MAGIC) ++n_required;
         if (w > REQUIRE_MAGIC || w < 0.0) masking = true;
     }
+#pragma unroll 8
     for (int64_t d = tid; d < D; d += 1024) {
         scores[d] = 0.0;
         if (masking) mark[d] = 0;
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
         if (t >= 0 && t < V) {
             const double idf_t = idf[t];
             const int64_t b = tptr[t], e = tptr[t + 1];
-            for (int64_t i = b + tid; i < e; i += 1024) {
+#pragma unroll 4
+            for (int64_t i = b + tid; i < e; i += 1024) {      // (distinct documents within a term: iterations are independent)
                 const int32_t d = tdoc[i];
                 if (w < 0.0) {
                     mark[d] |= 0x80;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
     }
     double mx = -INFINITY;
     if (masking) {
+#pragma unroll 8
         for (int64_t d = tid; d < D; d += 1024) {
             const uint8_t m = mark[d];
             double v = scores[d];
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
             mx = fmax(mx, v);
         }
     } else if (max_out) {
+#pragma unroll 8
         for (int64_t d = tid; d < D; d += 1024) mx = fmax(mx, scores[d]);
     }
     if (max_out) {      // row maximum for the normalisation of webui.py:379-380, fused here
