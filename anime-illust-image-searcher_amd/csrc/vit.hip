@@ -63,6 +63,8 @@ struct hipts_vit {
     int pool_splits = 1;
     static constexpr int kMaxSub = 4;
     int want_sub = 0;                             // hipts_vit_set_sub_batches; 0 = default
+    bool deferred_join = false;                   // hipts_vit_set_deferred_join
+    int last_ns = 0;                              // sub-batch streams the last forward used (0: none to join)
     hipStream_t sub[kMaxSub] = {};                // internal streams of the sub-batches
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
 };
@@ -748,10 +750,12 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
             HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i], true));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
-            HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+            if (!h->deferred_join || !dev_out) HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
+        h->last_ns = (h->deferred_join && dev_out) ? ns : 0;
     } else {
         HIPTS_TRY(vit_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s, false));
+        h->last_ns = 0;
     }
     if (!dev_out) {
         const size_t bytes = (size_t)batch * c.num_classes * 4;
@@ -782,6 +786,19 @@ int hipts_vit_set_sub_batches(hipts_vit_t* h, int n) {
     HIPTS_REQUIRE(h, "null handle");
     HIPTS_REQUIRE(n >= 0 && n <= hipts_vit::kMaxSub, "hipts_vit_set_sub_batches: n must be 0 .. %d", (int)hipts_vit::kMaxSub);
     h->want_sub = n;
+    return HIPTS_OK;
+}
+
+int hipts_vit_set_deferred_join(hipts_vit_t* h, int on) {
+    HIPTS_REQUIRE(h, "null handle");
+    h->deferred_join = on != 0;
+    return HIPTS_OK;
+}
+
+int hipts_vit_join(hipts_vit_t* h, void* stream) {
+    HIPTS_REQUIRE(h, "null handle");
+    HIPTS_TRY(use_device(h->device));
+    for (int i = 0; i < h->last_ns; ++i) HIPTS_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_join[i], 0));
     return HIPTS_OK;
 }
 

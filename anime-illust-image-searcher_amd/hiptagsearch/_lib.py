@@ -45,6 +45,8 @@ _SIGNATURES = {
     "hipts_vit_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_vit_flops_per_image": [c_void_p, POINTER(c_double)],
     "hipts_vit_set_sub_batches": [c_void_p, c_int],
+    "hipts_vit_set_deferred_join": [c_void_p, c_int],
+    "hipts_vit_join": [c_void_p, c_void_p],
     "hipts_vit_profile_enable": [c_void_p, c_int],
     "hipts_vit_profile_read": [c_void_p, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
     "hipts_vit_profile_name": [c_int, c_char_p, c_size_t],

@@ -280,6 +280,8 @@ def main():
     ev_fwd = [torch.cuda.Event(), torch.cuda.Event()]
     ev_sel = [torch.cuda.Event(), torch.cuda.Event()]
     counter = [0]
+    deferred = not os.environ.get("HIPTS_BENCH_SERIAL_SELECT") and not os.environ.get("HIPTS_BENCH_JOIN")
+    _lib.call("hipts_vit_set_deferred_join", model._h, 1 if deferred else 0)
 
     def step():
         b = counter[0] & 1
@@ -290,6 +292,8 @@ def main():
         ev_fwd[b].record(main)
         with torch.cuda.stream(main if os.environ.get("HIPTS_BENCH_SERIAL_SELECT") else side):     # A/B switch
             torch.cuda.current_stream().wait_event(ev_fwd[b])
+            if deferred:                                                  # the forward's two halves join HERE, not on main
+                _lib.call("hipts_vit_join", model._h, _lib.current_stream_ptr())
             selector.run_device(probs2[b], rows2[b])                      # MCut selection -> fixed-width tag rows
             if world > 1:
                 dist.all_gather_into_tensor(gathered, rows2[b])           # RCCL: rank order == file order
@@ -334,6 +338,7 @@ def main():
     # one stream).  In the timed region two sub-batch streams run concurrently, so a launch's duration there
     # includes the time it shares CUs with the other stream's kernel; this pass gives the kernel-alone figure.
     excl = []
+    _lib.call("hipts_vit_set_deferred_join", model._h, 0)
     if rank == 0 and not args.no_exclusive:
         _lib.call("hipts_vit_set_sub_batches", model._h, 1)
         model.forward_u8(images, probs=probs, want="probs")      # forward only: no collective outside the timed region

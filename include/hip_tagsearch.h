@@ -105,6 +105,15 @@ int hipts_vit_profile_name(int category, char* buf, size_t n);
  * fills the partial last round and the epilogue bubbles of the other's.  Results do not depend on it
  * (every image is computed by the same instruction sequence). */
 int hipts_vit_set_sub_batches(hipts_vit_t* h, int n);
+/* Deferred join (device outputs only): with it on, forward() returns once the sub-batch streams are fed and
+ * does NOT make the caller's stream wait for them; hipts_vit_join(h, stream) makes `stream` wait for the
+ * outputs of the most recent forward.  A tagging loop joins on the stream that consumes the probabilities
+ * and keeps submitting forwards on the other: the sub-batch streams then run from one batch straight into
+ * the next, and the low-occupancy first and last kernels of a forward (patch matrix, pooling, head) overlap
+ * the other half's bulk.  Each sub-batch stream stays in order, so workspace reuse is safe; the caller
+ * double-buffers what it hands in as outputs. */
+int hipts_vit_set_deferred_join(hipts_vit_t* h, int on);
+int hipts_vit_join(hipts_vit_t* h, void* stream);
 /* algorithmic FLOPs of one image's forward (2*M*N*K of every contraction), for roofline use */
 int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops);
 

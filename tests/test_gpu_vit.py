@@ -92,3 +92,35 @@ def test_vit_requires_all_tensors():
     model = ViTTagger(cfg, w, max_batch=2)
     with pytest.raises(hiptagsearch.HipTagSearchError):
         model.forward_u8(synth.images_u8(1, cfg["image_size"]))
+
+
+def test_deferred_join_gives_the_same_outputs():
+    """hipts_vit_set_deferred_join: forward() does not make the caller's stream wait for the sub-batch streams;
+    hipts_vit_join does, on whichever stream consumes the outputs.  Two forwards back to back, joined on a
+    side stream, must give the batch's ordinary outputs."""
+    import torch
+    from hiptagsearch import _lib, synth
+    from hiptagsearch.tagger import ViTTagger
+    cfg = dict(synth.VIT_TINY)
+    w = synth.vit_weights(cfg, seed=1)
+    model = ViTTagger(cfg, w, max_batch=32)
+    imgs = [torch.from_numpy(synth.images_u8(32, cfg["image_size"], seed=s)).cuda() for s in (21, 22)]     # 32 images -> two sub-batches
+    want = []
+    for im in imgs:
+        p = torch.empty((32, cfg["num_classes"]), dtype=torch.float32, device="cuda")
+        model.forward_u8(im, probs=p, want="probs")
+        torch.cuda.synchronize()
+        want.append(p.cpu().numpy())
+    _lib.call("hipts_vit_set_deferred_join", model._h, 1)
+    side = torch.cuda.Stream()
+    outs = [torch.empty((32, cfg["num_classes"]), dtype=torch.float32, device="cuda") for _ in imgs]
+    copies = []
+    for im, o in zip(imgs, outs):
+        model.forward_u8(im, probs=o, want="probs")
+        with torch.cuda.stream(side):
+            _lib.call("hipts_vit_join", model._h, _lib.current_stream_ptr())
+            copies.append(o.clone())                       # consumer on the side stream
+    torch.cuda.synchronize()
+    _lib.call("hipts_vit_set_deferred_join", model._h, 0)
+    for c, wnt in zip(copies, want):
+        np.testing.assert_array_equal(c.cpu().numpy(), wnt)
