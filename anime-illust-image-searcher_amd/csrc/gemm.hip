@@ -19,6 +19,11 @@
 // which is what the transposed V layout wants.
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) walk
 // neighbouring tiles and reuse operand panels in that XCD's L2.
+// The default kernel (gemm_pp_kernel) is persistent -- one workgroup per CU walks its tiles and requests the
+// next tile's first K-tile before its epilogue -- and the same loop serves the CAFormer of the CCIP encoder
+// (ccip.hip) through the StarReLU / scaled-residual / bias / residual+LayerNorm epilogues.  Half-precision
+// outputs leave through per-wave LDS images as whole 128 B lines (gemm_epilogue_staged, staged_store_rows).
+// gemm_dw_kernel (256 x 128 x 32, two workgroups per CU) takes launches with fewer tiles than CUs.
 #include <cstdlib>
 #include <type_traits>
 
