@@ -122,7 +122,7 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
 template <bool F16, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
-                                                   int tokens, int tokens_pad, int qblocks) {
+                                                   int tokens, int tokens_pad, int qblocks, int out_stride) {
     using G = Geo<HD>;
     constexpr int KS = G::KS, K_BYTES = G::K_BYTES, V_BYTES = G::V_BYTES, V_BASE = G::V_BASE;
     // iteration t multiplies K(t) (slot t & 1) and V(t-1) (slot (t-1) % 3) while tile t+1 is written: K(t+1)
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     const float inv = 1.0f / l_tot;
     const int qi = q0 + r;
     if (qi < tokens) {
-        bf16_t* op = out + ((size_t)b * tokens + qi) * (heads * HD) + head * HD;
+        bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
 #pragma unroll
         for (int blk = 0; blk < HD / 32; ++blk)
 #pragma unroll
@@ -251,18 +251,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
 }  // namespace
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
-                     int tokens_pad, bool f16, hipStream_t s, int head_dim) {
+                     int tokens_pad, bool f16, hipStream_t s, int head_dim, int out_tokens_stride) {
+    const int ost = out_tokens_stride > 0 ? out_tokens_stride : tokens;
     HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens, "attention: tokens_pad must be a multiple of %d", KV);
     HIPTS_REQUIRE(head_dim == 64 || head_dim == 32, "attention: head_dim must be 64 or 32");
     const int qtiles = (tokens + 31) / 32;
     const int qblocks = (qtiles + 3) / 4;
     const int grid = batch * heads * qblocks;
     if (head_dim == 64) {
-        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
-        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
+        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
     } else {
-        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
-        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks);
+        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
+        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
     }
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;

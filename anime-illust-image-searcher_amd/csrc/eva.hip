@@ -1,0 +1,562 @@
+// eva.hip -- EVA02 tagger forward (the model tagging.py:45 really loads: wd-eva02-large-tagger-v3 =
+// timm eva02_large_patch14_448) behind hipts_eva_*.
+//
+// Replaces `model.forward(batched_tensor)` + `F.sigmoid` (tagging.py:174-176) for that model family:
+//   patch-embed conv 14x14 s14 (+bias) -> [cls | patches] + pos_embed -> depth x {
+//       x += proj(softmax(rope(q) rope(k)^T / 8) v)     q/k/v = Linear(LN(x)) (q, v biased, k not), 2-D axial
+//                                                        RoPE on the patch tokens, head_dim 64
+//       x += fc2(LN(silu(fc1_g(LN(x))) * fc1_x(LN(x))))  SwiGLU with inner LayerNorm }
+//   -> mean over the patch tokens -> fc_norm -> head (+ sigmoid).            (oracle/eva.py restates the same graph)
+//
+// Built from the pieces of the ViT-B/16 path: every Linear is the persistent MFMA GEMM of gemm.hip (q|k and v^T
+// epilogues write the attention layouts, +bias+residual epilogues do the fp32 read-modify-write, the
+// bias+SiLU / bias-only epilogues feed the SwiGLU), attention is attn.hip<64> with the 1025 real tokens masked
+// inside a 1088-token padded layout.  An image owns TS = 1032 rows of the token matrices (1025 rounded up to 8):
+// the 7 spare rows are zero-initialised, stay finite and are never read as keys (masked) or pooled.
+// First version of this model: RoPE and SwiGLU-product + LayerNorm are separate HBM-bound kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "vit_internal.h"
+
+using namespace hipts;
+
+namespace {
+
+struct EvaLayer {
+    DevBuf ln1_g, ln1_b, ln2_g, ln2_b, mn_g, mn_b;
+    DevBuf qkv_w, qkv_b, proj_w, proj_b, g_w, g_b, x_w, x_b, fc2_w, fc2_b;
+};
+
+}  // namespace
+
+struct hipts_eva {
+    int device = 0;
+    hipts_eva_config_t cfg{};
+    int grid = 0, np = 0, T = 0, TS = 0, Tp = 0, PK = 0, HN = 0, HK = 0;
+    std::vector<EvaLayer> layers;
+    DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope_sin, rope_cos;
+    std::vector<std::string> missing;
+    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, g2, hn, pooled2, logits, probs;
+};
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Patch matrix, hi | lo halves of the normalised pixel (K = 2 PK, PK = P*P*3 rounded up to 64, pad columns stay
+// zero).  Column (ky*P + kx)*3 + c holds memory channel c (RGB); the BGR flip of tagging.py:243 lives in the
+// weight permutation.  U8: ToTensor (/255) and Normalize ((x - .5) / .5) in float32 like the reference.
+template <bool U8, bool F16>
+__global__ __launch_bounds__(256) void eva_patchify_kernel(const void* __restrict__ img, bf16_t* __restrict__ a0, int batch, int S, int P,
+                                                           int grid, int PK) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * grid * grid * P;
+    if (idx >= total) return;
+    const int ky = (int)(idx % P);
+    const int64_t tok = idx / P;
+    const int px = (int)(tok % grid), py = (int)((tok / grid) % grid);
+    const int64_t b = tok / ((int64_t)grid * grid);
+    bf16_t* dst = a0 + tok * (int64_t)(2 * PK) + ky * P * 3;
+    const int iy = py * P + ky;
+    for (int kx = 0; kx < P; ++kx) {
+        const int ix = px * P + kx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v;
+            if constexpr (U8) {
+                const float u = (float)reinterpret_cast<const uint8_t*>(img)[((b * S + iy) * S + ix) * 3 + c];
+                v = (u / 255.0f - 0.5f) / 0.5f;
+            } else {
+                v = reinterpret_cast<const float*>(img)[((b * 3 + (2 - c)) * S + iy) * (int64_t)S + ix];
+            }
+            const bf16_t hi = to_op<F16>(v);
+            dst[kx * 3 + c] = hi;
+            dst[PK + kx * 3 + c] = to_op<F16>(v - from_op<F16>(hi));
+        }
+    }
+}
+
+// x[b*TS + 0] = cls + pos[0]; x[b*TS + 1 + t] = tmp[b*np + t] (conv + bias + pos[1 + t], from the GEMM epilogue);
+// x[b*TS + T .. TS) = 0.   One thread per float4.
+__global__ __launch_bounds__(256) void eva_assemble_kernel(const float* __restrict__ tmp, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int batch, int np, int TS,
+                                                           int D) {
+    const int dq = D >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)batch * TS * dq;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % dq);
+    const int r = (int)((idx / dq) % TS);
+    const int64_t b = idx / ((int64_t)dq * TS);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r == 0) {
+        const float4 a = reinterpret_cast<const float4*>(cls)[c4], p = reinterpret_cast<const float4*>(pos)[c4];
+        v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    } else if (r <= np) {
+        v = reinterpret_cast<const float4*>(tmp)[(b * np + (r - 1)) * dq + c4];
+    }
+    reinterpret_cast<float4*>(x)[idx] = v;
+}
+
+// RoPE in place on q or k, layout [(b*H + h)*Tp + t][64]: for the patch tokens t = 1 .. np,
+// (x0, x1) -> (x0 c0 - x1 s0, x1 c1 + x0 s1) with the tables of token t-1.  One thread per 8 values.
+template <bool F16>
+__global__ __launch_bounds__(256) void eva_rope_kernel(bf16_t* __restrict__ qk, const float* __restrict__ sn, const float* __restrict__ cs,
+                                                       int64_t bh, int Tp, int np) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = bh * np * 8;
+    if (idx >= total) return;
+    const int c8 = (int)(idx & 7);
+    const int t = (int)((idx >> 3) % np);
+    const int64_t g = idx / ((int64_t)np * 8);
+    bf16_t* p = qk + ((g * Tp + 1 + t) * 64 + c8 * 8);
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+    const float* s = sn + (int64_t)t * 64 + c8 * 8;
+    const float* c = cs + (int64_t)t * 64 + c8 * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const float x0 = from_op<F16>(v[e]), x1 = from_op<F16>(v[e + 1]);
+        o[e] = to_op<F16>(x0 * c[e] - x1 * s[e]);
+        o[e + 1] = to_op<F16>(x1 * c[e + 1] + x0 * s[e + 1]);
+    }
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// hn[row][:] = LN(g1[row][:] * g2[row][:]) over the first Hd columns (g1 = silu(fc1_g), g2 = fc1_x, row pitch ld);
+// pad columns [Hd, ld) are written as zero (they are K columns of fc2).  One wave per row, values in registers.
+template <bool F16>
+__global__ __launch_bounds__(256) void eva_swiglu_ln_kernel(const bf16_t* __restrict__ g1, const bf16_t* __restrict__ g2,
+                                                            const float* __restrict__ gam, const float* __restrict__ bet,
+                                                            bf16_t* __restrict__ out, int64_t rows, int Hd, int ld, float eps) {
+    constexpr int MAXV = 8;                          // 8 x 64 lanes x 8 values = 4096 columns at most
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* a = g1 + row * ld;
+    const bf16_t* b = g2 + row * ld;
+    float v[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c0 = (lane + 64 * i) * 8;
+        if (c0 < ld) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c0), y = *reinterpret_cast<const bf16x8*>(b + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = c0 + e < Hd ? from_op<F16>(x[e]) * from_op<F16>(y[e]) : 0.f;
+                s += v[i][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wsum(s) / (float)Hd;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (lane + 64 * i) * 8 + e;
+            if (c < Hd) ss += (v[i][e] - mean) * (v[i][e] - mean);
+        }
+    const float rstd = 1.0f / sqrtf(wsum(ss) / (float)Hd + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c0 = (lane + 64 * i) * 8;
+        if (c0 >= ld) continue;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            o[e] = to_op<F16>(c < Hd ? (v[i][e] - mean) * rstd * gam[c] + bet[c] : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(out + row * ld + c0) = o;
+    }
+}
+
+// pooled2[b] = hi | lo of fc_norm(mean over the patch tokens 1 .. np of x[b]).  One 1024-thread workgroup per image.
+template <bool F16>
+__global__ __launch_bounds__(1024) void eva_pool_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
+                                                        bf16_t* __restrict__ out, int np, int TS, int D, float eps) {
+    __shared__ float part[4][1024];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x & 255, rg = threadIdx.x >> 8;
+    const float* xb = x + ((int64_t)b * TS + 1) * D;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int r = rg; r < np; r += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            if (c < D) m[u] += xb[(int64_t)r * D + c];
+        }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) part[rg][tid + 256 * u] = m[u];
+    __syncthreads();
+    float s = 0.f;
+    if (rg == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            m[u] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / (float)np;
+            if (c < D) s += m[u];
+        }
+        s = wsum(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+    }
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)D;
+    __syncthreads();
+    if (rg == 0) {
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (tid + 256 * u < D) ss += (m[u] - mean) * (m[u] - mean);
+        ss = wsum(ss);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+    }
+    __syncthreads();
+    if (rg != 0) return;
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        if (c < D) {
+            const float f = (m[u] - mean) * rstd * g[c] + bta[c];
+            const bf16_t hi = to_op<F16>(f);
+            out[(int64_t)b * 2 * D + c] = hi;
+            out[(int64_t)b * 2 * D + D + c] = to_op<F16>(f - from_op<F16>(hi));
+        }
+    }
+}
+
+int up_f32(DevBuf& buf, const float* data, size_t n) {
+    HIPTS_TRY(buf.alloc(n * 4));
+    return upload(buf.p, data, n * 4);
+}
+
+// rows x cols float block -> 16-bit operand bits at row offset `row0` of a [*, ld] matrix that was allocated zeroed
+int put_rows16(DevBuf& buf, const float* data, int rows, int cols, int row0, int ld, bool f16) {
+    std::vector<uint16_t> h((size_t)rows * ld, 0);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) h[(size_t)r * ld + c] = f16 ? f32_to_f16_rne(data[(size_t)r * cols + c]) : f32_to_bf16_rne(data[(size_t)r * cols + c]);
+    return upload(buf.as<uint16_t>() + (size_t)row0 * ld, h.data(), h.size() * 2);
+}
+
+int alloc_zero(DevBuf& buf, size_t bytes) {
+    HIPTS_TRY(buf.alloc(bytes));
+    HIPTS_HIP(hipMemset(buf.p, 0, bytes));
+    return HIPTS_OK;
+}
+
+int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u8, int batch, float* logits_out, float* probs_out,
+                     int out_memspace, hipStream_t s) {
+    HIPTS_REQUIRE(h && input && batch >= 1, "hipts_eva_forward: bad arguments");
+    HIPTS_REQUIRE(batch <= h->cfg.max_batch, "batch %d exceeds max_batch %d", batch, h->cfg.max_batch);
+    if (!h->missing.empty())
+        return set_error(HIPTS_ERR_STATE, "hipts_eva_forward: %zu checkpoint tensors not set (first: %s)", h->missing.size(),
+                         h->missing[0].c_str());
+    HIPTS_TRY(use_device(h->device));
+    const auto& c = h->cfg;
+    const int S = c.image_size, D = c.dim, P = c.patch, H = c.heads, T = h->T, TS = h->TS, Tp = h->Tp, np = h->np;
+    const bool f16 = c.operand_f16 != 0;
+    const int M = batch * TS;
+    const void* in_dev = input;
+    if (in_memspace != HIPTS_DEVICE) {
+        const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
+        HIPTS_TRY(h->img_in.reserve(bytes));
+        HIPTS_HIP(hipMemcpyAsync(h->img_in.p, input, bytes, hipMemcpyHostToDevice, s));
+        in_dev = h->img_in.p;
+    }
+    const bool dev_out = out_memspace == HIPTS_DEVICE;
+    float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
+    float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
+    float* x = h->x.as<float>();
+    bf16_t* xn = h->xn.as<bf16_t>();
+    GemmArgs g;
+    {
+        const int64_t total = (int64_t)batch * np * P;
+        const int blocks = ceil_div(total, 256);
+        bf16_t* a0 = h->a0.as<bf16_t>();
+        if (is_u8) {
+            if (f16) eva_patchify_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
+            else eva_patchify_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
+        } else {
+            if (f16) eva_patchify_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
+            else eva_patchify_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
+        }
+        HIPTS_LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = a0; g.W = h->patch_w.as<bf16_t>(); g.M = batch * np; g.N = D; g.K = 2 * h->PK;
+        g.bias = h->patch_b.as<float>(); g.out_f32 = h->tmp.as<float>(); g.pos = h->pos.as<float>() + D; g.tokens = np; g.qscale = 1.0f;
+        HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+        const int64_t tot4 = (int64_t)batch * TS * (D / 4);
+        eva_assemble_kernel<<<ceil_div(tot4, 256), 256, 0, s>>>(h->tmp.as<float>(), h->cls.as<float>(), h->pos.as<float>(), x, batch, np, TS, D);
+        HIPTS_LAUNCH_CHECK();
+    }
+    const int64_t bh = (int64_t)batch * H;
+    for (int li = 0; li < c.depth; ++li) {
+        EvaLayer& L = h->layers[li];
+        HIPTS_TRY(launch_layernorm(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D; g.bias = L.qkv_b.as<float>();
+        g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
+        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation below
+        HIPTS_TRY(launch_gemm(EPI_QK, g, s));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D; g.bias = L.qkv_b.as<float>() + 2 * D;
+        g.out_bf16 = h->vT.as<bf16_t>();
+        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        HIPTS_TRY(launch_gemm(EPI_VT, g, s));
+        {
+            const int64_t total = bh * np * 8;
+            const int blocks = ceil_div(total, 256);
+            if (f16) {
+                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(h->q.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(h->k.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+            } else {
+                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(h->q.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(h->k.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+            }
+            HIPTS_LAUNCH_CHECK();
+        }
+        HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, f16, s, 64, TS));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = h->att.as<bf16_t>(); g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        HIPTS_TRY(launch_layernorm(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = xn; g.W = L.g_w.as<bf16_t>(); g.M = M; g.N = h->HN; g.K = D; g.bias = L.g_b.as<float>();
+        g.out_bf16 = h->g1.as<bf16_t>(); g.ld_out = h->HK; g.star_kind = 1;          // bias + SiLU
+        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
+        g.W = L.x_w.as<bf16_t>(); g.bias = L.x_b.as<float>(); g.out_bf16 = h->g2.as<bf16_t>(); g.star_kind = 2;   // bias only
+        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
+        if (f16) eva_swiglu_ln_kernel<true><<<ceil_div(M, 4), 256, 0, s>>>(h->g1.as<bf16_t>(), h->g2.as<bf16_t>(), L.mn_g.as<float>(), L.mn_b.as<float>(), h->hn.as<bf16_t>(), M, c.mlp_hidden, h->HK, c.ln_eps);
+        else eva_swiglu_ln_kernel<false><<<ceil_div(M, 4), 256, 0, s>>>(h->g1.as<bf16_t>(), h->g2.as<bf16_t>(), L.mn_g.as<float>(), L.mn_b.as<float>(), h->hn.as<bf16_t>(), M, c.mlp_hidden, h->HK, c.ln_eps);
+        HIPTS_LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.A = h->hn.as<bf16_t>(); g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+    }
+    if (f16) eva_pool_kernel<true><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), h->pooled2.as<bf16_t>(), np, TS, D, c.ln_eps);
+    else eva_pool_kernel<false><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), h->pooled2.as<bf16_t>(), np, TS, D, c.ln_eps);
+    HIPTS_LAUNCH_CHECK();
+    g = GemmArgs{};
+    g.f16 = f16;
+    g.A = h->pooled2.as<bf16_t>(); g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
+    g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = pr;
+    HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
+    if (!dev_out) {
+        const size_t bytes = (size_t)batch * c.num_classes * 4;
+        if (logits_out) HIPTS_HIP(hipMemcpyAsync(logits_out, lg, bytes, hipMemcpyDeviceToHost, s));
+        if (probs_out) HIPTS_HIP(hipMemcpyAsync(probs_out, pr, bytes, hipMemcpyDeviceToHost, s));
+        HIPTS_HIP(hipStreamSynchronize(s));
+    }
+    return HIPTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** out) {
+    HIPTS_REQUIRE(cfg && out, "hipts_eva_create: null argument");
+    HIPTS_REQUIRE(cfg->patch >= 1 && cfg->image_size % cfg->patch == 0, "image_size %d must be a multiple of patch %d", cfg->image_size, cfg->patch);
+    HIPTS_REQUIRE(cfg->dim % 64 == 0 && cfg->dim <= 1024 && cfg->heads * 64 == cfg->dim, "dim %d / heads %d: head_dim must be 64, dim <= 1024", cfg->dim, cfg->heads);
+    HIPTS_REQUIRE(cfg->mlp_hidden >= 8 && cfg->mlp_hidden <= 4096, "mlp_hidden %d must be 8 .. 4096", cfg->mlp_hidden);
+    HIPTS_REQUIRE(cfg->depth >= 1 && cfg->num_classes >= 1 && cfg->max_batch >= 1 && cfg->rope_ref_grid >= 1, "bad configuration");
+    HIPTS_TRY(use_device(device));
+    auto* h = new hipts_eva();
+    h->device = device;
+    h->cfg = *cfg;
+    const int D = cfg->dim, B = cfg->max_batch;
+    h->grid = cfg->image_size / cfg->patch;
+    h->np = h->grid * h->grid;
+    h->T = h->np + 1;
+    h->TS = round_up(h->T, 8);
+    h->Tp = round_up(h->T, 64);
+    h->PK = round_up(cfg->patch * cfg->patch * 3, 64);
+    h->HN = round_up(cfg->mlp_hidden, 16);
+    h->HK = round_up(cfg->mlp_hidden, 64);
+    h->layers.resize(cfg->depth);
+    const size_t M = (size_t)B * h->TS;
+    const size_t qk = (size_t)B * cfg->heads * h->Tp * 64 * 2;
+    int st = 0;
+    if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
+        (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->vT, qk)) ||
+        (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) || (st = alloc_zero(h->g2, M * h->HK * 2)) ||
+        (st = alloc_zero(h->hn, M * h->HK * 2)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) ||
+        (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
+        delete h;
+        return st;
+    }
+    // RoPE tables (timm RotaryEmbeddingCat, in_pixels = False, positions rescaled to the reference grid)
+    {
+        const int nb = 16;      // head_dim / 4
+        std::vector<float> sn((size_t)h->np * 64), cs((size_t)h->np * 64);
+        for (int y = 0; y < h->grid; ++y)
+            for (int xx = 0; xx < h->grid; ++xx)
+                for (int ax = 0; ax < 2; ++ax)
+                    for (int i = 0; i < nb; ++i) {
+                        const float band = 1.0f / powf(10000.0f, (float)i / (float)nb);
+                        const float t = (float)(ax == 0 ? y : xx) / (float)h->grid * (float)cfg->rope_ref_grid;
+                        const float a = t * band;
+                        const size_t o = ((size_t)y * h->grid + xx) * 64 + (size_t)(ax * nb + i) * 2;
+                        sn[o] = sn[o + 1] = sinf(a);
+                        cs[o] = cs[o + 1] = cosf(a);
+                    }
+        if ((st = up_f32(h->rope_sin, sn.data(), sn.size())) || (st = up_f32(h->rope_cos, cs.data(), cs.size()))) {
+            delete h;
+            return st;
+        }
+    }
+    for (auto& L : h->layers) {
+        // assembled from three tensors each: allocate zeroed now (k has no bias; pad rows / columns stay zero)
+        if ((st = alloc_zero(L.qkv_w, (size_t)(round_up(2 * D, 256) + round_up(D, 256) + 256) * D * 2)) || (st = alloc_zero(L.qkv_b, (size_t)3 * D * 4)) ||
+            (st = alloc_zero(L.g_w, (size_t)round_up(h->HN, 256) * D * 2)) || (st = alloc_zero(L.x_w, (size_t)round_up(h->HN, 256) * D * 2)) ||
+            (st = alloc_zero(L.g_b, (size_t)round_up(h->HN, 256) * 4)) || (st = alloc_zero(L.x_b, (size_t)round_up(h->HN, 256) * 4)) ||
+            (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2))) {
+            delete h;
+            return st;
+        }
+    }
+    if ((st = alloc_zero(h->patch_w, (size_t)round_up(D, 256) * 2 * h->PK * 2))) {
+        delete h;
+        return st;
+    }
+    auto need = [&](const std::string& k) { h->missing.push_back(k); };
+    for (const char* k : {"patch_embed.proj.weight", "patch_embed.proj.bias", "cls_token", "pos_embed", "fc_norm.weight", "fc_norm.bias", "head.weight",
+                          "head.bias"})
+        need(k);
+    for (int i = 0; i < cfg->depth; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        for (const char* k : {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.q_proj.weight", "attn.q_proj.bias", "attn.k_proj.weight",
+                              "attn.v_proj.weight", "attn.v_proj.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1_g.weight", "mlp.fc1_g.bias",
+                              "mlp.fc1_x.weight", "mlp.fc1_x.bias", "mlp.norm.weight", "mlp.norm.bias", "mlp.fc2.weight", "mlp.fc2.bias"})
+            need(p + k);
+    }
+    *out = h;
+    return HIPTS_OK;
+}
+
+int hipts_eva_destroy(hipts_eva_t* h) {
+    if (h) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+        delete h;
+    }
+    return HIPTS_OK;
+}
+
+int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, int64_t numel) {
+    HIPTS_REQUIRE(h && key_c && data, "hipts_eva_set_tensor: null argument");
+    HIPTS_TRY(use_device(h->device));
+    const std::string key(key_c);
+    const auto& c = h->cfg;
+    const bool f16 = c.operand_f16 != 0;
+    const int D = c.dim, P = c.patch, Hd = c.mlp_hidden, C = c.num_classes;
+    int st = HIPTS_OK;
+#define EXPECT(n)                                                                                                         \
+    do {                                                                                                                  \
+        if (numel != (int64_t)(n)) return set_error(HIPTS_ERR_INVALID, "tensor %s: %lld elements, expected %lld", key_c, (long long)numel, (long long)(n)); \
+    } while (0)
+    if (key == "patch_embed.proj.weight") {
+        EXPECT((int64_t)D * 3 * P * P);
+        // [n][c_model][ky][kx] -> [n][(ky*P + kx)*3 + c_mem], c_model = 2 - c_mem (BGR flip), duplicated for hi | lo
+        const int K1 = P * P * 3;
+        std::vector<float> w2((size_t)D * 2 * h->PK, 0.f);
+        for (int n = 0; n < D; ++n)
+            for (int cm = 0; cm < 3; ++cm)
+                for (int t = 0; t < P * P; ++t) {
+                    const float v = data[((size_t)n * 3 + (2 - cm)) * P * P + t];
+                    w2[(size_t)n * 2 * h->PK + t * 3 + cm] = v;
+                    w2[(size_t)n * 2 * h->PK + h->PK + t * 3 + cm] = v;
+                }
+        (void)K1;
+        st = put_rows16(h->patch_w, w2.data(), D, 2 * h->PK, 0, 2 * h->PK, f16);
+    } else if (key == "patch_embed.proj.bias") { EXPECT(D); st = up_f32(h->patch_b, data, D); }
+    else if (key == "cls_token") { EXPECT(D); st = up_f32(h->cls, data, D); }
+    else if (key == "pos_embed") { EXPECT((int64_t)h->T * D); st = up_f32(h->pos, data, (size_t)h->T * D); }
+    else if (key == "fc_norm.weight") { EXPECT(D); st = up_f32(h->fcn_g, data, D); }
+    else if (key == "fc_norm.bias") { EXPECT(D); st = up_f32(h->fcn_b, data, D); }
+    else if (key == "head.bias") { EXPECT(C); st = up_f32(h->head_b, data, C); }
+    else if (key == "head.weight") {
+        EXPECT((int64_t)C * D);
+        std::vector<float> dup((size_t)C * 2 * D);
+        for (int n = 0; n < C; ++n)
+            for (int k2 = 0; k2 < D; ++k2) dup[(size_t)n * 2 * D + k2] = dup[(size_t)n * 2 * D + D + k2] = data[(size_t)n * D + k2];
+        st = upload_matrix16(h->head_w, dup.data(), C, 2 * D, round_up(C, 256), f16);
+    } else if (key.rfind("blocks.", 0) == 0) {
+        const size_t d1 = key.find('.', 7);
+        if (d1 == std::string::npos) return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+        const int li = atoi(key.substr(7, d1 - 7).c_str());
+        if (li < 0 || li >= c.depth) return set_error(HIPTS_ERR_INVALID, "tensor %s: block out of range", key_c);
+        EvaLayer& L = h->layers[li];
+        const std::string t = key.substr(d1 + 1);
+        if (t == "norm1.weight") { EXPECT(D); st = up_f32(L.ln1_g, data, D); }
+        else if (t == "norm1.bias") { EXPECT(D); st = up_f32(L.ln1_b, data, D); }
+        else if (t == "norm2.weight") { EXPECT(D); st = up_f32(L.ln2_g, data, D); }
+        else if (t == "norm2.bias") { EXPECT(D); st = up_f32(L.ln2_b, data, D); }
+        else if (t == "attn.q_proj.weight") { EXPECT((int64_t)D * D); st = put_rows16(L.qkv_w, data, D, D, 0, D, f16); }
+        else if (t == "attn.k_proj.weight") { EXPECT((int64_t)D * D); st = put_rows16(L.qkv_w, data, D, D, D, D, f16); }
+        else if (t == "attn.v_proj.weight") { EXPECT((int64_t)D * D); st = put_rows16(L.qkv_w, data, D, D, 2 * D, D, f16); }
+        else if (t == "attn.q_proj.bias") { EXPECT(D); st = upload(L.qkv_b.as<float>(), data, (size_t)D * 4); }
+        else if (t == "attn.v_proj.bias") { EXPECT(D); st = upload(L.qkv_b.as<float>() + 2 * D, data, (size_t)D * 4); }
+        else if (t == "attn.proj.weight") { EXPECT((int64_t)D * D); st = upload_matrix16(L.proj_w, data, D, D, round_up(D, 256), f16); }
+        else if (t == "attn.proj.bias") { EXPECT(D); st = up_f32(L.proj_b, data, D); }
+        else if (t == "mlp.fc1_g.weight") { EXPECT((int64_t)Hd * D); st = put_rows16(L.g_w, data, Hd, D, 0, D, f16); }
+        else if (t == "mlp.fc1_x.weight") { EXPECT((int64_t)Hd * D); st = put_rows16(L.x_w, data, Hd, D, 0, D, f16); }
+        else if (t == "mlp.fc1_g.bias") { EXPECT(Hd); st = upload(L.g_b.as<float>(), data, (size_t)Hd * 4); }
+        else if (t == "mlp.fc1_x.bias") { EXPECT(Hd); st = upload(L.x_b.as<float>(), data, (size_t)Hd * 4); }
+        else if (t == "mlp.norm.weight") { EXPECT(Hd); st = up_f32(L.mn_g, data, Hd); }
+        else if (t == "mlp.norm.bias") { EXPECT(Hd); st = up_f32(L.mn_b, data, Hd); }
+        else if (t == "mlp.fc2.weight") { EXPECT((int64_t)D * Hd); st = put_rows16(L.fc2_w, data, D, Hd, 0, h->HK, f16); }
+        else if (t == "mlp.fc2.bias") { EXPECT(D); st = up_f32(L.fc2_b, data, D); }
+        else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+    } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
+#undef EXPECT
+    if (st) return st;
+    auto it = std::find(h->missing.begin(), h->missing.end(), key);
+    if (it != h->missing.end()) h->missing.erase(it);
+    return HIPTS_OK;
+}
+
+int hipts_eva_forward_u8(hipts_eva_t* h, const uint8_t* images, int images_memspace, int batch, float* logits_out, float* probs_out,
+                         int out_memspace, void* stream) {
+    return eva_forward_impl(h, images, images_memspace, true, batch, logits_out, probs_out, out_memspace, (hipStream_t)stream);
+}
+
+int hipts_eva_forward_f32(hipts_eva_t* h, const float* x, int x_memspace, int batch, float* logits_out, float* probs_out, int out_memspace,
+                          void* stream) {
+    return eva_forward_impl(h, x, x_memspace, false, batch, logits_out, probs_out, out_memspace, (hipStream_t)stream);
+}
+
+int hipts_eva_flops_per_image(const hipts_eva_t* h, double* flops) {
+    HIPTS_REQUIRE(h && flops, "null argument");
+    const auto& c = h->cfg;
+    const double T = h->T, D = c.dim, Hd = c.mlp_hidden;
+    double f = 2.0 * h->np * D * (double)(c.patch * c.patch * 3);
+    f += c.depth * (2.0 * T * 3 * D * D + 4.0 * T * T * D + 2.0 * T * D * D + 2.0 * T * D * Hd * 3);
+    f += 2.0 * D * c.num_classes;
+    *flops = f;
+    return HIPTS_OK;
+}
+
+}  // extern "C"

@@ -114,7 +114,14 @@ __device__ __forceinline__ void load_bias(const GemmArgs& a, int n0, int wave_n,
 }
 
 // StarReLU (MetaFormer): s * relu(x)^2 + b with scalar s, b.
-__device__ __forceinline__ f32x4 star_relu4(f32x4 x, float s, float b) {
+__device__ __forceinline__ f32x4 star_relu4(f32x4 x, float s, float b, int kind = 0) {
+    if (kind == 1) {        // SiLU: x / (1 + 2^(-x log2 e))
+        const f32x4 g = x * -1.4426950408889634f;
+        const f32x4 e{__builtin_amdgcn_exp2f(g[0]), __builtin_amdgcn_exp2f(g[1]), __builtin_amdgcn_exp2f(g[2]), __builtin_amdgcn_exp2f(g[3])};
+        const f32x4 d = e + 1.0f;
+        return x * f32x4{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]), __builtin_amdgcn_rcpf(d[2]), __builtin_amdgcn_rcpf(d[3])};
+    }
+    if (kind == 2) return x;
     const f32x4 r = __builtin_elementwise_max(x, f32x4{0.f, 0.f, 0.f, 0.f});
     return r * r * s + b;
 }
@@ -363,7 +370,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!nv[j]) continue;
-                    const f32x4 v = star_relu4(acc[i][j] + bv[j], a.star_scale, a.star_bias);
+                    const f32x4 v = star_relu4(acc[i][j] + bv[j], a.star_scale, a.star_bias, a.star_kind);
                     *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = pack4<F16>(v[0], v[1], v[2], v[3]);
                 }
             } else if constexpr (EPI == EPI_GELU) {
@@ -492,7 +499,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                         const f32x4 gv = gelu_f4(v, a.gelu_tanh);
                         o = pack4<F16>(gv[0], gv[1], gv[2], gv[3]);
                     } else if constexpr (EPI == EPI_STAR) {
-                        const f32x4 gv = star_relu4(v, a.star_scale, a.star_bias);
+                        const f32x4 gv = star_relu4(v, a.star_scale, a.star_bias, a.star_kind);
                         o = pack4<F16>(gv[0], gv[1], gv[2], gv[3]);
                     } else
                         o = pack4<F16>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);

@@ -147,6 +147,7 @@ struct GemmArgs {
     const float* ln_beta = nullptr;     // RESID_LN, optional
     float ln_eps = 1e-6f;               // RESID_LN
     float star_scale = 1.0f, star_bias = 0.0f;   // STAR
+    int star_kind = 0;                  // STAR: 0 = StarReLU, 1 = SiLU (x * sigmoid(x)), 2 = identity (bias only)
     float qscale = 1.0f;
     int gelu_tanh = 1;
     int ld_out = 0;                 // row stride of out (elements); 0 = N
@@ -160,8 +161,9 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 
 // softmax(Q K^T) V for every (image, head): q,k [B*H][tokens_pad][64] bf16 (q pre-scaled by
 // head_dim^-0.5), vT [B*H][64][tokens_pad] bf16, out [B*tokens][H*64] bf16.
+// out_tokens_stride: rows an image owns in `out` (0 = tokens).
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
-                     int tokens_pad, bool f16, hipStream_t s, int head_dim = 64);
+                     int tokens_pad, bool f16, hipStream_t s, int head_dim = 64, int out_tokens_stride = 0);
 
 // out[row][:] = bf16((x[row][:] - mean) * rstd * g + b)  (b may be null: bias-free LayerNorm); D % 4 == 0, D <= 1024
 int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,

@@ -28,6 +28,12 @@ class VitConfig(ctypes.Structure):
                 ("gelu_tanh", c_int32), ("pool_then_norm", c_int32), ("max_batch", c_int32), ("operand_f16", c_int32)]
 
 
+class EvaConfig(ctypes.Structure):
+    _fields_ = [("image_size", c_int32), ("patch", c_int32), ("dim", c_int32), ("depth", c_int32), ("heads", c_int32),
+                ("mlp_hidden", c_int32), ("num_classes", c_int32), ("ln_eps", c_float), ("rope_ref_grid", c_int32),
+                ("max_batch", c_int32), ("operand_f16", c_int32)]
+
+
 class CcipConfig(ctypes.Structure):
     _fields_ = [("image_size", c_int32), ("dims", c_int32 * 4), ("depths", c_int32 * 4), ("head_dim", c_int32),
                 ("attn_from_stage", c_int32), ("ln_eps", c_float), ("max_batch", c_int32), ("operand_f16", c_int32)]
@@ -50,6 +56,12 @@ _SIGNATURES = {
     "hipts_vit_profile_enable": [c_void_p, c_int],
     "hipts_vit_profile_read": [c_void_p, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
     "hipts_vit_profile_name": [c_int, c_char_p, c_size_t],
+    "hipts_eva_create": [POINTER(EvaConfig), c_int, POINTER(c_void_p)],
+    "hipts_eva_destroy": [c_void_p],
+    "hipts_eva_set_tensor": [c_void_p, c_char_p, c_void_p, c_int64],
+    "hipts_eva_forward_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "hipts_eva_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "hipts_eva_flops_per_image": [c_void_p, POINTER(c_double)],
     "hipts_ccip_create": [POINTER(CcipConfig), c_int, POINTER(c_void_p)],
     "hipts_ccip_destroy": [c_void_p],
     "hipts_ccip_set_tensor": [c_void_p, c_char_p, c_void_p, c_int64],

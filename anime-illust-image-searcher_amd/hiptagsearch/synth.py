@@ -14,6 +14,11 @@ VIT_B16_448 = dict(image_size=448, patch=16, dim=768, depth=12, heads=12, mlp_di
                    ln_eps=1e-6, gelu_tanh=1, pool_then_norm=0)
 VIT_TINY = dict(image_size=64, patch=16, dim=128, depth=2, heads=2, mlp_dim=256, num_classes=200,
                 ln_eps=1e-6, gelu_tanh=1, pool_then_norm=0)
+# The model the reference really loads (tagging.py:45): EVA02-L/14 @448; hidden = int(1024 * 8 / 3)
+EVA02_L14_448 = dict(image_size=448, patch=14, dim=1024, depth=24, heads=16, mlp_hidden=2730, num_classes=10861, ln_eps=1e-6,
+                     rope_ref_grid=16)
+EVA02_TINY = dict(image_size=56, patch=14, dim=128, depth=2, heads=2, mlp_hidden=340, num_classes=200, ln_eps=1e-6,
+                  rope_ref_grid=16)
 # CCIP feature encoder (gen_cfeatures.py): CAFormer-B36 widths at 384 px, 768-d feature
 CCIP_B36_384 = dict(image_size=384, dims=(128, 256, 512, 768), depths=(3, 12, 18, 3), head_dim=32, ln_eps=1e-6)
 CCIP_TINY = dict(image_size=64, dims=(64, 64, 128, 128), depths=(1, 1, 2, 1), head_dim=32, ln_eps=1e-6)
@@ -61,6 +66,44 @@ def vit_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[st
         w[p + "mlp.fc2.bias"] = _trunc_normal(rng, (D,), 0.02)
     w["norm.weight"] = rng.uniform(0.5, 1.5, D).astype(np.float32)
     w["norm.bias"] = _trunc_normal(rng, (D,), 0.02)
+    w["head.weight"] = rb(_trunc_normal(rng, (C, D), 0.02))
+    w["head.bias"] = _trunc_normal(rng, (C,), 0.02)
+    return w
+
+
+def eva_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[str, np.ndarray]:
+    """Random-init EVA02 checkpoint with timm `Eva` state_dict keys (q/k/v separate, SwiGLU with inner norm),
+    same distributions as vit_weights."""
+    rng = np.random.default_rng(seed)
+    D, P, Hd, C = cfg["dim"], cfg["patch"], cfg["mlp_hidden"], cfg["num_classes"]
+    N = (cfg["image_size"] // P) ** 2
+    rb = round_to_bf16 if bf16_matrices else (lambda a: a)
+    w: Dict[str, np.ndarray] = {}
+    w["patch_embed.proj.weight"] = rb(_trunc_normal(rng, (D, 3, P, P), 0.02))
+    w["patch_embed.proj.bias"] = _trunc_normal(rng, (D,), 0.02)
+    w["cls_token"] = _trunc_normal(rng, (1, 1, D), 0.02)
+    w["pos_embed"] = _trunc_normal(rng, (1, N + 1, D), 0.02)
+    for i in range(cfg["depth"]):
+        p = "blocks.%d." % i
+        for ln in ("norm1", "norm2"):
+            w[p + ln + ".weight"] = rng.uniform(0.5, 1.5, D).astype(np.float32)
+            w[p + ln + ".bias"] = _trunc_normal(rng, (D,), 0.02)
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            w[p + "attn." + nm + ".weight"] = rb(_trunc_normal(rng, (D, D), 0.02))
+        w[p + "attn.q_proj.bias"] = _trunc_normal(rng, (D,), 0.02)
+        w[p + "attn.v_proj.bias"] = _trunc_normal(rng, (D,), 0.02)
+        w[p + "attn.proj.weight"] = rb(_trunc_normal(rng, (D, D), 0.02))
+        w[p + "attn.proj.bias"] = _trunc_normal(rng, (D,), 0.02)
+        w[p + "mlp.fc1_g.weight"] = rb(_trunc_normal(rng, (Hd, D), 0.02))
+        w[p + "mlp.fc1_g.bias"] = _trunc_normal(rng, (Hd,), 0.02)
+        w[p + "mlp.fc1_x.weight"] = rb(_trunc_normal(rng, (Hd, D), 0.02))
+        w[p + "mlp.fc1_x.bias"] = _trunc_normal(rng, (Hd,), 0.02)
+        w[p + "mlp.norm.weight"] = rng.uniform(0.5, 1.5, Hd).astype(np.float32)
+        w[p + "mlp.norm.bias"] = _trunc_normal(rng, (Hd,), 0.02)
+        w[p + "mlp.fc2.weight"] = rb(_trunc_normal(rng, (D, Hd), 0.02))
+        w[p + "mlp.fc2.bias"] = _trunc_normal(rng, (D,), 0.02)
+    w["fc_norm.weight"] = rng.uniform(0.5, 1.5, D).astype(np.float32)
+    w["fc_norm.bias"] = _trunc_normal(rng, (D,), 0.02)
     w["head.weight"] = rb(_trunc_normal(rng, (C, D), 0.02))
     w["head.bias"] = _trunc_normal(rng, (C,), 0.02)
     return w

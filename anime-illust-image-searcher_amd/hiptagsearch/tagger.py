@@ -98,6 +98,39 @@ class ViTTagger:
             pass
 
 
+class EvaTagger(ViTTagger):
+    """Device-resident EVA02 tagger (the model tagging.py:45 names: wd-eva02-large-tagger-v3).  Same interface as
+    ViTTagger; `weights` uses timm `Eva` state_dict keys."""
+
+    _PREFIX = "hipts_eva"
+
+    def __init__(self, cfg: Dict, weights: Dict[str, np.ndarray], max_batch: int = 32, device: int = 0):
+        self.cfg = dict(cfg)
+        self.device = device
+        self.max_batch = max_batch
+        self.num_classes = cfg["num_classes"]
+        c = _lib.EvaConfig(cfg["image_size"], cfg["patch"], cfg["dim"], cfg["depth"], cfg["heads"], cfg["mlp_hidden"], cfg["num_classes"],
+                           cfg.get("ln_eps", 1e-6), cfg.get("rope_ref_grid", 16), max_batch, cfg.get("operand_f16", 0))
+        self._h = c_void_p()
+        _lib.call("hipts_eva_create", ctypes.byref(c), device, ctypes.byref(self._h))
+        for key, val in weights.items():
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            _lib.call("hipts_eva_set_tensor", self._h, key.encode(), _lib.ptr(arr), ctypes.c_int64(arr.size))
+
+    def flops_per_image(self) -> float:
+        f = c_double()
+        _lib.call("hipts_eva_flops_per_image", self._h, ctypes.byref(f))
+        return f.value
+
+    def _run(self, fn: str, x, batch: int, logits, probs):
+        super()._run(fn.replace("hipts_vit", "hipts_eva"), x, batch, logits, probs)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.call("hipts_eva_destroy", self._h)
+            self._h = c_void_p()
+
+
 class TagSelector:
     def __init__(self, category: np.ndarray, max_batch: int = 64, device: int = 0):
         self.category = np.ascontiguousarray(category, dtype=np.int32)

@@ -118,6 +118,41 @@ int hipts_vit_join(hipts_vit_t* h, void* stream);
 int hipts_vit_flops_per_image(const hipts_vit_t* h, double* flops);
 
 /* ------------------------------------------------------------------------------------------
+ * EVA02 tagger forward -- the model the reference actually loads (tagging.py:45: wd-eva02-large-tagger-v3 =
+ * timm eva02_large_patch14_448).  Same call sites as the ViT above (tagging.py:174,176).
+ * Graph: patch-embed conv k=s=patch -> [cls | patches] + pos_embed -> depth x {LN, q/k/v (separate projections,
+ * k without bias), 2-D axial RoPE on the patch tokens, softmax(QK^T/8)V, proj, +res, LN, SwiGLU
+ * (silu(fc1_g) * fc1_x -> LayerNorm -> fc2), +res} -> mean over the patch tokens -> fc_norm -> head.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_eva hipts_eva_t;
+
+typedef struct hipts_eva_config {
+    int32_t image_size;      /* 448                                   */
+    int32_t patch;           /* 14                                    */
+    int32_t dim;             /* 1024 (multiple of 64, at most 1024)   */
+    int32_t depth;           /* 24                                    */
+    int32_t heads;           /* 16  (head dim must be 64)             */
+    int32_t mlp_hidden;      /* 2730 = int(dim * 8 / 3)               */
+    int32_t num_classes;     /* 10861                                 */
+    float   ln_eps;          /* 1e-6                                  */
+    int32_t rope_ref_grid;   /* 16: RoPE positions are rescaled to this reference grid (ref_feat_shape) */
+    int32_t max_batch;
+    int32_t operand_f16;     /* as hipts_vit_config_t.operand_f16     */
+} hipts_eva_config_t;
+
+int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** out);
+int hipts_eva_destroy(hipts_eva_t* h);
+/* timm `Eva` state_dict keys: "patch_embed.proj.weight", "cls_token", "pos_embed", "blocks.0.attn.q_proj.weight",
+ * "blocks.0.attn.k_proj.weight", "blocks.0.mlp.fc1_g.weight", "blocks.0.mlp.norm.weight", "fc_norm.weight", "head.weight", ... */
+int hipts_eva_set_tensor(hipts_eva_t* h, const char* key, const float* data, int64_t numel);
+/* same contracts as hipts_vit_forward_u8 / _f32 */
+int hipts_eva_forward_u8(hipts_eva_t* h, const uint8_t* images, int images_memspace, int batch, float* logits_out, float* probs_out,
+                         int out_memspace, void* stream);
+int hipts_eva_forward_f32(hipts_eva_t* h, const float* x, int x_memspace, int batch, float* logits_out, float* probs_out,
+                          int out_memspace, void* stream);
+int hipts_eva_flops_per_image(const hipts_eva_t* h, double* flops);
+
+/* ------------------------------------------------------------------------------------------
  * CCIP feature encoder.   Replaces the onnxruntime session of gen_cfeatures.py:112-118 and its
  * `session.run(['output'], {'input': x})` call (gen_cfeatures.py:158; batching :133-159).
  * Graph: CAFormer (timm MetaFormer) -- stem conv 7x7 s4 + bias-free LN; four stages (3x3 s2 conv
