@@ -174,12 +174,13 @@ __global__ __launch_bounds__(256) void eva_swiglu_ln_kernel(const bf16_t* __rest
     for (int i = 0; i < MAXV; ++i) {
         const int c0 = (lane + 64 * i) * 8;
         if (c0 >= ld) continue;
+        // gamma / beta are stored zero-padded to ld columns: the pad columns come out as 0 without a test
+        const float4 ga = *reinterpret_cast<const float4*>(gam + c0), gb = *reinterpret_cast<const float4*>(gam + c0 + 4);
+        const float4 ba = *reinterpret_cast<const float4*>(bet + c0), bb = *reinterpret_cast<const float4*>(bet + c0 + 4);
+        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e;
-            o[e] = to_op<F16>(c < Hd ? (v[i][e] - mean) * rstd * gam[c] + bet[c] : 0.f);
-        }
+        for (int e = 0; e < 8; ++e) o[e] = to_op<F16>((v[i][e] - mean) * rstd * gv[e] + bv[e]);
         *reinterpret_cast<bf16x8*>(out + row * ld + c0) = o;
     }
 }
@@ -432,7 +433,8 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
         if ((st = alloc_zero(L.qkv_w, (size_t)(round_up(2 * D, 256) + round_up(D, 256) + 256) * D * 2)) || (st = alloc_zero(L.qkv_b, (size_t)3 * D * 4)) ||
             (st = alloc_zero(L.g_w, (size_t)round_up(h->HN, 256) * D * 2)) || (st = alloc_zero(L.x_w, (size_t)round_up(h->HN, 256) * D * 2)) ||
             (st = alloc_zero(L.g_b, (size_t)round_up(h->HN, 256) * 4)) || (st = alloc_zero(L.x_b, (size_t)round_up(h->HN, 256) * 4)) ||
-            (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2))) {
+            (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2)) || (st = alloc_zero(L.mn_g, (size_t)h->HK * 4)) ||
+            (st = alloc_zero(L.mn_b, (size_t)h->HK * 4))) {
             delete h;
             return st;
         }
@@ -525,8 +527,8 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
         else if (t == "mlp.fc1_x.weight") { EXPECT((int64_t)Hd * D); st = put_rows16(L.x_w, data, Hd, D, 0, D, f16); }
         else if (t == "mlp.fc1_g.bias") { EXPECT(Hd); st = upload(L.g_b.as<float>(), data, (size_t)Hd * 4); }
         else if (t == "mlp.fc1_x.bias") { EXPECT(Hd); st = upload(L.x_b.as<float>(), data, (size_t)Hd * 4); }
-        else if (t == "mlp.norm.weight") { EXPECT(Hd); st = up_f32(L.mn_g, data, Hd); }
-        else if (t == "mlp.norm.bias") { EXPECT(Hd); st = up_f32(L.mn_b, data, Hd); }
+        else if (t == "mlp.norm.weight") { EXPECT(Hd); st = upload(L.mn_g.as<float>(), data, (size_t)Hd * 4); }
+        else if (t == "mlp.norm.bias") { EXPECT(Hd); st = upload(L.mn_b.as<float>(), data, (size_t)Hd * 4); }
         else if (t == "mlp.fc2.weight") { EXPECT((int64_t)D * Hd); st = put_rows16(L.fc2_w, data, D, Hd, 0, h->HK, f16); }
         else if (t == "mlp.fc2.bias") { EXPECT(D); st = up_f32(L.fc2_b, data, D); }
         else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
