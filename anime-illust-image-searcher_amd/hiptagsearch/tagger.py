@@ -244,11 +244,15 @@ class Predictor:
         if self.tagger_model is not None:
             return
         self.cfg = dict(cfg or synth.VIT_B16_448)
+        # an EVA02 configuration (the reference's MODEL_REPO, tagging.py:45) is recognised by its SwiGLU width
+        eva = "mlp_hidden" in self.cfg
+        cls_ = EvaTagger if eva else ViTTagger
         if checkpoint:
-            self.tagger_model = ViTTagger.from_safetensors(checkpoint, self.cfg, max_batch=self.max_batch, device=self.device)
+            self.tagger_model = cls_.from_safetensors(checkpoint, self.cfg, max_batch=self.max_batch, device=self.device)
         else:
-            print("No checkpoint given: using the seeded synthetic ViT weights (no network in this environment).")
-            self.tagger_model = ViTTagger(self.cfg, synth.vit_weights(self.cfg, seed), self.max_batch, self.device)
+            print("No checkpoint given: using the seeded synthetic %s weights (no network in this environment)." % ("EVA02" if eva else "ViT"))
+            weights = synth.eva_weights(self.cfg, seed) if eva else synth.vit_weights(self.cfg, seed)
+            self.tagger_model = cls_(self.cfg, weights, self.max_batch, self.device)
         if labels_csv:
             import pandas as pd
             df = pd.read_csv(labels_csv, usecols=["name", "category"])

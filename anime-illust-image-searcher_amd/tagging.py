@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """python tagging.py --dir D [--after YYYY-MM-DD]        (same flags as the reference, tagging.py:361-383)
 
-Extra switches: --checkpoint model.safetensors (timm key layout) and --labels selected_tags.csv for a
-real wd-vit-tagger; without them the seeded synthetic stand-ins are used (no network here).
+Extra switches: --model vit-b16|eva02-l14, --checkpoint model.safetensors (timm key layout) and --labels
+selected_tags.csv for a real wd tagger; without them the seeded synthetic stand-ins are used (no network here).
 --compat reproduces the reference's dropped tail batch; --batch sets the device batch size."""
 import argparse
 import datetime
@@ -19,12 +19,15 @@ def main(arg_str: list) -> None:
     parser.add_argument('--checkpoint', default=None)
     parser.add_argument('--labels', default=None)
     parser.add_argument('--compat', action='store_true')
+    parser.add_argument('--model', choices=['vit-b16', 'eva02-l14'], default='vit-b16',
+                        help='vit-b16: wd-vit-tagger-v3 geometry (BASELINE.json contract model); eva02-l14: wd-eva02-large-tagger-v3, the repo tagging.py:45 names')
     parser.add_argument('--batch', type=int, default=64)
     parser.add_argument('--device', type=int, default=0)
     args = parser.parse_args(arg_str)
     from hiptagsearch.tagger import Predictor
     predictor = Predictor(device=args.device, max_batch=args.batch, compat=args.compat)
-    predictor.load_model(args.checkpoint, args.labels)
+    from hiptagsearch import synth
+    predictor.load_model(args.checkpoint, args.labels, cfg=synth.EVA02_L14_448 if args.model == 'eva02-l14' else synth.VIT_B16_448)
     after_date = None
     if args.after is not None:
         try:

@@ -219,6 +219,35 @@ def ccip_section(device):
     return out
 
 
+def eva_section(device):
+    """The model the reference really loads (tagging.py:45): EVA02-L/14 @448, 723.5 GFLOP/image, bf16 MFMA."""
+    from hiptagsearch import synth
+    from hiptagsearch.tagger import EvaTagger
+    cfg = dict(synth.EVA02_L14_448)
+    w = synth.eva_weights(cfg, seed=0)
+    out = {"metric": "images/sec tagged, EVA02-L/14 @448 forward + sigmoid (bf16 MFMA)"}
+    for B in (10, 32):                                   # 10 = the reference's batch (tagging.py:49)
+        m = EvaTagger(cfg, w, max_batch=B, device=device)
+        imgs = torch.randint(0, 256, (B, 448, 448, 3), dtype=torch.uint8, device="cuda")
+        probs = torch.empty((B, cfg["num_classes"]), dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            m.forward_u8(imgs, probs=probs, want="probs")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 4
+        for _ in range(n):
+            m.forward_u8(imgs, probs=probs, want="probs")
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        fl = m.flops_per_image()
+        out["images_per_s_batch%d" % B] = B / dt
+        out["tflops_batch%d" % B] = B * fl / dt / 1e12
+        out["flops_per_image"] = fl
+        m.close()
+    out["published_reference"] = "0.59 images/sec CPU (Ryzen 7 5700X), ~2 images/sec GTX 1660 SUPER (reference README, this model)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -399,6 +428,10 @@ def main():
             result["ccip"] = ccip_section(local_rank)
         except Exception as e:
             result["ccip"] = {"error": repr(e)}
+        try:
+            result["eva02_large"] = eva_section(local_rank)
+        except Exception as e:
+            result["eva02_large"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_vit(cfg, weights)
         result["cpu_baseline"]["published_reference"] = "0.59 images/sec (README: EVA02-L tagger on Ryzen 7 5700X; different model and hardware)"

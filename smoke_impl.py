@@ -53,4 +53,14 @@ def run():
     cwant = occip.metaformer_forward(occip.to_torch(cw), occip.preprocess_u8_nhwc(cimgs), dims=ccfg["dims"], depths=ccfg["depths"]).numpy()
     cerr = float(np.abs(feat - cwant).max())
     assert cerr <= 1e-1, "CCIP features differ from the oracle by %g" % cerr
-    print("smoke ok: ViT max|dlogit| = %.2e, tag rows and top-50 identical to the oracle, CCIP max|df| = %.2e" % (err, cerr))
+    # EVA02 tagger (the reference's real model family): tiny geometry vs the oracle
+    from hiptagsearch.tagger import EvaTagger
+    from oracle import eva as oeva
+    ecfg = dict(synth.EVA02_TINY)
+    ew = synth.eva_weights(ecfg, seed=1)
+    eimgs = synth.images_u8(2, ecfg["image_size"], seed=2)
+    elog, _ = EvaTagger(ecfg, ew, max_batch=2).forward_u8(eimgs)
+    ewant = oeva.eva_forward(oeva.to_torch(ew), ovit.preprocess_u8_nhwc(eimgs), patch=ecfg["patch"], heads=ecfg["heads"]).numpy()
+    eerr = float(np.abs(elog - ewant).max())
+    assert eerr <= 1e-2, "EVA02 logits differ from the oracle by %g" % eerr
+    print("smoke ok: ViT max|dlogit| = %.2e, tag rows and top-50 identical to the oracle, CCIP max|df| = %.2e, EVA02 max|dlogit| = %.2e" % (err, cerr, eerr))
