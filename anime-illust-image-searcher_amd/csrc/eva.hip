@@ -41,6 +41,8 @@ struct hipts_eva {
     DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope_sin, rope_cos;
     std::vector<std::string> missing;
     DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, g2, hn, pooled2, logits, probs;
+    hipStream_t sub[2] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {};
 };
 
 namespace {
@@ -260,6 +262,117 @@ int alloc_zero(DevBuf& buf, size_t bytes) {
     return HIPTS_OK;
 }
 
+// The whole kernel sequence for images [i0, i0 + batch) on stream s (every buffer is indexed by image)
+int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int batch, float* lg, float* pr, hipStream_t s, bool shared_chip) {
+    const auto& c = h->cfg;
+    const int S = c.image_size, D = c.dim, P = c.patch, H = c.heads, T = h->T, TS = h->TS, Tp = h->Tp, np = h->np;
+    const bool f16 = c.operand_f16 != 0;
+    const int M = batch * TS;
+    in_dev = (const char*)in_dev + (size_t)i0 * S * S * 3 * (is_u8 ? 1 : 4);
+    const size_t r0 = (size_t)i0 * TS, qo = (size_t)i0 * H * Tp * 64;
+    bf16_t* a0_p = h->a0.as<bf16_t>() + (size_t)i0 * np * 2 * h->PK;
+    float* tmp_p = h->tmp.as<float>() + (size_t)i0 * np * D;
+    float* x = h->x.as<float>() + r0 * D;
+    bf16_t* xn = h->xn.as<bf16_t>() + r0 * D;
+    bf16_t* q_p = h->q.as<bf16_t>() + qo;
+    bf16_t* k_p = h->k.as<bf16_t>() + qo;
+    bf16_t* vT_p = h->vT.as<bf16_t>() + qo;
+    bf16_t* att_p = h->att.as<bf16_t>() + r0 * D;
+    bf16_t* g1_p = h->g1.as<bf16_t>() + r0 * h->HK;
+    bf16_t* g2_p = h->g2.as<bf16_t>() + r0 * h->HK;
+    bf16_t* hn_p = h->hn.as<bf16_t>() + r0 * h->HK;
+    bf16_t* pooled2_p = h->pooled2.as<bf16_t>() + (size_t)i0 * 2 * D;
+    if (lg) lg += (size_t)i0 * c.num_classes;
+    if (pr) pr += (size_t)i0 * c.num_classes;
+    GemmArgs g;
+    {
+        const int64_t total = (int64_t)batch * np * P;
+        const int blocks = ceil_div(total, 256);
+        if (is_u8) {
+            if (f16) eva_patchify_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, a0_p, batch, S, P, h->grid, h->PK);
+            else eva_patchify_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, a0_p, batch, S, P, h->grid, h->PK);
+        } else {
+            if (f16) eva_patchify_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, a0_p, batch, S, P, h->grid, h->PK);
+            else eva_patchify_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, a0_p, batch, S, P, h->grid, h->PK);
+        }
+        HIPTS_LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.shared_chip = shared_chip;
+        g.A = a0_p; g.W = h->patch_w.as<bf16_t>(); g.M = batch * np; g.N = D; g.K = 2 * h->PK;
+        g.bias = h->patch_b.as<float>(); g.out_f32 = tmp_p; g.pos = h->pos.as<float>() + D; g.tokens = np; g.qscale = 1.0f;
+        HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+        const int64_t tot4 = (int64_t)batch * TS * (D / 4);
+        eva_assemble_kernel<<<ceil_div(tot4, 256), 256, 0, s>>>(tmp_p, h->cls.as<float>(), h->pos.as<float>(), x, batch, np, TS, D);
+        HIPTS_LAUNCH_CHECK();
+    }
+    const int64_t bh = (int64_t)batch * H;
+    for (int li = 0; li < c.depth; ++li) {
+        EvaLayer& L = h->layers[li];
+        HIPTS_TRY(launch_layernorm(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.shared_chip = shared_chip;
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D; g.bias = L.qkv_b.as<float>();
+        g.out_bf16 = q_p; g.out2_bf16 = k_p;
+        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation below
+        HIPTS_TRY(launch_gemm(EPI_QK, g, s));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.shared_chip = shared_chip;
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D; g.bias = L.qkv_b.as<float>() + 2 * D;
+        g.out_bf16 = vT_p;
+        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        HIPTS_TRY(launch_gemm(EPI_VT, g, s));
+        {
+            const int64_t total = bh * np * 8;
+            const int blocks = ceil_div(total, 256);
+            if (f16) {
+                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(q_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(k_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+            } else {
+                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(q_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(k_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+            }
+            HIPTS_LAUNCH_CHECK();
+        }
+        HIPTS_TRY(launch_attention(q_p, k_p, vT_p, att_p, batch, H, T, Tp, f16, s, 64, TS));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.shared_chip = shared_chip;
+        g.A = att_p; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        HIPTS_TRY(launch_layernorm(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.shared_chip = shared_chip;
+        g.A = xn; g.W = L.g_w.as<bf16_t>(); g.M = M; g.N = h->HN; g.K = D; g.bias = L.g_b.as<float>();
+        g.out_bf16 = g1_p; g.ld_out = h->HK; g.star_kind = 1;          // bias + SiLU
+        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
+        g.W = L.x_w.as<bf16_t>(); g.bias = L.x_b.as<float>(); g.out_bf16 = g2_p; g.star_kind = 2;   // bias only
+        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
+        if (f16) eva_swiglu_ln_kernel<true><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, g2_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
+        else eva_swiglu_ln_kernel<false><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, g2_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
+        HIPTS_LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.f16 = f16;
+        g.shared_chip = shared_chip;
+        g.A = hn_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+    }
+    if (f16) eva_pool_kernel<true><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, np, TS, D, c.ln_eps);
+    else eva_pool_kernel<false><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, np, TS, D, c.ln_eps);
+    HIPTS_LAUNCH_CHECK();
+    g = GemmArgs{};
+    g.f16 = f16;
+    g.shared_chip = shared_chip;
+    g.A = pooled2_p; g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
+    g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = pr;
+    HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
+    return HIPTS_OK;
+}
+
 int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u8, int batch, float* logits_out, float* probs_out,
                      int out_memspace, hipStream_t s) {
     HIPTS_REQUIRE(h && input && batch >= 1, "hipts_eva_forward: bad arguments");
@@ -269,9 +382,7 @@ int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u
                          h->missing[0].c_str());
     HIPTS_TRY(use_device(h->device));
     const auto& c = h->cfg;
-    const int S = c.image_size, D = c.dim, P = c.patch, H = c.heads, T = h->T, TS = h->TS, Tp = h->Tp, np = h->np;
-    const bool f16 = c.operand_f16 != 0;
-    const int M = batch * TS;
+    const int S = c.image_size;
     const void* in_dev = input;
     if (in_memspace != HIPTS_DEVICE) {
         const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
@@ -282,88 +393,28 @@ int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u
     const bool dev_out = out_memspace == HIPTS_DEVICE;
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
     float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
-    float* x = h->x.as<float>();
-    bf16_t* xn = h->xn.as<bf16_t>();
-    GemmArgs g;
-    {
-        const int64_t total = (int64_t)batch * np * P;
-        const int blocks = ceil_div(total, 256);
-        bf16_t* a0 = h->a0.as<bf16_t>();
-        if (is_u8) {
-            if (f16) eva_patchify_kernel<true, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
-            else eva_patchify_kernel<true, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
-        } else {
-            if (f16) eva_patchify_kernel<false, true><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
-            else eva_patchify_kernel<false, false><<<blocks, 256, 0, s>>>(in_dev, a0, batch, S, P, h->grid, h->PK);
-        }
-        HIPTS_LAUNCH_CHECK();
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.A = a0; g.W = h->patch_w.as<bf16_t>(); g.M = batch * np; g.N = D; g.K = 2 * h->PK;
-        g.bias = h->patch_b.as<float>(); g.out_f32 = h->tmp.as<float>(); g.pos = h->pos.as<float>() + D; g.tokens = np; g.qscale = 1.0f;
-        HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
-        const int64_t tot4 = (int64_t)batch * TS * (D / 4);
-        eva_assemble_kernel<<<ceil_div(tot4, 256), 256, 0, s>>>(h->tmp.as<float>(), h->cls.as<float>(), h->pos.as<float>(), x, batch, np, TS, D);
-        HIPTS_LAUNCH_CHECK();
-    }
-    const int64_t bh = (int64_t)batch * H;
-    for (int li = 0; li < c.depth; ++li) {
-        EvaLayer& L = h->layers[li];
-        HIPTS_TRY(launch_layernorm(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D; g.bias = L.qkv_b.as<float>();
-        g.out_bf16 = h->q.as<bf16_t>(); g.out2_bf16 = h->k.as<bf16_t>();
-        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
-        g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation below
-        HIPTS_TRY(launch_gemm(EPI_QK, g, s));
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D; g.bias = L.qkv_b.as<float>() + 2 * D;
-        g.out_bf16 = h->vT.as<bf16_t>();
-        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
-        HIPTS_TRY(launch_gemm(EPI_VT, g, s));
-        {
-            const int64_t total = bh * np * 8;
-            const int blocks = ceil_div(total, 256);
-            if (f16) {
-                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(h->q.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(h->k.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-            } else {
-                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(h->q.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(h->k.as<bf16_t>(), h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
+    static const int want_streams = getenv("HIPTS_EVA_STREAMS") ? atoi(getenv("HIPTS_EVA_STREAMS")) : 2;
+    const int ns = std::min({want_streams, 2, batch / 8});
+    if (ns >= 2) {
+        // two sub-batches on two internal streams, as in the ViT forward (partial last rounds of the persistent GEMMs)
+        if (!h->ev_fork) {
+            HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; ++i) {
+                HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking));
+                HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
             }
-            HIPTS_LAUNCH_CHECK();
         }
-        HIPTS_TRY(launch_attention(h->q.as<bf16_t>(), h->k.as<bf16_t>(), h->vT.as<bf16_t>(), h->att.as<bf16_t>(), batch, H, T, Tp, f16, s, 64, TS));
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.A = h->att.as<bf16_t>(); g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
-        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
-        HIPTS_TRY(launch_layernorm(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.A = xn; g.W = L.g_w.as<bf16_t>(); g.M = M; g.N = h->HN; g.K = D; g.bias = L.g_b.as<float>();
-        g.out_bf16 = h->g1.as<bf16_t>(); g.ld_out = h->HK; g.star_kind = 1;          // bias + SiLU
-        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
-        g.W = L.x_w.as<bf16_t>(); g.bias = L.x_b.as<float>(); g.out_bf16 = h->g2.as<bf16_t>(); g.star_kind = 2;   // bias only
-        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
-        if (f16) eva_swiglu_ln_kernel<true><<<ceil_div(M, 4), 256, 0, s>>>(h->g1.as<bf16_t>(), h->g2.as<bf16_t>(), L.mn_g.as<float>(), L.mn_b.as<float>(), h->hn.as<bf16_t>(), M, c.mlp_hidden, h->HK, c.ln_eps);
-        else eva_swiglu_ln_kernel<false><<<ceil_div(M, 4), 256, 0, s>>>(h->g1.as<bf16_t>(), h->g2.as<bf16_t>(), L.mn_g.as<float>(), L.mn_b.as<float>(), h->hn.as<bf16_t>(), M, c.mlp_hidden, h->HK, c.ln_eps);
-        HIPTS_LAUNCH_CHECK();
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.A = h->hn.as<bf16_t>(); g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
-        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        HIPTS_HIP(hipEventRecord(h->ev_fork, s));
+        const int nb0 = (batch + 1) / 2;
+        for (int i = 0; i < 2; ++i) {
+            HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
+            HIPTS_TRY(eva_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, lg, pr, h->sub[i], true));
+            HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
+            HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        }
+    } else {
+        HIPTS_TRY(eva_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s, false));
     }
-    if (f16) eva_pool_kernel<true><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), h->pooled2.as<bf16_t>(), np, TS, D, c.ln_eps);
-    else eva_pool_kernel<false><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), h->pooled2.as<bf16_t>(), np, TS, D, c.ln_eps);
-    HIPTS_LAUNCH_CHECK();
-    g = GemmArgs{};
-    g.f16 = f16;
-    g.A = h->pooled2.as<bf16_t>(); g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
-    g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = pr;
-    HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
     if (!dev_out) {
         const size_t bytes = (size_t)batch * c.num_classes * 4;
         if (logits_out) HIPTS_HIP(hipMemcpyAsync(logits_out, lg, bytes, hipMemcpyDeviceToHost, s));
@@ -462,6 +513,11 @@ int hipts_eva_destroy(hipts_eva_t* h) {
     if (h) {
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
+        for (int i = 0; i < 2; ++i) {
+            if (h->sub[i]) (void)hipStreamDestroy(h->sub[i]);
+            if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+        }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
         delete h;
     }
     return HIPTS_OK;

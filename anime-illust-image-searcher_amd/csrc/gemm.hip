@@ -65,6 +65,16 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int rowblk, in
     return *reinterpret_cast<const bf16x8*>(lds_tile + (rowblk * 2 + (r >> 3)) * 1024 + (r & 7) * 128 + c * 16);
 }
 
+// e4m3 operands: a K-tile is 128 elements = the same 128 B row, and the 16x16x128 fragment of lane (r, q) is bytes
+// 32 q .. 32 q + 31 of row r: logical chunks 2 q and 2 q + 1.
+__device__ __forceinline__ i32x8 read_frag8(const char* lds_tile, int rowblk, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    const char* row = lds_tile + (rowblk * 2 + (r >> 3)) * 1024 + (r & 7) * 128;
+    const int4 lo = *reinterpret_cast<const int4*>(row + (((2 * q) ^ (r & 7)) * 16));
+    const int4 hi = *reinterpret_cast<const int4*>(row + (((2 * q + 1) ^ (r & 7)) * 16));
+    return i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+}
+
 __device__ __forceinline__ float gelu_f(float x, int tanh_form) {
     if (tanh_form) {
         // torch gelu(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
@@ -158,6 +168,43 @@ __device__ __forceinline__ void staged_store_rows(char* region, int lane, int mr
             const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
             if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
             *reinterpret_cast<uint4*>(out + (size_t)m * ld + ncol0 + lc * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// The same for e4m3 outputs: a (16 MR) x 64 block is 64 B per row; image rows of 64 B with the 16 B chunk XOR-swizzled by
+// (row >> 2) & 3 (conflict-free 4 B writes: bank = 16 (row & 3) + 4 (chunk ^ (row >> 2) & 3) + lq), read back as
+// 16 rows x 64 B per store instruction.
+template <int MR, typename ValueOf>
+__device__ __forceinline__ void staged_store_rows8(char* region, int lane, int mrow0, int M, uint8_t* out, int ld, int ncol0, int N,
+                                                   ValueOf value_of) {
+    const int lr = lane & 15, lq = lane >> 4, lc = lane & 3, lrow = lane >> 2;
+    const bool nvl = ncol0 + lc * 16 < N;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = pass * 4 + ii;
+            if (i >= MR) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = ii * 16 + lr;
+                const int pc = j ^ ((row >> 2) & 3);
+                const f32x4 v = value_of(i, j);
+                *reinterpret_cast<uint32_t*>(region + row * 64 + pc * 16 + lq * 4) = pack4_e4m3(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r16 = 0; r16 < 4; ++r16) {
+            const int row = r16 * 16 + lrow;
+            const int m = mrow0 + pass * 64 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(region + row * 64 + ((lc ^ ((row >> 2) & 3)) * 16));
+            if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
+            *reinterpret_cast<uint4*>(out + (size_t)m * ld + ncol0 + lc * 16) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
@@ -306,6 +353,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             // through the wave's private 8 KB LDS image (red is dead: every wave is past the last barrier), so that
             // the stores are whole 128 B lines
             const int wave_id = wave_m * 4 + wave_n;
+            if (a.out8)
+                staged_store_rows8<MR>(scratch + wave_id * 8192, lane, m0 + wave_m * (MR * 16), a.M, reinterpret_cast<uint8_t*>(a.out_bf16), ld,
+                                       n0 + wave_n * 64, a.N, [&](int i, int j) { return (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j]; });
+            else
             staged_store_rows<MR, F16>(scratch + wave_id * 8192, lane, m0 + wave_m * (MR * 16), a.M, a.out_bf16, ld, n0 + wave_n * 64, a.N,
                                        [&](int i, int j) { return (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j]; });
             return;
@@ -464,6 +515,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = bias_v[j];
+        if constexpr (EPI == EPI_STAR) {
+            if (a.out8) {
+                staged_store_rows8<MR>(region, lane, mrow0, a.M, reinterpret_cast<uint8_t*>(a.out_bf16), a.ld_out ? a.ld_out : a.N, ncol0, a.N,
+                                       [&](int i, int j) { return star_relu4(acc[i][j] + bv[j], a.star_scale, a.star_bias, a.star_kind); });
+                return;
+            }
+        }
         const int which = (EPI == EPI_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
         const float sc = (EPI == EPI_QK && !which) ? a.qscale : 1.0f;
         const bool nvl = ncol0 + lc * 8 < a.N;
@@ -615,8 +673,14 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a, int tiles_m
 // ---------------------------------------------------------------------------------------------
 // MR = 16-row blocks per wave: 8 -> 256-row tiles, 7 -> 224-row tiles (50176 = 224 * 224: for N = 768 the
 // grid becomes 672 tiles = 3 rounds of 0.875-size tiles instead of 588 = 3 rounds (2.3 needed) of full ones).
-template <int EPI, int MR = 8, bool F16 = false>
+// OP8: e4m3 operands.  A K-tile is the same 256 rows x 128 B (now 128 elements), staged by the same code with the
+// matrices seen as 16-bit ones of K / 2 columns; one 16x16x128 MFMA (32 cycles) replaces the two 16x16x32 (16 each)
+// of a (row block, column block), so the four phases split the column blocks instead of the K halves --
+// phase = (m-half, j-half): 4 x 2 MFMAs, the same 256 matrix-pipe cycles -- and barriers, staging order and counted
+// waits are unchanged.  W fragments are read in phases 0/1 and kept; A fragments in phases 0 and 2.
+template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
     constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -633,8 +697,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         m0 = (bid / tiles_n) * TBM;
         n0 = (bid % tiles_n) * BN;
     };
-    const int K = a.K, nt = K / BK;
+    const int K = OP8 ? a.K / 2 : a.K, nt = K / BK;      // row stride in 16-bit units
     const int w_rows = tiles_n * BN;
+    const int scale_w = (127 - a.w_exp) * 0x01010101, scale_1 = 127 * 0x01010101;
 
     int stamp_tile = 0;
 #define PPSTAMP(idx)                                                                                     \
@@ -716,6 +781,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         if (a.stamps && blockIdx.x == 8 && stamp_tile < 8 && lane == 0) a.stamps[wave * 64 + stamp_tile * 8 + 6] = wall_clock64();
 
         bf16x8 wf[2][4];
+        i32x8 wf8[4], af8[4];
         for (int t = 0; t < nt; ++t) {
             const char* cur = smem + ((par + t) & 1) * STAGE_BYTES;
             char* nxt = smem + ((par + t + 1) & 1) * STAGE_BYTES;
@@ -725,6 +791,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                 const int mh = p >> 1, kk = p & 1;
                 // ---------------- R(P): issue only -- fragment reads of this phase, two loads of the next K-tile
                 bf16x8 af[4];
+                if constexpr (OP8) {
+                    if (p < 2) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) wf8[2 * kk + jj] = read_frag8(cur + TILE_BYTES, wave_n * 4 + 2 * kk + jj, lane);
+                    }
+                    if (kk == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af8[i] = read_frag8(cur, wave_m * MR + mh * 4 + i, lane);
+                    }
+                } else {
                 if (p < 2) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) wf[kk][j] = read_frag(cur + TILE_BYTES, wave_n * 4 + j, kk, lane);
@@ -732,6 +808,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (mh * 4 + i < MR) af[i] = read_frag(cur, wave_m * MR + mh * 4 + i, kk, lane);
+                }
                 if (more) {
                     glds16(src[2 * p], nxt + dst[2 * p]);
                     src[2 * p] += BK;
@@ -755,6 +832,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (OP8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * kk + jj;
+                            if constexpr (EPI == EPI_VT)
+                                acc[mh * 4 + i][j] = mfma_16x16x128_e4m3(af8[i], wf8[j], acc[mh * 4 + i][j], scale_1, scale_w);
+                            else
+                                acc[mh * 4 + i][j] = mfma_16x16x128_e4m3(wf8[j], af8[i], acc[mh * 4 + i][j], scale_w, scale_1);
+                        }
+                } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -765,6 +854,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                         else
                             acc[mh * 4 + i][j] = mfma_16x16x32<F16>(wf[kk][j], af[i], acc[mh * 4 + i][j]);
                     }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -1274,6 +1364,33 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         attr = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM;
+    if (a.op8) {
+        // e4m3 operands: the persistent ping-pong loop with full tiles only
+        if constexpr (EPI == EPI_STAR || EPI == EPI_RESID || EPI == EPI_RESCALE || EPI == EPI_RESID_LN || EPI == EPI_QK || EPI == EPI_VT ||
+                      EPI == EPI_BIAS) {
+            static bool attr8 = false;
+            if (!attr8) {
+                HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                attr8 = true;
+            }
+            static int cus8 = 0;
+            if (!cus8) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                HIPTS_HIP(hipGetDevice(&dev));
+                HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
+                cus8 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            const int tiles_n = (a.N + BN - 1) / BN;
+            const int ntile = tiles_m * tiles_n;
+            const int slots = cus8 >= 8 ? cus8 / 8 * 8 : cus8;
+            gemm_pp_kernel<EPI, 8, true, true><<<ntile > slots ? slots : ntile, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+            HIPTS_LAUNCH_CHECK();
+            return HIPTS_OK;
+        } else {
+            return set_error(HIPTS_ERR_INVALID, "gemm: e4m3 operands are not built for epilogue %d", (int)EPI);
+        }
+    }
     int variant = gemm_variant();
     if (EPI == EPI_RESID_LN) variant = 1;      // the row reduction across waves uses the persistent loop's LDS scratch stage
     if (variant == 1 && EPI != EPI_HEAD && EPI != EPI_RESID_LN && !getenv("HIPTS_GEMM")) {
@@ -1353,6 +1470,10 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
+    if (a.op8) HIPTS_REQUIRE(a.K % 128 == 0 && a.K >= 128, "gemm: K=%d must be a positive multiple of 128 with e4m3 operands", a.K);
+    if (a.out8)
+        HIPTS_REQUIRE((epi == EPI_STAR || epi == EPI_RESID_LN) && (a.ld_out ? a.ld_out : a.N) % 16 == 0,
+                      "gemm: e4m3 output needs the STAR / RESID_LN epilogue and a row stride that is a multiple of 16");
     HIPTS_REQUIRE(a.K % BK == 0 && a.K >= BK, "gemm: K=%d must be a positive multiple of %d", a.K, BK);
     HIPTS_REQUIRE(a.M >= 1 && a.N >= 1, "gemm: empty problem");
     if (epi != EPI_HEAD) HIPTS_REQUIRE(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);

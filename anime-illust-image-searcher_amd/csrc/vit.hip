@@ -147,7 +147,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <bool F16>
+template <bool F16, bool OUT8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ bta, bf16_t* __restrict__ out, int64_t rows,
                                                         int D, float eps) {
@@ -181,6 +181,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < nvec) {
             const float4 gg = gr[c], bb = bta ? br[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (OUT8)
+                reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + row * D)[c] =
+                    pack4_e4m3((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                               (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+            else
             *reinterpret_cast<bf16x4*>(out + row * D + 4 * c) =
                 pack4<F16>((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
                            (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
@@ -778,6 +783,14 @@ int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
+
+int launch_layernorm8(const float* x, const float* g, const float* b, uint8_t* out, int64_t rows, int D, float eps, hipStream_t s) {
+    HIPTS_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d must be a multiple of 4, at most 1024", D);
+    const int blocks = (int)((rows + 3) / 4);
+    layernorm_kernel<true, true><<<blocks, 256, 0, s>>>(x, g, b, reinterpret_cast<bf16_t*>(out), rows, D, eps);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
 }  // namespace hipts
 
 extern "C" {
@@ -863,6 +876,11 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f * 2.0f - 1.0f; };
     for (auto& v : ha) v = f32_to_bf16_rne(rnd());
     for (auto& v : hw) v = f32_to_bf16_rne(rnd() * 0.05f);
+    const bool op8 = getenv("HIPTS_GEMM_OP8") != nullptr;      // e4m3 operands: the same bytes, two finite codes per element
+    if (op8) {
+        for (auto& v : ha) v &= 0xbfbf;
+        for (auto& v : hw) v &= 0xbfbf;
+    }
     HIPTS_TRY(upload(A.p, ha.data(), ha.size() * 2));
     HIPTS_TRY(upload(W.p, hw.data(), hw.size() * 2));
     HIPTS_HIP(hipMemset(bias.p, 0, bias.bytes));
@@ -873,6 +891,7 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     g.out_f32 = of32.as<float>(); g.out_bf16 = obf.as<bf16_t>(); g.out2_bf16 = obf2.as<bf16_t>(); g.pos = pos.as<float>();
     g.tokens = 784; g.tokens_pad = 832; g.heads = N / 128 > 0 ? N / 128 : 1; g.dim = N / 2; g.qscale = 0.125f;
     if (epi == EPI_VT) { g.heads = N / 64; g.dim = N; }
+    if (op8) { g.op8 = 1; g.f16 = 1; g.w_exp = 3; g.out8 = (epi == EPI_STAR && getenv("HIPTS_GEMM_OUT8")) ? 1 : 0; }
     DevBuf stamps;
     if (getenv("HIPTS_GEMM_STAMPS")) {
         HIPTS_TRY(stamps.alloc(4096 * 8 * 8));
@@ -949,6 +968,38 @@ extern "C" int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, co
     g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>(); g.out_f32 = out.as<float>();
     HIPTS_TRY(launch_gemm(EPI_RESID, g, nullptr));
     HIPTS_HIP(hipMemcpy(out_host, out.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}
+
+// Test entry for the e4m3 operand path: quantises a (as is) and w (times the per-tensor power of two, returned in
+// *w_exp) on the host, runs out = A W^T (kind 0: fp32 through EPI_RESID into zeros; kind 1: e4m3 bytes through the
+// staged EPI_STAR epilogue with the identity activation) and returns the result.
+extern "C" int hiptsdbg_gemm8_run(int M, int N, int K, const float* a_f32, const float* w_f32, int kind, void* out_host, int* w_exp) {
+    HIPTS_TRY(use_device(0));
+    HIPTS_REQUIRE(M >= 1 && N >= 16 && N % 16 == 0 && K >= 128 && K % 128 == 0 && w_exp, "hiptsdbg_gemm8_run: unsupported shape");
+    const int Np = round_up(N, 256);
+    DevBuf A, W, bias, out;
+    HIPTS_TRY(A.alloc((size_t)M * K));
+    std::vector<uint8_t> ha((size_t)M * K);
+    for (size_t i = 0; i < ha.size(); ++i) ha[i] = f32_to_e4m3_rne(a_f32[i]);
+    HIPTS_TRY(upload(A.p, ha.data(), ha.size()));
+    HIPTS_TRY(upload_matrix8(W, w_f32, N, K, Np, w_exp));
+    HIPTS_TRY(bias.alloc((size_t)Np * 4));
+    HIPTS_TRY(out.alloc((size_t)M * N * 4));
+    HIPTS_HIP(hipMemset(bias.p, 0, bias.bytes));
+    HIPTS_HIP(hipMemset(out.p, 0, out.bytes));
+    GemmArgs g{};
+    g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>();
+    g.f16 = 1; g.op8 = 1; g.w_exp = *w_exp;
+    if (kind == 0) {
+        g.out_f32 = out.as<float>();
+        HIPTS_TRY(launch_gemm(EPI_RESID, g, nullptr));
+        HIPTS_HIP(hipMemcpy(out_host, out.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    } else {
+        g.out_bf16 = out.as<bf16_t>(); g.out8 = 1; g.star_kind = 2;
+        HIPTS_TRY(launch_gemm(EPI_STAR, g, nullptr));
+        HIPTS_HIP(hipMemcpy(out_host, out.p, (size_t)M * N, hipMemcpyDeviceToHost));
+    }
     return HIPTS_OK;
 }
 

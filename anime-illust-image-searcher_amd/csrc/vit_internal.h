@@ -1,5 +1,6 @@
 // vit_internal.h -- shared declarations of the ViT forward kernels (gemm.hip, attn.hip, vit.hip).
 #pragma once
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -14,6 +15,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // The 16-bit MFMA operand type is bf16 (default, what BASELINE.json names) or IEEE half (F16 = true,
 // hipts_vit_config_t.operand_f16): same MFMA rate, 3 more mantissa bits.  Buffers are declared bf16_t
@@ -51,7 +53,60 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- 8-bit operands (OCP e4m3fn, the gfx950 fp8; BASELINE.json configs[4]) ----
+// v_cvt_pk_fp8_f32 rounds to nearest even and turns everything above 464 into NaN (measured, tools/micro/
+// fp8_mfma.hip), so values are clamped to the largest finite e4m3 (448) first.
+__device__ __forceinline__ uint32_t pack4_e4m3(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
+    b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f);
+    d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (uint32_t)p;
+}
+// D += A B with e4m3 operands, K = 128: lane (r = lane & 15, q = lane >> 4) holds bytes 32 q .. 32 q + 31 of row r of
+// both operands (checked with exact data, tools/micro/fp8_mfma.hip); the E8M0 scale bytes multiply the products by
+// 2^(scale - 127) in the instruction -- how the per-tensor power-of-two weight scale is undone for free.
+__device__ __forceinline__ f32x4 mfma_16x16x128_e4m3(i32x8 a, i32x8 b, f32x4 c, int scale_a, int scale_b) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
+}
+
 // ---- host-side operand conversion (weights are converted once at upload) ----
+// float -> e4m3fn bits, round to nearest even, saturating at +-448 (NaN -> 0x7f)
+inline uint8_t f32_to_e4m3_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (uint8_t)(sign | 0x7f);
+    float a;
+    memcpy(&a, &u, 4);
+    if (a >= 448.0f) return (uint8_t)(sign | 0x7e);
+    if (a < 0.0009765625f) return sign;                      // < 2^-10: below half of the smallest subnormal (ties to even -> 0)
+    int e;
+    (void)frexpf(a, &e);                                     // a = m 2^e, m in [0.5, 1)
+    int ex = e - 1;                                          // a = 1.x * 2^ex
+    if (ex < -6) ex = -6;                                    // subnormal range: fixed quantum 2^-9
+    const float q = ldexpf(1.0f, ex - 3);                    // quantum
+    const float n = nearbyintf(a / q);                       // RNE under the default rounding mode; exact (a / q has <= 24 bits)
+    float v = n * q;
+    if (v >= 448.0f) return (uint8_t)(sign | 0x7e);
+    if (v < 0.015625f) return (uint8_t)(sign | (uint8_t)n);  // subnormal: mantissa = n (n = 8 is the first normal and encodes alike)
+    int e2;
+    const float m2 = frexpf(v, &e2);                         // v = m2 2^e2
+    const int bexp = e2 - 1 + 7;
+    const int mant = (int)((m2 * 2.0f - 1.0f) * 8.0f);
+    return (uint8_t)(sign | (bexp << 3) | mant);
+}
+inline float e4m3_bits_to_f32(uint8_t v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float f;
+    if (e == 15 && m == 7) f = NAN;
+    else if (e == 0) f = ldexpf((float)m, -9);
+    else f = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return s ? -f : f;
+}
 inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -108,6 +163,24 @@ inline int upload_matrix16(DevBuf& buf, const float* data, int rows, int cols, i
     return upload(buf.p, h.data(), h.size() * 2);
 }
 
+// rows x cols float matrix -> e4m3 bytes of W * 2^w_exp (per-tensor power-of-two scale that puts max |W| in
+// (224, 448]; the GEMM undoes it through the MFMA scale operand), zero padded to rows_pad rows
+inline int upload_matrix8(DevBuf& buf, const float* data, int rows, int cols, int rows_pad, int* w_exp) {
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) mx = fmaxf(mx, fabsf(data[i]));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) {
+        e = (int)floorf(log2f(448.0f / mx));
+        if (ldexpf(mx, e) > 448.0f) --e;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    std::vector<uint8_t> h((size_t)rows_pad * cols, 0);
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) h[i] = f32_to_e4m3_rne(ldexpf(data[i], e));
+    *w_exp = e;
+    HIPTS_TRY(buf.alloc(h.size()));
+    return upload(buf.p, h.data(), h.size());
+}
+
 // GEMM  C[M,N] = A[M,K] (bf16, row-major) x W[N,K]^T (bf16, row-major: torch Linear layout), fp32
 // accumulate on MFMA, fused epilogue.  K % 64 == 0; W must be allocated (zero padded) up to a
 // multiple of 256 rows; A rows beyond M are never read (row index clamped), stores are masked.
@@ -152,6 +225,9 @@ struct GemmArgs {
     int gelu_tanh = 1;
     int ld_out = 0;                 // row stride of out (elements); 0 = N
     int f16 = 0;                    // operands (and 16-bit outputs) are IEEE half instead of bf16
+    int op8 = 0;                    // A and W are e4m3 bytes (K counts elements, K % 128 == 0; W holds W * 2^w_exp); 16-bit outputs are half
+    int w_exp = 0;                  // op8: the weight scale exponent
+    int out8 = 0;                   // STAR / RESID_LN: the 16-bit output (out_bf16) is written as e4m3 bytes instead (ld_out in bytes)
     int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
     int trace = 0;                          // diagnostic: per-workgroup timeline records instead of stamps (dw loop)
     unsigned long long* stamps = nullptr;   // diagnostic build only (tools/gemm_bench.py): s_memtime stamps of block 0
@@ -168,5 +244,7 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
 // out[row][:] = bf16((x[row][:] - mean) * rstd * g + b)  (b may be null: bias-free LayerNorm); D % 4 == 0, D <= 1024
 int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,
                      hipStream_t s);
+// the same with e4m3 output bytes (the A operand of an op8 GEMM)
+int launch_layernorm8(const float* x, const float* g, const float* b, uint8_t* out, int64_t rows, int D, float eps, hipStream_t s);
 
 }  // namespace hipts

@@ -42,6 +42,8 @@ def main(arg_str: list) -> None:
     parser.add_argument('--checkpoint', default=None)
     parser.add_argument('--batch', type=int, default=64)
     parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='bf16',
+                        help='MFMA operand type of the encoder GEMMs (e4m3 = the fp8 mode: faster, 3 mantissa bits)')
     args = parser.parse_args(arg_str)
     after_date = None
     if args.after is not None:
@@ -56,7 +58,7 @@ def main(arg_str: list) -> None:
     from hiptagsearch import synth
     from hiptagsearch.cfeatures import CCIPEncoder, CharacterFeatureIndex, gen_image_ndarray
     from hiptagsearch.index import Similarity
-    cfg = dict(synth.CCIP_B36_384)
+    cfg = dict(synth.CCIP_B36_384, operand_f16={'bf16': 0, 'half': 1, 'e4m3': 2}[args.operands])
     if args.checkpoint:
         encoder = CCIPEncoder.from_safetensors(args.checkpoint, cfg, max_batch=args.batch, device=args.device)
     else:

@@ -37,10 +37,30 @@ def _ln(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
+def _q8(a: torch.Tensor) -> torch.Tensor:
+    """Activation as an e4m3 operand: saturate at +-448, round to nearest even (OCP e4m3fn)."""
+    return a.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def _q8w(m: torch.Tensor) -> torch.Tensor:
+    """Weight matrix as stored by the e4m3 mode: e4m3(W 2^e) 2^-e with the per-tensor power of two e that puts
+    max |W| in (224, 448] (csrc/vit_internal.h upload_matrix8)."""
+    mx = float(m.abs().max())
+    if mx == 0.0:
+        return m
+    e = int(np.floor(np.log2(448.0 / mx)))
+    if mx * 2.0 ** e > 448.0:
+        e -= 1
+    return (m * 2.0 ** e).to(torch.float8_e4m3fn).to(torch.float32) * 2.0 ** -e
+
+
 @torch.no_grad()
 def metaformer_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, *, dims: Sequence[int], depths: Sequence[int],
-                       head_dim: int = 32, eps: float = 1e-6, attn_from_stage: int = 2) -> torch.Tensor:
-    """x: float32 [B,3,S,S] (normalised RGB).  Returns the pooled, normalised feature [B, dims[-1]]."""
+                       head_dim: int = 32, eps: float = 1e-6, attn_from_stage: int = 2, e4m3: bool = False) -> torch.Tensor:
+    """x: float32 [B,3,S,S] (normalised RGB).  Returns the pooled, normalised feature [B, dims[-1]].
+    e4m3=True emulates the library's fp8 operand mode (hipts_ccip_config_t.operand_f16 = 2): in stages whose width is a
+    multiple of 128 the operands of pwconv2, fc1 and fc2 -- activations and weights -- are rounded to e4m3 first;
+    everything else stays float32.  It separates the mode's rounding noise from implementation error."""
     t = F.conv2d(x, w["stem.conv.weight"], w["stem.conv.bias"], stride=4, padding=2).permute(0, 2, 3, 1)   # NHWC
     t = _ln(t, w["stem.norm.weight"], None, eps)
     for s in range(len(dims)):
@@ -51,6 +71,9 @@ def metaformer_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, *, dims: Seq
                          stride=2, padding=1)
             t = u.permute(0, 2, 3, 1)
         B, H, W, _ = t.shape
+        q8 = e4m3 and C % 128 == 0
+        qa = _q8 if q8 else (lambda a: a)
+        qw = _q8w if q8 else (lambda m: m)
         for i in range(depths[s]):
             p = "stages.%d.blocks.%d." % (s, i)
             h = _ln(t, w[p + "norm1.weight"], None, eps)
@@ -59,7 +82,7 @@ def metaformer_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, *, dims: Seq
                 y = star_relu(y, w[p + "token_mixer.act1.scale"], w[p + "token_mixer.act1.bias"])
                 y = F.conv2d(y.permute(0, 3, 1, 2), w[p + "token_mixer.dwconv.weight"].reshape(2 * C, 1, 7, 7), None, padding=3,
                              groups=2 * C).permute(0, 2, 3, 1)
-                y = F.linear(y, w[p + "token_mixer.pwconv2.weight"].reshape(C, 2 * C))
+                y = F.linear(qa(y), qw(w[p + "token_mixer.pwconv2.weight"].reshape(C, 2 * C)))
             else:                                                       # self-attention, head_dim 32, no biases
                 heads = C // head_dim
                 N = H * W
@@ -71,9 +94,9 @@ def metaformer_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, *, dims: Seq
             rs = w.get(p + "res_scale1.scale")
             t = (t * rs if rs is not None else t) + y
             h = _ln(t, w[p + "norm2.weight"], None, eps)
-            y = F.linear(h, w[p + "mlp.fc1.weight"].reshape(4 * C, C))
+            y = F.linear(qa(h), qw(w[p + "mlp.fc1.weight"].reshape(4 * C, C)))
             y = star_relu(y, w[p + "mlp.act.scale"], w[p + "mlp.act.bias"])
-            y = F.linear(y, w[p + "mlp.fc2.weight"].reshape(C, 4 * C))
+            y = F.linear(qa(y), qw(w[p + "mlp.fc2.weight"].reshape(C, 4 * C)))
             rs = w.get(p + "res_scale2.scale")
             t = (t * rs if rs is not None else t) + y
     f = t.mean(dim=(1, 2))                                              # global average pool

@@ -75,3 +75,31 @@ def test_forward_is_deterministic_and_batch_invariant():
         np.testing.assert_array_equal(again, ref)          # bitwise: no race, no atomics in the forward
     one, _ = model.forward_u8(imgs[4:5])                   # an image's logits do not depend on its batch
     np.testing.assert_array_equal(one[0], ref[4])
+
+
+def test_gemm_e4m3_operands_match_float64():
+    """configs[4] names fp8 MFMA: the e4m3 operand path (v_mfma_scale_f32_16x16x128_f8f6f4) against a float64 product
+    of the same quantised operands (torch's float8_e4m3fn conversion is the independent quantiser), fp32 and e4m3 outputs."""
+    import torch
+    from hiptagsearch import _lib
+    lib = _lib.load()
+    f = lib.hiptsdbg_gemm8_run
+    f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for (M, N, K) in [(256, 256, 128), (1, 16, 128), (300, 272, 256), (3000, 768, 768), (777, 512, 2048), (70000, 256, 128)]:
+        rng = np.random.default_rng(M + 3 * N + 7 * K)
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+        e = ctypes.c_int(0)
+        out = np.empty((M, N), np.float32)
+        assert f(M, N, K, a.ctypes.data, w.ctypes.data, 0, out.ctypes.data, ctypes.byref(e)) == 0, _lib.last_error()
+        assert 224.0 < np.abs(w).max() * 2.0 ** e.value <= 448.0
+        aq = torch.from_numpy(a).to(torch.float8_e4m3fn).to(torch.float64).numpy()
+        wq = torch.from_numpy(w * np.float32(2.0 ** e.value)).to(torch.float8_e4m3fn).to(torch.float64).numpy() * 2.0 ** -e.value
+        want = aq @ wq.T
+        err = np.abs(out - want).max()
+        assert err <= 2e-6 * K ** 0.5 * 4 * np.abs(want).max() + 1e-6, (M, N, K, err)
+        out8 = np.empty((M, N), np.uint8)
+        assert f(M, N, K, a.ctypes.data, w.ctypes.data, 1, out8.ctypes.data, ctypes.byref(e)) == 0, _lib.last_error()
+        got8 = torch.from_numpy(out8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+        want8 = torch.from_numpy(out).to(torch.float8_e4m3fn).to(torch.float32).numpy()      # RNE of the fp32 result
+        np.testing.assert_array_equal(got8, want8)
