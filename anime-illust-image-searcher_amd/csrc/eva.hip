@@ -28,7 +28,7 @@ namespace {
 
 struct EvaLayer {
     DevBuf ln1_g, ln1_b, ln2_g, ln2_b, mn_g, mn_b;
-    DevBuf qkv_w, qkv_b, proj_w, proj_b, g_w, g_b, x_w, x_b, fc2_w, fc2_b;
+    DevBuf qkv_w, qkv_b, proj_w, proj_b, gx_w, gx_b, fc2_w, fc2_b;     // gx: fc1_g | fc1_x rows interleaved per 32 hidden units
 };
 
 }  // namespace
@@ -38,9 +38,9 @@ struct hipts_eva {
     hipts_eva_config_t cfg{};
     int grid = 0, np = 0, T = 0, TS = 0, Tp = 0, PK = 0, HN = 0, HK = 0;
     std::vector<EvaLayer> layers;
-    DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope_sin, rope_cos;
+    DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope;
     std::vector<std::string> missing;
-    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, g2, hn, pooled2, logits, probs;
+    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, hn, pool_part, pooled2, logits, probs;
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
 };
@@ -108,35 +108,10 @@ __global__ __launch_bounds__(256) void eva_assemble_kernel(const float* __restri
     reinterpret_cast<float4*>(x)[idx] = v;
 }
 
-// RoPE in place on q or k, layout [(b*H + h)*Tp + t][64]: for the patch tokens t = 1 .. np,
-// (x0, x1) -> (x0 c0 - x1 s0, x1 c1 + x0 s1) with the tables of token t-1.  One thread per 8 values.
-template <bool F16>
-__global__ __launch_bounds__(256) void eva_rope_kernel(bf16_t* __restrict__ qk, const float* __restrict__ sn, const float* __restrict__ cs,
-                                                       int64_t bh, int Tp, int np) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = bh * np * 8;
-    if (idx >= total) return;
-    const int c8 = (int)(idx & 7);
-    const int t = (int)((idx >> 3) % np);
-    const int64_t g = idx / ((int64_t)np * 8);
-    bf16_t* p = qk + ((g * Tp + 1 + t) * 64 + c8 * 8);
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-    const float* s = sn + (int64_t)t * 64 + c8 * 8;
-    const float* c = cs + (int64_t)t * 64 + c8 * 8;
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const float x0 = from_op<F16>(v[e]), x1 = from_op<F16>(v[e + 1]);
-        o[e] = to_op<F16>(x0 * c[e] - x1 * s[e]);
-        o[e + 1] = to_op<F16>(x1 * c[e + 1] + x0 * s[e + 1]);
-    }
-    *reinterpret_cast<bf16x8*>(p) = o;
-}
-
-// hn[row][:] = LN(g1[row][:] * g2[row][:]) over the first Hd columns (g1 = silu(fc1_g), g2 = fc1_x, row pitch ld);
+// hn[row][:] = LN(p[row][:]) over the first Hd columns (p = silu(fc1_g) * fc1_x from the EPI_SWIGLU epilogue, row pitch ld);
 // pad columns [Hd, ld) are written as zero (they are K columns of fc2).  One wave per row, values in registers.
 template <bool F16>
-__global__ __launch_bounds__(256) void eva_swiglu_ln_kernel(const bf16_t* __restrict__ g1, const bf16_t* __restrict__ g2,
+__global__ __launch_bounds__(256) void eva_hidden_ln_kernel(const bf16_t* __restrict__ g1,
                                                             const float* __restrict__ gam, const float* __restrict__ bet,
                                                             bf16_t* __restrict__ out, int64_t rows, int Hd, int ld, float eps) {
     constexpr int MAXV = 8;                          // 8 x 64 lanes x 8 values = 4096 columns at most
@@ -144,17 +119,16 @@ __global__ __launch_bounds__(256) void eva_swiglu_ln_kernel(const bf16_t* __rest
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const bf16_t* a = g1 + row * ld;
-    const bf16_t* b = g2 + row * ld;
     float v[MAXV][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c0 = (lane + 64 * i) * 8;
         if (c0 < ld) {
-            const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c0), y = *reinterpret_cast<const bf16x8*>(b + c0);
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[i][e] = c0 + e < Hd ? from_op<F16>(x[e]) * from_op<F16>(y[e]) : 0.f;
+                v[i][e] = c0 + e < Hd ? from_op<F16>(x[e]) : 0.f;
                 s += v[i][e];
             }
         } else {
@@ -187,14 +161,34 @@ __global__ __launch_bounds__(256) void eva_swiglu_ln_kernel(const bf16_t* __rest
     }
 }
 
-// pooled2[b] = hi | lo of fc_norm(mean over the patch tokens 1 .. np of x[b]).  One 1024-thread workgroup per image.
+// part[b][split][:] = sum of the patch-token rows of split `split` of image b (grid (POOL_SPLITS, batch)): the whole chip
+// reads the 4 MB an image's tokens occupy instead of one workgroup per image (312 -> ~20 us at batch 32).
+constexpr int POOL_SPLITS = 16;
+__global__ __launch_bounds__(256) void eva_colsum_kernel(const float* __restrict__ x, float* __restrict__ part, int np, int TS, int D) {
+    const int split = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int per = (np + POOL_SPLITS - 1) / POOL_SPLITS;
+    const int r0 = split * per, r1 = min(np, r0 + per);
+    if (tid * 4 >= D) return;
+    const float4* xb = reinterpret_cast<const float4*>(x + ((int64_t)b * TS + 1) * D) + tid;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int dq = D >> 2;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+        const float4 v = xb[(int64_t)r * dq];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(part + ((int64_t)b * POOL_SPLITS + split) * D)[tid] = acc;
+}
+
+// pooled2[b] = hi | lo of fc_norm(mean over the patch tokens of x[b]) from the POOL_SPLITS partial row sums.  One
+// 1024-thread workgroup per image; x = part, np = POOL_SPLITS rows, TS = POOL_SPLITS, first row 0, count = patch tokens.
 template <bool F16>
 __global__ __launch_bounds__(1024) void eva_pool_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
-                                                        bf16_t* __restrict__ out, int np, int TS, int D, float eps) {
+                                                        bf16_t* __restrict__ out, int np, int TS, int D, float eps, int count) {
     __shared__ float part[4][1024];
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x & 255, rg = threadIdx.x >> 8;
-    const float* xb = x + ((int64_t)b * TS + 1) * D;
+    const float* xb = x + (int64_t)b * TS * D;
     float m[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int r = rg; r < np; r += 4)
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(1024) void eva_pool_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = tid + 256 * u;
-            m[u] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / (float)np;
+            m[u] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) / (float)count;
             if (c < D) s += m[u];
         }
         s = wsum(s);
@@ -279,7 +273,6 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     bf16_t* vT_p = h->vT.as<bf16_t>() + qo;
     bf16_t* att_p = h->att.as<bf16_t>() + r0 * D;
     bf16_t* g1_p = h->g1.as<bf16_t>() + r0 * h->HK;
-    bf16_t* g2_p = h->g2.as<bf16_t>() + r0 * h->HK;
     bf16_t* hn_p = h->hn.as<bf16_t>() + r0 * h->HK;
     bf16_t* pooled2_p = h->pooled2.as<bf16_t>() + (size_t)i0 * 2 * D;
     if (lg) lg += (size_t)i0 * c.num_classes;
@@ -316,8 +309,9 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D; g.bias = L.qkv_b.as<float>();
         g.out_bf16 = q_p; g.out2_bf16 = k_p;
         g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
-        g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation below
-        HIPTS_TRY(launch_gemm(EPI_QK, g, s));
+        g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation
+        g.rope = h->rope.as<float>(); g.rope_tokens = np;  // 2-D rotary embedding on the fp32 result, in the epilogue
+        HIPTS_TRY(launch_gemm(EPI_QK_ROPE, g, s));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
@@ -325,18 +319,6 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.out_bf16 = vT_p;
         g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         HIPTS_TRY(launch_gemm(EPI_VT, g, s));
-        {
-            const int64_t total = bh * np * 8;
-            const int blocks = ceil_div(total, 256);
-            if (f16) {
-                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(q_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-                eva_rope_kernel<true><<<blocks, 256, 0, s>>>(k_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-            } else {
-                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(q_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-                eva_rope_kernel<false><<<blocks, 256, 0, s>>>(k_p, h->rope_sin.as<float>(), h->rope_cos.as<float>(), bh, Tp, np);
-            }
-            HIPTS_LAUNCH_CHECK();
-        }
         HIPTS_TRY(launch_attention(q_p, k_p, vT_p, att_p, batch, H, T, Tp, f16, s, 64, TS));
         g = GemmArgs{};
         g.f16 = f16;
@@ -347,13 +329,12 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-        g.A = xn; g.W = L.g_w.as<bf16_t>(); g.M = M; g.N = h->HN; g.K = D; g.bias = L.g_b.as<float>();
-        g.out_bf16 = g1_p; g.ld_out = h->HK; g.star_kind = 1;          // bias + SiLU
-        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
-        g.W = L.x_w.as<bf16_t>(); g.bias = L.x_b.as<float>(); g.out_bf16 = g2_p; g.star_kind = 2;   // bias only
-        HIPTS_TRY(launch_gemm(EPI_STAR, g, s));
-        if (f16) eva_swiglu_ln_kernel<true><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, g2_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
-        else eva_swiglu_ln_kernel<false><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, g2_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
+        // fc1_g and fc1_x in one launch (rows interleaved per 32 hidden units); silu(gate) * value in the epilogue
+        g.A = xn; g.W = L.gx_w.as<bf16_t>(); g.M = M; g.N = 2 * h->HK; g.K = D; g.bias = L.gx_b.as<float>();
+        g.out_bf16 = g1_p; g.ld_out = h->HK;
+        HIPTS_TRY(launch_gemm(EPI_SWIGLU, g, s));
+        if (f16) eva_hidden_ln_kernel<true><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
+        else eva_hidden_ln_kernel<false><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
         HIPTS_LAUNCH_CHECK();
         g = GemmArgs{};
         g.f16 = f16;
@@ -361,8 +342,10 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.A = hn_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
         HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
     }
-    if (f16) eva_pool_kernel<true><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, np, TS, D, c.ln_eps);
-    else eva_pool_kernel<false><<<batch, 1024, 0, s>>>(x, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, np, TS, D, c.ln_eps);
+    float* part_p = h->pool_part.as<float>() + (size_t)i0 * POOL_SPLITS * D;
+    eva_colsum_kernel<<<dim3(POOL_SPLITS, batch), 256, 0, s>>>(x, part_p, np, TS, D);
+    if (f16) eva_pool_kernel<true><<<batch, 1024, 0, s>>>(part_p, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, POOL_SPLITS, POOL_SPLITS, D, c.ln_eps, np);
+    else eva_pool_kernel<false><<<batch, 1024, 0, s>>>(part_p, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, POOL_SPLITS, POOL_SPLITS, D, c.ln_eps, np);
     HIPTS_LAUNCH_CHECK();
     g = GemmArgs{};
     g.f16 = f16;
@@ -453,8 +436,8 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     int st = 0;
     if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->vT, qk)) ||
-        (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) || (st = alloc_zero(h->g2, M * h->HK * 2)) ||
-        (st = alloc_zero(h->hn, M * h->HK * 2)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) ||
+        (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
+        (st = alloc_zero(h->hn, M * h->HK * 2)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
         (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
         delete h;
         return st;
@@ -462,7 +445,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     // RoPE tables (timm RotaryEmbeddingCat, in_pixels = False, positions rescaled to the reference grid)
     {
         const int nb = 16;      // head_dim / 4
-        std::vector<float> sn((size_t)h->np * 64), cs((size_t)h->np * 64);
+        std::vector<float> sn((size_t)h->np * 64), cs((size_t)h->np * 64), tab((size_t)h->np * 64);
         for (int y = 0; y < h->grid; ++y)
             for (int xx = 0; xx < h->grid; ++xx)
                 for (int ax = 0; ax < 2; ++ax)
@@ -474,7 +457,12 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
                         sn[o] = sn[o + 1] = sinf(a);
                         cs[o] = cs[o + 1] = cosf(a);
                     }
-        if ((st = up_f32(h->rope_sin, sn.data(), sn.size())) || (st = up_f32(h->rope_cos, cs.data(), cs.size()))) {
+        for (size_t t = 0; t < (size_t)h->np; ++t)
+            for (int i = 0; i < 32; ++i) {          // (sin, cos) of column pair (2i, 2i+1)
+                tab[t * 64 + 2 * i] = sn[t * 64 + 2 * i];
+                tab[t * 64 + 2 * i + 1] = cs[t * 64 + 2 * i];
+            }
+        if ((st = up_f32(h->rope, tab.data(), tab.size()))) {
             delete h;
             return st;
         }
@@ -482,8 +470,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     for (auto& L : h->layers) {
         // assembled from three tensors each: allocate zeroed now (k has no bias; pad rows / columns stay zero)
         if ((st = alloc_zero(L.qkv_w, (size_t)(round_up(2 * D, 256) + round_up(D, 256) + 256) * D * 2)) || (st = alloc_zero(L.qkv_b, (size_t)3 * D * 4)) ||
-            (st = alloc_zero(L.g_w, (size_t)round_up(h->HN, 256) * D * 2)) || (st = alloc_zero(L.x_w, (size_t)round_up(h->HN, 256) * D * 2)) ||
-            (st = alloc_zero(L.g_b, (size_t)round_up(h->HN, 256) * 4)) || (st = alloc_zero(L.x_b, (size_t)round_up(h->HN, 256) * 4)) ||
+            (st = alloc_zero(L.gx_w, (size_t)round_up(2 * h->HK, 256) * D * 2)) || (st = alloc_zero(L.gx_b, (size_t)round_up(2 * h->HK, 256) * 4)) ||
             (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2)) || (st = alloc_zero(L.mn_g, (size_t)h->HK * 4)) ||
             (st = alloc_zero(L.mn_b, (size_t)h->HK * 4))) {
             delete h;
@@ -579,10 +566,19 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
         else if (t == "attn.v_proj.bias") { EXPECT(D); st = upload(L.qkv_b.as<float>() + 2 * D, data, (size_t)D * 4); }
         else if (t == "attn.proj.weight") { EXPECT((int64_t)D * D); st = upload_matrix16(L.proj_w, data, D, D, round_up(D, 256), f16); }
         else if (t == "attn.proj.bias") { EXPECT(D); st = up_f32(L.proj_b, data, D); }
-        else if (t == "mlp.fc1_g.weight") { EXPECT((int64_t)Hd * D); st = put_rows16(L.g_w, data, Hd, D, 0, D, f16); }
-        else if (t == "mlp.fc1_x.weight") { EXPECT((int64_t)Hd * D); st = put_rows16(L.x_w, data, Hd, D, 0, D, f16); }
-        else if (t == "mlp.fc1_g.bias") { EXPECT(Hd); st = upload(L.g_b.as<float>(), data, (size_t)Hd * 4); }
-        else if (t == "mlp.fc1_x.bias") { EXPECT(Hd); st = upload(L.x_b.as<float>(), data, (size_t)Hd * 4); }
+        else if (t == "mlp.fc1_g.weight" || t == "mlp.fc1_x.weight") {
+            // hidden unit u -> physical row 64 (u / 32) + (u % 32), + 32 for the value half (EPI_SWIGLU)
+            EXPECT((int64_t)Hd * D);
+            const int half = t == "mlp.fc1_x.weight" ? 32 : 0;
+            for (int u0 = 0; u0 < Hd && !st; u0 += 32)
+                st = put_rows16(L.gx_w, data + (size_t)u0 * D, std::min(32, Hd - u0), D, (u0 / 32) * 64 + half, D, f16);
+        }
+        else if (t == "mlp.fc1_g.bias" || t == "mlp.fc1_x.bias") {
+            EXPECT(Hd);
+            const int half = t == "mlp.fc1_x.bias" ? 32 : 0;
+            for (int u0 = 0; u0 < Hd && !st; u0 += 32)
+                st = upload(L.gx_b.as<float>() + (u0 / 32) * 64 + half, data + u0, (size_t)std::min(32, Hd - u0) * 4);
+        }
         else if (t == "mlp.norm.weight") { EXPECT(Hd); st = upload(L.mn_g.as<float>(), data, (size_t)Hd * 4); }
         else if (t == "mlp.norm.bias") { EXPECT(Hd); st = upload(L.mn_b.as<float>(), data, (size_t)Hd * 4); }
         else if (t == "mlp.fc2.weight") { EXPECT((int64_t)D * Hd); st = put_rows16(L.fc2_w, data, D, Hd, 0, h->HK, f16); }

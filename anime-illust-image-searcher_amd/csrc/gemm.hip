@@ -210,6 +210,43 @@ __device__ __forceinline__ void staged_store_rows8(char* region, int lane, int m
     }
 }
 
+// A (16 MR) x 32 block of 16-bit values (the SwiGLU product: half as many output columns as accumulator columns):
+// 64 B per row, the image geometry of staged_store_rows8 with 8 B per (row block, column block) -- lane (lr, lq) writes
+// columns 16 jj + 4 lq ..+3 of row 16 i + lr; bank = 16 (row & 3) + 4 (chunk ^ (row >> 2) & 3) + 2 (lq & 1) per half wave.
+template <int MR, bool F16, typename ValueOf>
+__device__ __forceinline__ void staged_store_half_rows(char* region, int lane, int mrow0, int M, bf16_t* out, int ld, int ocol0, int Nout,
+                                                       ValueOf value_of) {
+    const int lr = lane & 15, lq = lane >> 4, lc = lane & 3, lrow = lane >> 2;
+    const bool nvl = ocol0 + lc * 8 < Nout;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = pass * 4 + ii;
+            if (i >= MR) continue;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int row = ii * 16 + lr;
+                const int pc = (jj * 2 + (lq >> 1)) ^ ((row >> 2) & 3);
+                const f32x4 v = value_of(i, jj);
+                *reinterpret_cast<bf16x4*>(region + row * 64 + pc * 16 + (lq & 1) * 8) = pack4<F16>(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r16 = 0; r16 < 4; ++r16) {
+            const int row = r16 * 16 + lrow;
+            const int m = mrow0 + pass * 64 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(region + row * 64 + ((lc ^ ((row >> 2) & 3)) * 16));
+            if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
+            *reinterpret_cast<uint4*>(out + (size_t)m * ld + ocol0 + lc * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // Epilogue shared by both main-loop variants.  acc[i][j]: 16 x 16 tile (i: 16-row block of the
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
@@ -468,7 +505,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
     } else {
         load_bias<EPI>(a, n0, wave_n, lane, bias_v);
     }
-    static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK, "staged epilogue: half-precision outputs only");
+    static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU,
+                  "staged epilogue: half-precision outputs only");
+    constexpr bool IS_QK = EPI == EPI_QK || EPI == EPI_QK_ROPE;
     const int lr = lane & 15, lq = lane >> 4;
     const int ncol0 = n0 + wave_n * 64;
     const int mrow0 = m0 + wave_m * (MR * 16);
@@ -522,13 +561,19 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                 return;
             }
         }
-        const int which = (EPI == EPI_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
-        const float sc = (EPI == EPI_QK && !which) ? a.qscale : 1.0f;
+        if constexpr (EPI == EPI_SWIGLU) {
+            // acc[i][0..1]: gate columns, acc[i][2..3]: value columns of the same 32 hidden units
+            staged_store_half_rows<MR, F16>(region, lane, mrow0, a.M, a.out_bf16, a.ld_out ? a.ld_out : a.N / 2, ncol0 >> 1, a.N >> 1,
+                                            [&](int i, int jj) { return star_relu4(acc[i][jj] + bv[jj], 0.f, 0.f, 1) * (acc[i][jj + 2] + bv[jj + 2]); });
+            return;
+        }
+        const int which = (IS_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
+        const float sc = (IS_QK && !which) ? a.qscale : 1.0f;
         const bool nvl = ncol0 + lc * 8 < a.N;
         const int ld = a.ld_out ? a.ld_out : a.N;
         bf16_t* qk_base = nullptr;
         int head = 0, hd_off = 0;          // this lane's 8 columns: head and offset inside the head
-        if constexpr (EPI == EPI_QK) {
+        if constexpr (IS_QK) {
             qk_base = which ? a.out2_bf16 : a.out_bf16;
             const int col = ncol0 - which * a.dim + lc * 8;
             head = col >> a.hd_log2;
@@ -536,7 +581,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         }
         // (image, token) of this lane's first output row; later rows advance by 8 without dividing again
         int qb = 0, qt = 0;
-        if constexpr (EPI == EPI_QK) {
+        if constexpr (IS_QK) {
             qb = (mrow0 + lrow) / a.tokens;
             qt = (mrow0 + lrow) - qb * a.tokens;
         }
@@ -547,11 +592,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = pass * 4 + ii;
                 if (i >= MR) continue;
+                f32x4 rp[4];                // QK_ROPE: (sin, cos, sin, cos) of this lane's two column pairs, per column block
+                bool rok = false;
+                if constexpr (EPI == EPI_QK_ROPE) {
+                    const int m = mrow0 + i * 16 + lr;
+                    const int t = m - (m / a.tokens) * a.tokens;
+                    rok = t >= 1 && t <= a.rope_tokens;
+                    const f32x4* rr = reinterpret_cast<const f32x4*>(a.rope) + (size_t)(rok ? t - 1 : 0) * 16 + lq;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rp[j] = rr[j * 4];
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = ii * 16 + lr;
                     const int pc = (j * 2 + (lq >> 1)) ^ ((row >> 1) & 7);
-                    const f32x4 v = acc[i][j] + bv[j];
+                    f32x4 v = acc[i][j] + bv[j];
+                    if constexpr (EPI == EPI_QK_ROPE) {
+                        if (rok)
+                            v = f32x4{v[0] * rp[j][1] - v[1] * rp[j][0], v[1] * rp[j][1] + v[0] * rp[j][0],
+                                      v[2] * rp[j][3] - v[3] * rp[j][2], v[3] * rp[j][3] + v[2] * rp[j][2]};
+                    }
                     bf16x4 o;
                     if constexpr (EPI == EPI_GELU) {
                         const f32x4 gv = gelu_f4(v, a.gelu_tanh);
@@ -572,7 +632,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                 const int m = mrow0 + pass * 64 + row;
                 const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
                 const int qb_now = qb, qt_now = qt;
-                if constexpr (EPI == EPI_QK) {
+                if constexpr (IS_QK) {
                     qt += 8;
                     while (qt >= a.tokens) {      // at most once unless an image has fewer than 8 tokens
                         qt -= a.tokens;
@@ -882,10 +942,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         }
         PPSTAMP(4);
         bool staged = false;
-        if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK) {
-            const bool ok = EPI == EPI_VT   ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
-                            : EPI == EPI_QK ? (a.dim % 64 == 0)
-                                            : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
+        if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU) {
+            const bool ok = EPI == EPI_VT                            ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
+                            : (EPI == EPI_QK || EPI == EPI_QK_ROPE) ? (a.dim % 64 == 0)
+                                                                     : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
             if (ok) {
                 gemm_epilogue_staged<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane,
                                                    smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192, bias_pre);
@@ -1322,10 +1382,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmArgs a, int t
         a.stamps[wave * 64 + 3] = wall_clock64() - wall_t0;
     }
     __builtin_amdgcn_s_barrier();       // every wave is past its last fragment read; all loads have landed
-    if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK) {
-        const bool ok = EPI == EPI_VT   ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
-                        : EPI == EPI_QK ? (a.dim % 64 == 0)
-                                        : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
+    if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU) {
+        const bool ok = EPI == EPI_VT                            ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
+                        : (EPI == EPI_QK || EPI == EPI_QK_ROPE) ? (a.dim % 64 == 0)
+                                                                 : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
         if (ok) {
             gemm_epilogue_staged<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane, smem + wave * 8192);
             if (trace && tid == 0) a.stamps[blockIdx.x * 8 + 4] = wall_clock64();
@@ -1392,8 +1452,9 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         }
     }
     int variant = gemm_variant();
+    if (EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU) variant = 1;      // staged epilogue only (pp, or dw below)
     if (EPI == EPI_RESID_LN) variant = 1;      // the row reduction across waves uses the persistent loop's LDS scratch stage
-    if (variant == 1 && EPI != EPI_HEAD && EPI != EPI_RESID_LN && !getenv("HIPTS_GEMM")) {
+    if (variant == 1 && EPI != EPI_HEAD && EPI != EPI_RESID_LN && (!getenv("HIPTS_GEMM") || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU)) {
         // A launch with fewer 256 x 256 tiles than CUs (the CAFormer's late stages: 11 520 tokens x 512 columns
         // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
@@ -1479,6 +1540,10 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     if (epi != EPI_HEAD) HIPTS_REQUIRE(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);
     if (epi == EPI_VT) HIPTS_REQUIRE(a.M % 4 == 0 && a.tokens % 4 == 0, "gemm: V^T epilogue needs tokens %% 4 == 0");
     if (epi == EPI_QK || epi == EPI_VT) HIPTS_REQUIRE(a.hd_log2 == 5 || a.hd_log2 == 6, "gemm: head_dim must be 32 or 64");
+    if (epi == EPI_QK_ROPE)
+        HIPTS_REQUIRE(a.hd_log2 == 6 && a.dim % 64 == 0 && a.rope && a.rope_tokens >= 0 && a.tokens >= 1, "gemm: QK_ROPE needs head_dim 64 and the rotary table");
+    if (epi == EPI_SWIGLU)
+        HIPTS_REQUIRE(a.N % 64 == 0 && (a.ld_out ? a.ld_out : a.N / 2) % 8 == 0 && a.out_bf16, "gemm: SWIGLU needs N %% 64 == 0 and an output stride that is a multiple of 8");
     if (epi == EPI_RESCALE) HIPTS_REQUIRE(a.res_scale != nullptr, "gemm: RESCALE epilogue needs res_scale");
     if (epi == EPI_RESID_LN)
         HIPTS_REQUIRE(a.N <= BN && a.ln_gamma && a.out_bf16 && a.out_f32, "gemm: RESID_LN needs the whole row in one tile (N <= %d), gamma and both outputs", BN);
@@ -1493,6 +1558,8 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
         case EPI_RESCALE: return launch_t<EPI_RESCALE>(a, s);
         case EPI_BIAS: return launch_t<EPI_BIAS>(a, s);
         case EPI_RESID_LN: return launch_t<EPI_RESID_LN>(a, s);
+        case EPI_QK_ROPE: return launch_t<EPI_QK_ROPE>(a, s);
+        case EPI_SWIGLU: return launch_t<EPI_SWIGLU>(a, s);
     }
     return set_error(HIPTS_ERR_INVALID, "gemm: unknown epilogue");
 }

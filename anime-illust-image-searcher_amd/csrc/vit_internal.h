@@ -195,6 +195,11 @@ enum GemmEpilogue {
     EPI_STAR = 6,    // out[m][n] = bf16(star_scale * relu(acc + bias[n])^2 + star_bias)  (StarReLU)
     EPI_RESCALE = 7, // x[m][n] = x[m][n] * res_scale[n] + acc + bias[n]                (fp32 in/out)
     EPI_BIAS = 8,    // x[m][n] = acc + bias[n]                                         (fp32 out)
+    EPI_QK_ROPE = 10, // EPI_QK with the EVA02 2-D rotary embedding applied to the fp32 result before the single rounding: token t
+                      // (1 <= t <= rope_tokens) of an image rotates each column pair (2i, 2i+1) of a 64-wide head by the angle in
+                      // rope[t - 1][i] = (sin, cos); token 0 (class) and padding rows pass through.  Staged epilogue only.
+    EPI_SWIGLU = 11,  // W rows interleaved per 32 hidden units [gate 0..31 | value 0..31]: out[m][u] = bf16(silu(gate + bias) * (value + bias)),
+                      // N / 2 output columns (row stride ld_out).  Staged epilogue only.
     EPI_RESID_LN = 9 // x[m][n] = x[m][n] * (res_scale ? res_scale[n] : 1) + acc + bias[n]  (fp32 in/out), AND the LayerNorm
                      // of the new row: xn[m][n] = bf16((x - mean) * rstd * ln_gamma[n] (+ ln_beta[n])).  Needs the whole
                      // row in one tile: N <= 256.  Saves the separate LayerNorm pass over x (HBM-bound).
@@ -222,6 +227,8 @@ struct GemmArgs {
     float star_scale = 1.0f, star_bias = 0.0f;   // STAR
     int star_kind = 0;                  // STAR: 0 = StarReLU, 1 = SiLU (x * sigmoid(x)), 2 = identity (bias only)
     float qscale = 1.0f;
+    const float* rope = nullptr;    // QK_ROPE: [rope_tokens][32] (sin, cos) pairs
+    int rope_tokens = 0;
     int gelu_tanh = 1;
     int ld_out = 0;                 // row stride of out (elements); 0 = N
     int f16 = 0;                    // operands (and 16-bit outputs) are IEEE half instead of bf16
