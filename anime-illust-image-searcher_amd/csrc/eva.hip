@@ -27,8 +27,13 @@ using namespace hipts;
 namespace {
 
 struct EvaLayer {
-    DevBuf ln1_g, ln1_b, ln2_g, ln2_b, mn_g, mn_b;
-    DevBuf qkv_w, qkv_b, proj_w, proj_b, gx_w, gx_b, fc2_w, fc2_b;     // gx: fc1_g | fc1_x rows interleaved per 32 hidden units
+    DevBuf ln1_g, ln1_b, ln2_g, ln2_b;
+    DevBuf qkv_w, qkv_b, proj_w, proj_b, gx_w, gx_b;     // gx: fc1_g | fc1_x rows interleaved per 32 hidden units
+    // fc2 with the inner LayerNorm (mlp.norm) folded in: fc2(LN(p)) = rstd (W' p) - rstd mean u + c with W' = W diag(gamma),
+    // u[n] = sum_k W'[n][k] (of the rounded operand values), c = W beta + b.  Built when all four tensors are set; the host
+    // copies stay so that any of them can be set again.
+    DevBuf fc2_w, fc2_u, fc2_c;
+    std::vector<float> h_fc2_w, h_fc2_b, h_mn_g, h_mn_b;
 };
 
 }  // namespace
@@ -40,7 +45,7 @@ struct hipts_eva {
     std::vector<EvaLayer> layers;
     DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope;
     std::vector<std::string> missing;
-    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, hn, pool_part, pooled2, logits, probs;
+    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, stat_part, rowstat, pool_part, pooled2, logits, probs;
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
 };
@@ -108,57 +113,34 @@ __global__ __launch_bounds__(256) void eva_assemble_kernel(const float* __restri
     reinterpret_cast<float4*>(x)[idx] = v;
 }
 
-// hn[row][:] = LN(p[row][:]) over the first Hd columns (p = silu(fc1_g) * fc1_x from the EPI_SWIGLU epilogue, row pitch ld);
-// pad columns [Hd, ld) are written as zero (they are K columns of fc2).  One wave per row, values in registers.
-template <bool F16>
-__global__ __launch_bounds__(256) void eva_hidden_ln_kernel(const bf16_t* __restrict__ g1,
-                                                            const float* __restrict__ gam, const float* __restrict__ bet,
-                                                            bf16_t* __restrict__ out, int64_t rows, int Hd, int ld, float eps) {
-    constexpr int MAXV = 8;                          // 8 x 64 lanes x 8 values = 4096 columns at most
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const bf16_t* a = g1 + row * ld;
-    float v[MAXV][8];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c0 = (lane + 64 * i) * 8;
-        if (c0 < ld) {
-            const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + c0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[i][e] = c0 + e < Hd ? from_op<F16>(x[e]) : 0.f;
-                s += v[i][e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+// rowstat[m] = (rstd, rstd * mean) of the hidden row m from the per-64-column partial (sum, sum of squares) pairs the
+// SwiGLU epilogue wrote: part[(block * stride + m)], blocks summed in index order (deterministic).
+__global__ __launch_bounds__(256) void eva_rowstat_kernel(const float2* __restrict__ part, float2* __restrict__ rowstat, int M, int stride,
+                                                          int blocks, int Hd, float eps) {
+    // 64 rows x 4 quarters per workgroup: quarter q sums blocks q, q + 4, ... (8 loads in flight), then the quarters are
+    // combined in a fixed order -- the loop over 86 dependent-latency loads by one thread took 45 us
+    const int q = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ float2 red[4][64];
+    float s1 = 0.f, s2 = 0.f;
+    if (m < M) {
+#pragma unroll 8
+        for (int b = q; b < blocks; b += 4) {
+            const float2 v = part[(size_t)b * stride + m];
+            s1 += v.x;
+            s2 += v.y;
         }
     }
-    const float mean = wsum(s) / (float)Hd;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = (lane + 64 * i) * 8 + e;
-            if (c < Hd) ss += (v[i][e] - mean) * (v[i][e] - mean);
-        }
-    const float rstd = 1.0f / sqrtf(wsum(ss) / (float)Hd + eps);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c0 = (lane + 64 * i) * 8;
-        if (c0 >= ld) continue;
-        // gamma / beta are stored zero-padded to ld columns: the pad columns come out as 0 without a test
-        const float4 ga = *reinterpret_cast<const float4*>(gam + c0), gb = *reinterpret_cast<const float4*>(gam + c0 + 4);
-        const float4 ba = *reinterpret_cast<const float4*>(bet + c0), bb = *reinterpret_cast<const float4*>(bet + c0 + 4);
-        const float gv[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w}, bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = to_op<F16>((v[i][e] - mean) * rstd * gv[e] + bv[e]);
-        *reinterpret_cast<bf16x8*>(out + row * ld + c0) = o;
-    }
+    red[q][threadIdx.x & 63] = make_float2(s1, s2);
+    __syncthreads();
+    if (q != 0 || m >= M) return;
+    const float2 a = red[0][threadIdx.x], b2 = red[1][threadIdx.x], c = red[2][threadIdx.x], d = red[3][threadIdx.x];
+    s1 = (a.x + b2.x) + (c.x + d.x);
+    s2 = (a.y + b2.y) + (c.y + d.y);
+    const float mean = s1 / (float)Hd;
+    const float var = fmaxf(s2 / (float)Hd - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    rowstat[m] = make_float2(rstd, rstd * mean);
 }
 
 // part[b][split][:] = sum of the patch-token rows of split `split` of image b (grid (POOL_SPLITS, batch)): the whole chip
@@ -273,7 +255,9 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     bf16_t* vT_p = h->vT.as<bf16_t>() + qo;
     bf16_t* att_p = h->att.as<bf16_t>() + r0 * D;
     bf16_t* g1_p = h->g1.as<bf16_t>() + r0 * h->HK;
-    bf16_t* hn_p = h->hn.as<bf16_t>() + r0 * h->HK;
+    const int sblocks = 2 * h->HK / 64;                                        // 64-column blocks of the fc1 launch
+    float* stat_p = h->stat_part.as<float>() + 2 * (size_t)sblocks * r0;      // [sblocks][M] float2, this sub-batch's region
+    float* rowstat_p = h->rowstat.as<float>() + 2 * r0;
     bf16_t* pooled2_p = h->pooled2.as<bf16_t>() + (size_t)i0 * 2 * D;
     if (lg) lg += (size_t)i0 * c.num_classes;
     if (pr) pr += (size_t)i0 * c.num_classes;
@@ -332,15 +316,17 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         // fc1_g and fc1_x in one launch (rows interleaved per 32 hidden units); silu(gate) * value in the epilogue
         g.A = xn; g.W = L.gx_w.as<bf16_t>(); g.M = M; g.N = 2 * h->HK; g.K = D; g.bias = L.gx_b.as<float>();
         g.out_bf16 = g1_p; g.ld_out = h->HK;
+        g.stat_part = stat_p; g.stat_stride = M;             // row sums of the product for the LayerNorm folded into fc2
         HIPTS_TRY(launch_gemm(EPI_SWIGLU, g, s));
-        if (f16) eva_hidden_ln_kernel<true><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
-        else eva_hidden_ln_kernel<false><<<ceil_div(M, 4), 256, 0, s>>>(g1_p, L.mn_g.as<float>(), L.mn_b.as<float>(), hn_p, M, c.mlp_hidden, h->HK, c.ln_eps);
+        eva_rowstat_kernel<<<ceil_div(M, 64), 256, 0, s>>>(reinterpret_cast<const float2*>(stat_p), reinterpret_cast<float2*>(rowstat_p), M, M, sblocks,
+                                                           c.mlp_hidden, c.ln_eps);
         HIPTS_LAUNCH_CHECK();
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-        g.A = hn_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
-        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+        g.A = g1_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_c.as<float>(); g.out_f32 = x;
+        g.rowstat = rowstat_p; g.col_u = L.fc2_u.as<float>();
+        HIPTS_TRY(launch_gemm(EPI_RESID_ROWSTAT, g, s));
     }
     float* part_p = h->pool_part.as<float>() + (size_t)i0 * POOL_SPLITS * D;
     eva_colsum_kernel<<<dim3(POOL_SPLITS, batch), 256, 0, s>>>(x, part_p, np, TS, D);
@@ -437,7 +423,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->vT, qk)) ||
         (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
-        (st = alloc_zero(h->hn, M * h->HK * 2)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
+        (st = h->stat_part.alloc((size_t)(2 * h->HK / 64) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
         (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
         delete h;
         return st;
@@ -471,8 +457,8 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
         // assembled from three tensors each: allocate zeroed now (k has no bias; pad rows / columns stay zero)
         if ((st = alloc_zero(L.qkv_w, (size_t)(round_up(2 * D, 256) + round_up(D, 256) + 256) * D * 2)) || (st = alloc_zero(L.qkv_b, (size_t)3 * D * 4)) ||
             (st = alloc_zero(L.gx_w, (size_t)round_up(2 * h->HK, 256) * D * 2)) || (st = alloc_zero(L.gx_b, (size_t)round_up(2 * h->HK, 256) * 4)) ||
-            (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2)) || (st = alloc_zero(L.mn_g, (size_t)h->HK * 4)) ||
-            (st = alloc_zero(L.mn_b, (size_t)h->HK * 4))) {
+            (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2)) || (st = alloc_zero(L.fc2_u, (size_t)round_up(D, 256) * 4)) ||
+            (st = alloc_zero(L.fc2_c, (size_t)round_up(D, 256) * 4))) {
             delete h;
             return st;
         }
@@ -579,10 +565,34 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
             for (int u0 = 0; u0 < Hd && !st; u0 += 32)
                 st = upload(L.gx_b.as<float>() + (u0 / 32) * 64 + half, data + u0, (size_t)std::min(32, Hd - u0) * 4);
         }
-        else if (t == "mlp.norm.weight") { EXPECT(Hd); st = upload(L.mn_g.as<float>(), data, (size_t)Hd * 4); }
-        else if (t == "mlp.norm.bias") { EXPECT(Hd); st = upload(L.mn_b.as<float>(), data, (size_t)Hd * 4); }
-        else if (t == "mlp.fc2.weight") { EXPECT((int64_t)D * Hd); st = put_rows16(L.fc2_w, data, D, Hd, 0, h->HK, f16); }
-        else if (t == "mlp.fc2.bias") { EXPECT(D); st = up_f32(L.fc2_b, data, D); }
+        else if (t == "mlp.norm.weight" || t == "mlp.norm.bias" || t == "mlp.fc2.weight" || t == "mlp.fc2.bias") {
+            if (t == "mlp.norm.weight") { EXPECT(Hd); L.h_mn_g.assign(data, data + Hd); }
+            else if (t == "mlp.norm.bias") { EXPECT(Hd); L.h_mn_b.assign(data, data + Hd); }
+            else if (t == "mlp.fc2.weight") { EXPECT((int64_t)D * Hd); L.h_fc2_w.assign(data, data + (size_t)D * Hd); }
+            else { EXPECT(D); L.h_fc2_b.assign(data, data + D); }
+            if (!L.h_mn_g.empty() && !L.h_mn_b.empty() && !L.h_fc2_w.empty() && !L.h_fc2_b.empty()) {
+                // W' = W diag(gamma) rounded to the operand type; u from the rounded values so that the mean term cancels exactly
+                std::vector<float> wp((size_t)D * Hd), u(D), cc(D);
+                for (int n = 0; n < D; ++n) {
+                    double su = 0.0, sc = 0.0;
+                    for (int k = 0; k < Hd; ++k) {
+                        const float w = L.h_fc2_w[(size_t)n * Hd + k];
+                        const float v = w * L.h_mn_g[k];
+                        wp[(size_t)n * Hd + k] = v;
+                        float r;
+                        if (f16) r = f16_bits_to_f32(f32_to_f16_rne(v));
+                        else { const uint32_t bits = (uint32_t)f32_to_bf16_rne(v) << 16; memcpy(&r, &bits, 4); }
+                        su += (double)r;
+                        sc += (double)w * (double)L.h_mn_b[k];
+                    }
+                    u[n] = (float)su;
+                    cc[n] = (float)(sc + (double)L.h_fc2_b[n]);
+                }
+                st = put_rows16(L.fc2_w, wp.data(), D, Hd, 0, h->HK, f16);
+                if (!st) st = upload(L.fc2_u.as<float>(), u.data(), (size_t)D * 4);
+                if (!st) st = upload(L.fc2_c.as<float>(), cc.data(), (size_t)D * 4);
+            }
+        }
         else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
     } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
 #undef EXPECT

@@ -398,11 +398,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                                        [&](int i, int j) { return (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j]; });
             return;
         }
-        if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE) {
+        if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE || EPI == EPI_RESID_ROWSTAT) {
             f32x4 rs[4];
             if constexpr (EPI == EPI_RESCALE) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rs[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.res_scale + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if constexpr (EPI == EPI_RESID_ROWSTAT) {      // rs = col_u
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.col_u + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             // read-modify-write of the fp32 residual stream: RB x 4 loads of 16 B per lane in flight before the
             // first dependent add (RB 16-row blocks; the fragment registers of the main loop are free here),
@@ -425,11 +429,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     if (m >= a.M) continue;
                     float* row = a.out_f32 + (size_t)m * ld;
+                    float2 st = make_float2(1.f, 0.f);
+                    if constexpr (EPI == EPI_RESID_ROWSTAT) st = *reinterpret_cast<const float2*>(a.rowstat + 2 * (size_t)m);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (!nv[j]) continue;
                         if constexpr (EPI == EPI_RESCALE)
                             *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] * rs[j] + (acc[i2 + u][j] + bv[j]);
+                        else if constexpr (EPI == EPI_RESID_ROWSTAT)
+                            *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + ((acc[i2 + u][j] * st.x - rs[j] * st.y) + bv[j]);
                         else
                             *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + (acc[i2 + u][j] + bv[j]);
                     }
@@ -563,8 +571,24 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
         }
         if constexpr (EPI == EPI_SWIGLU) {
             // acc[i][0..1]: gate columns, acc[i][2..3]: value columns of the same 32 hidden units
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = star_relu4(acc[i][jj] + bv[jj], 0.f, 0.f, 1) * (acc[i][jj + 2] + bv[jj + 2]);
+                if (a.stat_part) {
+                    // this wave's share of the row statistics of the product (a LayerNorm over the hidden units follows):
+                    // sum over the lane's 8 values, then over the four lane quarters
+                    const f32x4 t = acc[i][0] + acc[i][1], q = acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1];
+                    float s1 = (t[0] + t[1]) + (t[2] + t[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+                    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    const int m = mrow0 + i * 16 + lr;
+                    if (lq == 0 && m < a.M && ncol0 < a.N)
+                        *reinterpret_cast<float2*>(a.stat_part + 2 * ((size_t)(ncol0 >> 6) * a.stat_stride + m)) = make_float2(s1, s2);
+                }
+            }
             staged_store_half_rows<MR, F16>(region, lane, mrow0, a.M, a.out_bf16, a.ld_out ? a.ld_out : a.N / 2, ncol0 >> 1, a.N >> 1,
-                                            [&](int i, int jj) { return star_relu4(acc[i][jj] + bv[jj], 0.f, 0.f, 1) * (acc[i][jj + 2] + bv[jj + 2]); });
+                                            [&](int i, int jj) { return acc[i][jj]; });
             return;
         }
         const int which = (IS_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
@@ -1542,6 +1566,8 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_QK || epi == EPI_VT) HIPTS_REQUIRE(a.hd_log2 == 5 || a.hd_log2 == 6, "gemm: head_dim must be 32 or 64");
     if (epi == EPI_QK_ROPE)
         HIPTS_REQUIRE(a.hd_log2 == 6 && a.dim % 64 == 0 && a.rope && a.rope_tokens >= 0 && a.tokens >= 1, "gemm: QK_ROPE needs head_dim 64 and the rotary table");
+    if (epi == EPI_RESID_ROWSTAT) HIPTS_REQUIRE(a.rowstat && a.col_u && a.out_f32, "gemm: RESID_ROWSTAT needs rowstat, col_u and the fp32 stream");
+    if (epi == EPI_SWIGLU) HIPTS_REQUIRE(!a.stat_part || a.stat_stride >= a.M, "gemm: SWIGLU stat_stride must cover M rows");
     if (epi == EPI_SWIGLU)
         HIPTS_REQUIRE(a.N % 64 == 0 && (a.ld_out ? a.ld_out : a.N / 2) % 8 == 0 && a.out_bf16, "gemm: SWIGLU needs N %% 64 == 0 and an output stride that is a multiple of 8");
     if (epi == EPI_RESCALE) HIPTS_REQUIRE(a.res_scale != nullptr, "gemm: RESCALE epilogue needs res_scale");
@@ -1560,6 +1586,7 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
         case EPI_RESID_LN: return launch_t<EPI_RESID_LN>(a, s);
         case EPI_QK_ROPE: return launch_t<EPI_QK_ROPE>(a, s);
         case EPI_SWIGLU: return launch_t<EPI_SWIGLU>(a, s);
+        case EPI_RESID_ROWSTAT: return launch_t<EPI_RESID_ROWSTAT>(a, s);
     }
     return set_error(HIPTS_ERR_INVALID, "gemm: unknown epilogue");
 }

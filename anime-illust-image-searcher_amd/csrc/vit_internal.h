@@ -200,6 +200,9 @@ enum GemmEpilogue {
                       // rope[t - 1][i] = (sin, cos); token 0 (class) and padding rows pass through.  Staged epilogue only.
     EPI_SWIGLU = 11,  // W rows interleaved per 32 hidden units [gate 0..31 | value 0..31]: out[m][u] = bf16(silu(gate + bias) * (value + bias)),
                       // N / 2 output columns (row stride ld_out).  Staged epilogue only.
+    EPI_RESID_ROWSTAT = 12, // x[m][n] += rowstat[m].x * acc - rowstat[m].y * col_u[n] + bias[n]: the residual GEMM of a LayerNorm-ed operand with
+                            // the LayerNorm folded into the weights -- A holds the raw rows p, W holds W diag(gamma), col_u[n] = sum_k W'[n][k],
+                            // bias[n] = W beta + b, rowstat[m] = (rstd, rstd * mean) of row m (from the stat_part partials of EPI_SWIGLU)
     EPI_RESID_LN = 9 // x[m][n] = x[m][n] * (res_scale ? res_scale[n] : 1) + acc + bias[n]  (fp32 in/out), AND the LayerNorm
                      // of the new row: xn[m][n] = bf16((x - mean) * rstd * ln_gamma[n] (+ ln_beta[n])).  Needs the whole
                      // row in one tile: N <= 256.  Saves the separate LayerNorm pass over x (HBM-bound).
@@ -227,6 +230,10 @@ struct GemmArgs {
     float star_scale = 1.0f, star_bias = 0.0f;   // STAR
     int star_kind = 0;                  // STAR: 0 = StarReLU, 1 = SiLU (x * sigmoid(x)), 2 = identity (bias only)
     float qscale = 1.0f;
+    float* stat_part = nullptr;     // SWIGLU (optional): per (64-column block, row) partial (sum, sum of squares) of the fp32 products,
+    int stat_stride = 0;            //   float2 at stat_part[2 * (block * stat_stride + m)]
+    const float* rowstat = nullptr; // RESID_ROWSTAT: float2 per row
+    const float* col_u = nullptr;   // RESID_ROWSTAT
     const float* rope = nullptr;    // QK_ROPE: [rope_tokens][32] (sin, cos) pairs
     int rope_tokens = 0;
     int gelu_tanh = 1;
