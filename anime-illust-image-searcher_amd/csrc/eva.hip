@@ -29,10 +29,12 @@ namespace {
 struct EvaLayer {
     DevBuf ln1_g, ln1_b, ln2_g, ln2_b;
     DevBuf qkv_w, qkv_b, proj_w, proj_b, gx_w, gx_b;     // gx: fc1_g | fc1_x rows interleaved per 32 hidden units
-    // fc2 with the inner LayerNorm (mlp.norm) folded in: fc2(LN(p)) = rstd (W' p) - rstd mean u + c with W' = W diag(gamma),
-    // u[n] = sum_k W'[n][k] (of the rounded operand values), c = W beta + b.  Built when all four tensors are set; the host
-    // copies stay so that any of them can be set again.
-    DevBuf fc2_w, fc2_u, fc2_c;
+    // fc2 with the inner LayerNorm (mlp.norm) folded in: fc2(LN(p)) = rstd (W (gamma p)) - rstd mean u + c with
+    // u[n] = sum_k W[n][k] gamma[k] (of the rounded operand values of W), c = W beta + b; the fc1 epilogue stores gamma p.
+    // Built when all four tensors are set; the host copies stay so that any of them can be set again.
+    DevBuf fc2_w, fc2_u, fc2_c, mn_g;
+    // pre-LayerNorms folded into the GEMM epilogues (EPI_RESID_XG): W gamma and W beta + b of the GEMMs that consume norm1 / norm2
+    DevBuf qkv_u, qkv_c, gx_u, gx_c;
     std::vector<float> h_fc2_w, h_fc2_b, h_mn_g, h_mn_b;
 };
 
@@ -45,7 +47,8 @@ struct hipts_eva {
     std::vector<EvaLayer> layers;
     DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope;
     std::vector<std::string> missing;
-    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, stat_part, rowstat, pool_part, pooled2, logits, probs;
+    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, stat_part, rowstat, xstat, pool_part, pooled2, logits, probs;
+    bool fold_ln = false, fold_dirty = true;      // as in the ViT forward (vit.hip)
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
 };
@@ -283,10 +286,19 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         eva_assemble_kernel<<<ceil_div(tot4, 256), 256, 0, s>>>(tmp_p, h->cls.as<float>(), h->pos.as<float>(), x, batch, np, TS, D);
         HIPTS_LAUNCH_CHECK();
     }
-    const int64_t bh = (int64_t)batch * H;
+    // pre-LayerNorms folded into the neighbouring GEMM epilogues, as in the ViT forward: the residual GEMM writes gamma * x (16-bit)
+    // and the per-tile row sums of x; the consumer finishes the statistics per tile and applies rstd / mean / beta
+    const bool fold = h->fold_ln;
+    const int xblocks = (D + 255) / 256;
+    float* xstat_p = fold ? h->xstat.as<float>() + 2 * (size_t)xblocks * r0 : nullptr;
+    auto folded = [&](GemmArgs& ga, const float* u, const float* cvec) {
+        ga.stat_in = xstat_p; ga.stat_in_blocks = xblocks; ga.stat_in_stride = M; ga.ln_dim = D; ga.ln_eps = c.ln_eps;
+        ga.col_u = u; ga.bias = cvec;
+    };
     for (int li = 0; li < c.depth; ++li) {
         EvaLayer& L = h->layers[li];
-        HIPTS_TRY(launch_layernorm(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        const bool ln1_folded = fold && li > 0;
+        if (!ln1_folded) HIPTS_TRY(launch_layernorm(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
@@ -295,6 +307,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation
         g.rope = h->rope.as<float>(); g.rope_tokens = np;  // 2-D rotary embedding on the fp32 result, in the epilogue
+        if (ln1_folded) folded(g, L.qkv_u.as<float>(), L.qkv_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_QK_ROPE, g, s));
         g = GemmArgs{};
         g.f16 = f16;
@@ -302,14 +315,20 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D; g.bias = L.qkv_b.as<float>() + 2 * D;
         g.out_bf16 = vT_p;
         g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
+        if (ln1_folded) folded(g, L.qkv_u.as<float>() + 2 * D, L.qkv_c.as<float>() + 2 * D);
         HIPTS_TRY(launch_gemm(EPI_VT, g, s));
         HIPTS_TRY(launch_attention(q_p, k_p, vT_p, att_p, batch, H, T, Tp, f16, s, 64, TS));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
         g.A = att_p; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
-        HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
-        HIPTS_TRY(launch_layernorm(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        if (fold) {
+            g.out_bf16 = xn; g.ln_gamma = L.ln2_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
+            HIPTS_TRY(launch_gemm(EPI_RESID_XG, g, s));
+        } else {
+            HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
+            HIPTS_TRY(launch_layernorm(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        }
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
@@ -317,6 +336,8 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.A = xn; g.W = L.gx_w.as<bf16_t>(); g.M = M; g.N = 2 * h->HK; g.K = D; g.bias = L.gx_b.as<float>();
         g.out_bf16 = g1_p; g.ld_out = h->HK;
         g.stat_part = stat_p; g.stat_stride = M;             // row sums of the product for the LayerNorm folded into fc2
+        g.ln_gamma = L.mn_g.as<float>();
+        if (fold) folded(g, L.gx_u.as<float>(), L.gx_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_SWIGLU, g, s));
         eva_rowstat_kernel<<<ceil_div(M, 64), 256, 0, s>>>(reinterpret_cast<const float2*>(stat_p), reinterpret_cast<float2*>(rowstat_p), M, M, sblocks,
                                                            c.mlp_hidden, c.ln_eps);
@@ -326,7 +347,12 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.shared_chip = shared_chip;
         g.A = g1_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_c.as<float>(); g.out_f32 = x;
         g.rowstat = rowstat_p; g.col_u = L.fc2_u.as<float>();
-        HIPTS_TRY(launch_gemm(EPI_RESID_ROWSTAT, g, s));
+        if (fold && li + 1 < c.depth) {      // the next layer's norm1 prepared here
+            g.out_bf16 = xn; g.ln_gamma = h->layers[li + 1].ln1_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
+            HIPTS_TRY(launch_gemm(EPI_RESID_XGI, g, s));
+        } else {
+            HIPTS_TRY(launch_gemm(EPI_RESID_ROWSTAT, g, s));
+        }
     }
     float* part_p = h->pool_part.as<float>() + (size_t)i0 * POOL_SPLITS * D;
     eva_colsum_kernel<<<dim3(POOL_SPLITS, batch), 256, 0, s>>>(x, part_p, np, TS, D);
@@ -362,6 +388,16 @@ int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u
     const bool dev_out = out_memspace == HIPTS_DEVICE;
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
     float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
+    if (h->fold_ln && h->fold_dirty) {
+        const bool f16w = c.operand_f16 != 0;
+        for (auto& L : h->layers) {
+            HIPTS_TRY(launch_fold_ln(L.qkv_w.as<bf16_t>(), f16w, L.ln1_g.as<float>(), L.ln1_b.as<float>(), L.qkv_b.as<float>(), L.qkv_u.as<float>(),
+                                     L.qkv_c.as<float>(), 3 * c.dim, c.dim, s));
+            HIPTS_TRY(launch_fold_ln(L.gx_w.as<bf16_t>(), f16w, L.ln2_g.as<float>(), L.ln2_b.as<float>(), L.gx_b.as<float>(), L.gx_u.as<float>(),
+                                     L.gx_c.as<float>(), 2 * h->HK, c.dim, s));
+        }
+        h->fold_dirty = false;
+    }
     static const int want_streams = getenv("HIPTS_EVA_STREAMS") ? atoi(getenv("HIPTS_EVA_STREAMS")) : 2;
     const int ns = std::min({want_streams, 2, batch / 8});
     if (ns >= 2) {
@@ -416,6 +452,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     h->PK = round_up(cfg->patch * cfg->patch * 3, 64);
     h->HN = round_up(cfg->mlp_hidden, 16);
     h->HK = round_up(cfg->mlp_hidden, 64);
+    h->fold_ln = cfg->dim % 64 == 0 && !getenv("HIPTS_GEMM") && !(getenv("HIPTS_LN_FOLD") && atoi(getenv("HIPTS_LN_FOLD")) == 0);
     h->layers.resize(cfg->depth);
     const size_t M = (size_t)B * h->TS;
     const size_t qk = (size_t)B * cfg->heads * h->Tp * 64 * 2;
@@ -423,7 +460,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->vT, qk)) ||
         (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
-        (st = h->stat_part.alloc((size_t)(2 * h->HK / 64) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
+        (st = h->stat_part.alloc((size_t)(2 * h->HK / 64) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
         (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
         delete h;
         return st;
@@ -458,7 +495,9 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
         if ((st = alloc_zero(L.qkv_w, (size_t)(round_up(2 * D, 256) + round_up(D, 256) + 256) * D * 2)) || (st = alloc_zero(L.qkv_b, (size_t)3 * D * 4)) ||
             (st = alloc_zero(L.gx_w, (size_t)round_up(2 * h->HK, 256) * D * 2)) || (st = alloc_zero(L.gx_b, (size_t)round_up(2 * h->HK, 256) * 4)) ||
             (st = alloc_zero(L.fc2_w, (size_t)round_up(D, 256) * h->HK * 2)) || (st = alloc_zero(L.fc2_u, (size_t)round_up(D, 256) * 4)) ||
-            (st = alloc_zero(L.fc2_c, (size_t)round_up(D, 256) * 4))) {
+            (st = alloc_zero(L.fc2_c, (size_t)round_up(D, 256) * 4)) ||
+            (st = alloc_zero(L.mn_g, (size_t)h->HK * 4)) || (st = alloc_zero(L.qkv_u, (size_t)3 * D * 4)) || (st = alloc_zero(L.qkv_c, (size_t)3 * D * 4)) ||
+            (st = alloc_zero(L.gx_u, (size_t)2 * h->HK * 4)) || (st = alloc_zero(L.gx_c, (size_t)2 * h->HK * 4))) {
             delete h;
             return st;
         }
@@ -571,24 +610,23 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
             else if (t == "mlp.fc2.weight") { EXPECT((int64_t)D * Hd); L.h_fc2_w.assign(data, data + (size_t)D * Hd); }
             else { EXPECT(D); L.h_fc2_b.assign(data, data + D); }
             if (!L.h_mn_g.empty() && !L.h_mn_b.empty() && !L.h_fc2_w.empty() && !L.h_fc2_b.empty()) {
-                // W' = W diag(gamma) rounded to the operand type; u from the rounded values so that the mean term cancels exactly
-                std::vector<float> wp((size_t)D * Hd), u(D), cc(D);
+                // u and c from the rounded operand values of W, so that the mean term cancels against what the MFMA sums
+                std::vector<float> u(D), cc(D);
                 for (int n = 0; n < D; ++n) {
                     double su = 0.0, sc = 0.0;
                     for (int k = 0; k < Hd; ++k) {
                         const float w = L.h_fc2_w[(size_t)n * Hd + k];
-                        const float v = w * L.h_mn_g[k];
-                        wp[(size_t)n * Hd + k] = v;
                         float r;
-                        if (f16) r = f16_bits_to_f32(f32_to_f16_rne(v));
-                        else { const uint32_t bits = (uint32_t)f32_to_bf16_rne(v) << 16; memcpy(&r, &bits, 4); }
-                        su += (double)r;
-                        sc += (double)w * (double)L.h_mn_b[k];
+                        if (f16) r = f16_bits_to_f32(f32_to_f16_rne(w));
+                        else { const uint32_t bits = (uint32_t)f32_to_bf16_rne(w) << 16; memcpy(&r, &bits, 4); }
+                        su += (double)r * (double)L.h_mn_g[k];
+                        sc += (double)r * (double)L.h_mn_b[k];
                     }
                     u[n] = (float)su;
                     cc[n] = (float)(sc + (double)L.h_fc2_b[n]);
                 }
-                st = put_rows16(L.fc2_w, wp.data(), D, Hd, 0, h->HK, f16);
+                st = put_rows16(L.fc2_w, L.h_fc2_w.data(), D, Hd, 0, h->HK, f16);
+                if (!st) st = upload(L.mn_g.as<float>(), L.h_mn_g.data(), (size_t)Hd * 4);      // pad entries stay zero
                 if (!st) st = upload(L.fc2_u.as<float>(), u.data(), (size_t)D * 4);
                 if (!st) st = upload(L.fc2_c.as<float>(), cc.data(), (size_t)D * 4);
             }
@@ -597,6 +635,7 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
     } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
 #undef EXPECT
     if (st) return st;
+    h->fold_dirty = true;
     auto it = std::find(h->missing.begin(), h->missing.end(), key);
     if (it != h->missing.end()) h->missing.erase(it);
     return HIPTS_OK;

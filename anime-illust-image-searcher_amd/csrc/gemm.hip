@@ -103,22 +103,66 @@ __device__ __forceinline__ f32x4 gelu_f4(f32x4 x, int tanh_form) {
     return f32x4{gelu_f(x[0], 0), gelu_f(x[1], 0), gelu_f(x[2], 0), gelu_f(x[3], 0)};
 }
 
+// (rstd, rstd * mean) of row m for a folded LayerNorm: finished by a kernel (rowstat) or from the producer's per-tile partial
+// sums (stat_in; summed in index order, so the result does not depend on who reads it)
+__device__ __forceinline__ float2 row_stat(const GemmArgs& a, int m) {
+    m = m < a.M ? m : a.M - 1;
+    if (a.stat_in) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < a.stat_in_blocks; ++b) {
+            const float2 v = *reinterpret_cast<const float2*>(a.stat_in + 2 * ((size_t)b * a.stat_in_stride + m));
+            s1 += v.x;
+            s2 += v.y;
+        }
+        const float inv = 1.0f / (float)a.ln_dim;
+        const float mean = s1 * inv;
+        const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+        return make_float2(rstd, rstd * mean);
+    }
+    return *reinterpret_cast<const float2*>(a.rowstat + 2 * (size_t)m);
+}
+
+// The same in two steps for the GEMM kernels: thread t of a workgroup requests the (at most four) partial pairs of row m0 + t
+// when the main loop ends, and finishes them into an LDS table once the next tile's prologue has been issued.
+__device__ __forceinline__ void row_stat_request(const GemmArgs& a, int m, float2 (&pv)[4]) {
+    m = m < a.M ? m : a.M - 1;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        pv[b] = b < a.stat_in_blocks ? *reinterpret_cast<const float2*>(a.stat_in + 2 * ((size_t)b * a.stat_in_stride + m)) : make_float2(0.f, 0.f);
+}
+__device__ __forceinline__ float2 row_stat_finish(const GemmArgs& a, const float2 (&pv)[4]) {
+    const float s1 = ((pv[0].x + pv[1].x) + pv[2].x) + pv[3].x, s2 = ((pv[0].y + pv[1].y) + pv[2].y) + pv[3].y;
+    const float inv = 1.0f / (float)a.ln_dim;
+    const float mean = s1 * inv;
+    const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+    return make_float2(rstd, rstd * mean);
+}
+
 // The bias values an epilogue needs, in its accumulator layout (V^T: one column per lane and 16-column
 // block, in [j][0]; otherwise four consecutive columns).  The persistent loop issues these loads before
 // the next tile's prologue so that their latency is not the first thing the epilogue waits for.
 template <int EPI>
+__device__ __forceinline__ void load_cols(const float* __restrict__ vec, const GemmArgs& a, int n0, int wave_n, int lane, f32x4 (&bv)[4]);
+template <int EPI>
 __device__ __forceinline__ void load_bias(const GemmArgs& a, int n0, int wave_n, int lane, f32x4 (&bv)[4]) {
+    load_cols<EPI>(a.bias, a, n0, wave_n, lane, bv);
+}
+// a per-column vector (bias, col_u) in the epilogue's accumulator layout
+template <int EPI>
+__device__ __forceinline__ void load_cols(const float* __restrict__ vec, const GemmArgs& a, int n0, int wave_n, int lane, f32x4 (&bv)[4]) {
     const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if constexpr (EPI == EPI_VT) {
             const int n = n0 + wave_n * 64 + j * 16 + lr;
-            bv[j] = f32x4{n < a.N ? a.bias[n] : 0.f, 0.f, 0.f, 0.f};
+            bv[j] = f32x4{n < a.N ? vec[n] : 0.f, 0.f, 0.f, 0.f};
         } else if constexpr (EPI == EPI_HEAD) {
             bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             const int nc = n0 + wave_n * 64 + j * 16 + 4 * lq;
-            bv[j] = nc < a.N ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[j] = nc < a.N ? *reinterpret_cast<const f32x4*>(vec + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
@@ -139,13 +183,13 @@ __device__ __forceinline__ f32x4 star_relu4(f32x4 x, float s, float b, int kind 
 // Row-contiguous store of a wave's (16 MR) x 64 block of 16-bit values through a private 8 KB LDS image (the
 // mechanism of gemm_epilogue_staged, for epilogues that produce their values from a callback): lane layout
 // in = (row 16 i + lr, columns 16 j + 4 lq ..+3), out = 8 rows x 128 B per store instruction.
-template <int MR, bool F16, typename ValueOf>
+template <int MR, bool F16, int P0 = 0, int P1 = 2, typename ValueOf>
 __device__ __forceinline__ void staged_store_rows(char* region, int lane, int mrow0, int M, bf16_t* out, int ld, int ncol0, int N,
                                                   ValueOf value_of) {
     const int lr = lane & 15, lq = lane >> 4, lc = lane & 7, lrow = lane >> 3;
     const bool nvl = ncol0 + lc * 8 < N;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = P0; pass < P1; ++pass) {
         if (pass) __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
@@ -398,6 +442,85 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                                        [&](int i, int j) { return (acc[i][j] - mean[i]) * rstd[i] * gv[j] + bt[j]; });
             return;
         }
+        if constexpr (EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) {
+            constexpr bool fold = EPI == EPI_RESID_XGI;
+            // (A software-pipelined form -- loads of rows 64..127 in flight under the LDS-staged copy of rows 0..63 -- needs the
+            // 64 load registers, 128 accumulators, gamma and bias at once: it spilled 95 registers and ran 242 vs 215 us.)
+            f32x4 uv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) uv[j] = (fold && nv[j]) ? *reinterpret_cast<const f32x4*>(a.col_u + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // ---- the residual read-modify-write; the new row values stay in acc (two row blocks of loads in flight: four
+            // measured the same, 215 us, with 24 B of spills)
+            constexpr int RB = 2;
+#pragma unroll
+            for (int i2 = 0; i2 < MR; i2 += RB) {
+                f32x4 xv[RB][4];
+                float2 st[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (i2 + u >= MR) continue;
+                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
+                    const int mc = m < a.M ? m : a.M - 1;
+                    const float* row = a.out_f32 + (size_t)mc * ld;
+                    st[u] = fold ? row_stat(a, mc) : make_float2(1.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    if (i2 + u >= MR) continue;
+                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
+                    float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (fold)
+                            acc[i2 + u][j] = nv[j] ? xv[u][j] + (acc[i2 + u][j] * st[u].x + (bv[j] - uv[j] * st[u].y)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        else
+                            acc[i2 + u][j] = nv[j] ? xv[u][j] + (acc[i2 + u][j] + bv[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(row + nc[j]) = acc[i2 + u][j];
+                    }
+                }
+            }
+            if (!a.out_bf16) return;
+            // ---- what the next LayerNorm needs: the row sums over this tile's 256 columns (the four waves that hold a row meet
+            // in LDS, like EPI_RESID_LN), and the gamma-scaled 16-bit copy
+            const int ncol0 = n0 + wave_n * 64;
+            if (a.stat_part) {
+                float2* red = reinterpret_cast<float2*>(scratch);
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    f32x4 t = acc[i][0], q = acc[i][0] * acc[i][0];
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        t = t + acc[i][j];
+                        q = q + acc[i][j] * acc[i][j];
+                    }
+                    float s1 = (t[0] + t[1]) + (t[2] + t[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+                    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    if (lq == 0) red[(wave_m * (MR * 16) + i * 16 + lr) * 4 + wave_n] = make_float2(s1, s2);      // columns past N hold zeros
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int t = wave_n * 64 + lane;                     // 256 threads of a wave group own its MR * 16 rows
+                if (t < MR * 16) {
+                    const int r = wave_m * (MR * 16) + t;
+                    const float2 p0 = red[r * 4], p1 = red[r * 4 + 1], p2 = red[r * 4 + 2], p3 = red[r * 4 + 3];
+                    const int m = m0 + r;
+                    if (m < a.M)
+                        *reinterpret_cast<float2*>(a.stat_part + 2 * ((size_t)(n0 >> 8) * a.stat_stride + m)) =
+                            make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+                }
+                __builtin_amdgcn_s_barrier();       // red is overwritten by the staging images below
+            }
+            f32x4 gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            staged_store_rows<MR, F16>(scratch + (wave_m * 4 + wave_n) * 8192, lane, m0 + wave_m * (MR * 16), a.M, a.out_bf16, ld, ncol0, a.N,
+                                       [&](int i, int j) { return acc[i][j] * gv[j]; });
+            return;
+        }
         if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE || EPI == EPI_RESID_ROWSTAT) {
             f32x4 rs[4];
             if constexpr (EPI == EPI_RESCALE) {
@@ -505,7 +628,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 // Wave-private image: no workgroup barrier, LDS operations of one wave execute in order.
 template <int EPI, int MR, bool F16>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                                     int lane, char* region, const f32x4* bias_pre = nullptr) {
+                                                     int lane, char* region, const f32x4* bias_pre = nullptr, const float2* st_lds = nullptr) {
+    // st_lds: (rstd, rstd * mean) of the tile's rows m0 .. m0 + 255, finished from the producer's partials by the caller
     f32x4 bias_v[4];
     if (bias_pre) {
 #pragma unroll
@@ -516,6 +640,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
     static_assert(EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU,
                   "staged epilogue: half-precision outputs only");
     constexpr bool IS_QK = EPI == EPI_QK || EPI == EPI_QK_ROPE;
+    // LayerNorm folded into this GEMM (see EPI_RESID_XG): value = acc * rstd[row] + (bias[col] - col_u[col] * rstd_mean[row]);
+    // without it the row pair is (1, 0) and col_u is zero, the same expression
+    const bool fold = a.rowstat != nullptr || a.stat_in != nullptr;
+    f32x4 cu[4];
+    if (fold) load_cols<EPI>(a.col_u, a, n0, wave_n, lane, cu);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cu[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int lr = lane & 15, lq = lane >> 4;
     const int ncol0 = n0 + wave_n * 64;
     const int mrow0 = m0 + wave_m * (MR * 16);
@@ -532,13 +665,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = pass * 4 + ii;
                 if (i >= MR) continue;
+                f32x4 sx{1.f, 1.f, 1.f, 1.f}, sy{0.f, 0.f, 0.f, 0.f};      // this lane's four rows (tokens)
+                if (fold) {
+                    const int mr = mrow0 + i * 16 + 4 * lq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float2 st = st_lds ? st_lds[mr + e - m0] : row_stat(a, mr + e);
+                        sx[e] = st.x;
+                        sy[e] = st.y;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 c = acc[i][j];
+                    const f32x4 c = acc[i][j] * sx + (bv[j] - sy * cu[j][0]);
                     const int d = j * 16 + lr;
                     const int pc = (ii * 2 + (lq >> 1)) ^ ((d >> 1) & 7);
-                    *reinterpret_cast<bf16x4*>(region + d * 128 + pc * 16 + (lq & 1) * 8) =
-                        pack4<F16>(c[0] + bv[j], c[1] + bv[j], c[2] + bv[j], c[3] + bv[j]);
+                    *reinterpret_cast<bf16x4*>(region + d * 128 + pc * 16 + (lq & 1) * 8) = pack4<F16>(c[0], c[1], c[2], c[3]);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -573,8 +715,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
             // acc[i][0..1]: gate columns, acc[i][2..3]: value columns of the same 32 hidden units
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
+                float2 st = make_float2(1.f, 0.f);
+                if (fold) st = st_lds ? st_lds[mrow0 - m0 + i * 16 + lr] : row_stat(a, mrow0 + i * 16 + lr);
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = star_relu4(acc[i][jj] + bv[jj], 0.f, 0.f, 1) * (acc[i][jj + 2] + bv[jj + 2]);
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[i][jj] = star_relu4(acc[i][jj] * st.x + (bv[jj] - cu[jj] * st.y), 0.f, 0.f, 1) *
+                                 (acc[i][jj + 2] * st.x + (bv[jj + 2] - cu[jj + 2] * st.y));
                 if (a.stat_part) {
                     // this wave's share of the row statistics of the product (a LayerNorm over the hidden units follows):
                     // sum over the lane's 8 values, then over the four lane quarters
@@ -585,6 +731,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                     const int m = mrow0 + i * 16 + lr;
                     if (lq == 0 && m < a.M && ncol0 < a.N)
                         *reinterpret_cast<float2*>(a.stat_part + 2 * ((size_t)(ncol0 >> 6) * a.stat_stride + m)) = make_float2(s1, s2);
+                }
+                // the gamma of the LayerNorm that follows, applied to the stored operand (the statistics above are of the raw
+                // product): the next GEMM then keeps its own weights unchanged
+                if (a.ln_gamma) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int u0 = (ncol0 >> 1) + jj * 16 + 4 * lq;
+                        if (u0 < (a.N >> 1)) acc[i][jj] = acc[i][jj] * *reinterpret_cast<const f32x4*>(a.ln_gamma + u0);
+                    }
                 }
             }
             staged_store_half_rows<MR, F16>(region, lane, mrow0, a.M, a.out_bf16, a.ld_out ? a.ld_out : a.N / 2, ncol0 >> 1, a.N >> 1,
@@ -616,6 +771,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = pass * 4 + ii;
                 if (i >= MR) continue;
+                float2 st = make_float2(1.f, 0.f);
+                if (fold) st = st_lds ? st_lds[mrow0 - m0 + i * 16 + lr] : row_stat(a, mrow0 + i * 16 + lr);
                 f32x4 rp[4];                // QK_ROPE: (sin, cos, sin, cos) of this lane's two column pairs, per column block
                 bool rok = false;
                 if constexpr (EPI == EPI_QK_ROPE) {
@@ -630,7 +787,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                 for (int j = 0; j < 4; ++j) {
                     const int row = ii * 16 + lr;
                     const int pc = (j * 2 + (lq >> 1)) ^ ((row >> 1) & 7);
-                    f32x4 v = acc[i][j] + bv[j];
+                    f32x4 v = acc[i][j] * st.x + (bv[j] - cu[j] * st.y);
                     if constexpr (EPI == EPI_QK_ROPE) {
                         if (rok)
                             v = f32x4{v[0] * rp[j][1] - v[1] * rp[j][0], v[1] * rp[j][1] + v[0] * rp[j][0],
@@ -767,6 +924,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
     constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float2 st_table[256];        // folded LayerNorm: (rstd, rstd * mean) of the current tile's rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
@@ -954,6 +1112,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         // latency is covered by the epilogue; the stage of the last K-tile is the epilogue's scratch.
         f32x4 bias_pre[4];
         load_bias<EPI>(a, n0, wave_n, lane, bias_pre);      // in flight while the next prologue is issued
+        constexpr bool FOLDABLE = EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU;
+        const bool fold_st = FOLDABLE && a.stat_in != nullptr;
+        float2 st_pv[4];
+        if (fold_st && tid < TBM) row_stat_request(a, m0 + tid, st_pv);
         const int next = tile + gridDim.x;
         const bool has_next = next < nwg;
         int m0n = 0, n0n = 0;
@@ -965,6 +1127,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
             stage_tile(a.W, w_rows, K, n0n, 0, st + TILE_BYTES, wave, lane);
         }
         PPSTAMP(4);
+        if (fold_st) {      // uniform over the workgroup
+            if (tid < TBM) st_table[tid] = row_stat_finish(a, st_pv);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         bool staged = false;
         if constexpr (EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU) {
             const bool ok = EPI == EPI_VT                            ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
@@ -972,7 +1140,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                                                                      : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
             if (ok) {
                 gemm_epilogue_staged<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane,
-                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192, bias_pre);
+                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192, bias_pre, fold_st ? st_table : nullptr);
                 staged = true;
             }
         }
@@ -1411,12 +1579,23 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmArgs a, int t
                         : (EPI == EPI_QK || EPI == EPI_QK_ROPE) ? (a.dim % 64 == 0)
                                                                  : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
         if (ok) {
-            gemm_epilogue_staged<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane, smem + wave * 8192);
+            const float2* st_tab = nullptr;
+            if (a.stat_in) {        // folded LayerNorm: finish this tile's 256 row statistics (one row per thread) into LDS past the staging images
+                float2 pv[4];
+                row_stat_request(a, m0 + tid, pv);
+                float2* tab = reinterpret_cast<float2*>(smem + 4 * 8192 * 2);
+                tab[tid] = row_stat_finish(a, pv);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                st_tab = tab;
+            }
+            gemm_epilogue_staged<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane, smem + wave * 8192, nullptr, st_tab);
             if (trace && tid == 0) a.stamps[blockIdx.x * 8 + 4] = wall_clock64();
             return;
         }
     }
-    gemm_epilogue<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane);
+    gemm_epilogue<EPI, 8, F16>(a, acc, m0, n0, wave_m, wave_n, lane, nullptr, smem);      // all of LDS is free: scratch of the RESID_XG copy
     if (trace && tid == 0) a.stamps[blockIdx.x * 8 + 4] = wall_clock64();
 }
 
@@ -1476,9 +1655,9 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         }
     }
     int variant = gemm_variant();
-    if (EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU) variant = 1;      // staged epilogue only (pp, or dw below)
+    if (EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU || EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) variant = 1;      // staged epilogue only (pp, or dw below)
     if (EPI == EPI_RESID_LN) variant = 1;      // the row reduction across waves uses the persistent loop's LDS scratch stage
-    if (variant == 1 && EPI != EPI_HEAD && EPI != EPI_RESID_LN && (!getenv("HIPTS_GEMM") || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU)) {
+    if (variant == 1 && EPI != EPI_HEAD && EPI != EPI_RESID_LN && (!getenv("HIPTS_GEMM") || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU || EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI)) {
         // A launch with fewer 256 x 256 tiles than CUs (the CAFormer's late stages: 11 520 tokens x 512 columns
         // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
@@ -1490,7 +1669,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
             cus0 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM) variant = 4;
+        if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && a.stat_part)) variant = 4;
     }
     HIPTS_REQUIRE(!a.f16 || variant == 1 || variant == 4, "half-precision operands are only built for the pp and dw GEMM loops");
     if (variant == 4) {
@@ -1566,6 +1745,23 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_QK || epi == EPI_VT) HIPTS_REQUIRE(a.hd_log2 == 5 || a.hd_log2 == 6, "gemm: head_dim must be 32 or 64");
     if (epi == EPI_QK_ROPE)
         HIPTS_REQUIRE(a.hd_log2 == 6 && a.dim % 64 == 0 && a.rope && a.rope_tokens >= 0 && a.tokens >= 1, "gemm: QK_ROPE needs head_dim 64 and the rotary table");
+    if (epi == EPI_RESID_XG) HIPTS_REQUIRE(!a.rowstat && !a.stat_in, "gemm: RESID_XG ignores an input fold; use RESID_XGI");
+    if (epi == EPI_RESID_XGI) HIPTS_REQUIRE((a.rowstat || a.stat_in) && a.col_u, "gemm: RESID_XGI needs rowstat / stat_in and col_u");
+    if (epi == EPI_RESID_XG || epi == EPI_RESID_XGI)
+        HIPTS_REQUIRE(a.out_f32 && (!a.out_bf16 || (a.ln_gamma && a.N % 8 == 0 && (!a.stat_part || a.stat_stride >= a.M))),
+                      "gemm: RESID_XG needs the fp32 stream, col_u with rowstat, and gamma (N %% 8 == 0) with the 16-bit copy");
+    if (a.stat_in) HIPTS_REQUIRE(a.stat_in_blocks <= 4 && a.stat_in_blocks >= 1 && a.stat_in_stride >= a.M && a.ln_dim >= 1, "gemm: stat_in needs its block count, stride and ln_dim");
+    if ((a.rowstat || a.stat_in) && epi != EPI_RESID_ROWSTAT && epi != EPI_RESID_XGI)
+        HIPTS_REQUIRE(a.col_u && (epi == EPI_QK || epi == EPI_QK_ROPE || epi == EPI_VT || epi == EPI_GELU || epi == EPI_SWIGLU || epi == EPI_STAR),
+                      "gemm: a folded LayerNorm (rowstat) is built for the QK, QK_ROPE, VT, GELU, STAR and SWIGLU epilogues");
+    if ((a.rowstat || a.stat_in) && epi != EPI_RESID_ROWSTAT && epi != EPI_RESID_XGI) {
+        // the fold lives in the LDS-staged epilogues only
+        const int ldo = a.ld_out ? a.ld_out : (epi == EPI_SWIGLU ? a.N / 2 : a.N);
+        const bool staged = (epi == EPI_QK || epi == EPI_QK_ROPE) ? a.dim % 64 == 0
+                            : epi == EPI_VT                       ? (a.tokens % 8 == 0 && a.tokens_pad % 8 == 0)
+                                                                  : ldo % 8 == 0;
+        HIPTS_REQUIRE(staged && (gemm_variant() == 1 || gemm_variant() == 4), "gemm: a folded LayerNorm needs the staged epilogue (pp / dw loops, aligned outputs)");
+    }
     if (epi == EPI_RESID_ROWSTAT) HIPTS_REQUIRE(a.rowstat && a.col_u && a.out_f32, "gemm: RESID_ROWSTAT needs rowstat, col_u and the fp32 stream");
     if (epi == EPI_SWIGLU) HIPTS_REQUIRE(!a.stat_part || a.stat_stride >= a.M, "gemm: SWIGLU stat_stride must cover M rows");
     if (epi == EPI_SWIGLU)
@@ -1587,6 +1783,8 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
         case EPI_QK_ROPE: return launch_t<EPI_QK_ROPE>(a, s);
         case EPI_SWIGLU: return launch_t<EPI_SWIGLU>(a, s);
         case EPI_RESID_ROWSTAT: return launch_t<EPI_RESID_ROWSTAT>(a, s);
+        case EPI_RESID_XG: return launch_t<EPI_RESID_XG>(a, s);
+        case EPI_RESID_XGI: return launch_t<EPI_RESID_XGI>(a, s);
     }
     return set_error(HIPTS_ERR_INVALID, "gemm: unknown epilogue");
 }

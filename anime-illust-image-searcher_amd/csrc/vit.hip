@@ -25,6 +25,8 @@ namespace {
 struct Layer {
     DevBuf ln1_g, ln1_b, ln2_g, ln2_b;
     DevBuf qkv_w, qkv_b, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b;
+    // folded LayerNorms (EPI_RESID_XG): W gamma and W beta + b of the GEMMs that consume norm1 / norm2
+    DevBuf qkv_u, qkv_c, fc1_u, fc1_c;
 };
 
 
@@ -59,7 +61,9 @@ struct hipts_vit {
     std::vector<float> h_patch_bias, h_patch_rowsum;   // bias and sum_k W[n][k] (of the bf16 values)
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
-    DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs;
+    DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs, stat_part, rowstat;
+    bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default when dim % 64 == 0; HIPTS_LN_FOLD=0 turns it off)
+    bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
     int pool_splits = 1;
     static constexpr int kMaxSub = 4;
     int want_sub = 0;                             // hipts_vit_set_sub_batches; 0 = default
@@ -365,6 +369,20 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
         delete h;
         return st;
     }
+    h->fold_ln = D % 64 == 0 && h->tokens % 8 == 0 && cfg->mlp_dim % 8 == 0 && !getenv("HIPTS_GEMM") &&
+                 !(getenv("HIPTS_LN_FOLD") && atoi(getenv("HIPTS_LN_FOLD")) == 0);
+    if (h->fold_ln) {
+        if ((st = h->stat_part.alloc(2 * ((D + 255) / 256) * M * 8))) {      // two sets: norm1 and norm2 statistics alternate
+            delete h;
+            return st;
+        }
+        for (auto& L : h->layers)
+            if ((st = L.qkv_u.alloc(3 * D * 4)) || (st = L.qkv_c.alloc(3 * D * 4)) || (st = L.fc1_u.alloc((size_t)cfg->mlp_dim * 4)) ||
+                (st = L.fc1_c.alloc((size_t)cfg->mlp_dim * 4))) {
+                delete h;
+                return st;
+            }
+    }
     // padded token rows of q / k / vT must be finite (zero): cleared once, never written afterwards
     hipError_t e;
     if ((e = hipMemset(h->q.p, 0, h->q.bytes)) != hipSuccess || (e = hipMemset(h->k.p, 0, h->k.bytes)) != hipSuccess ||
@@ -482,6 +500,7 @@ int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, i
     }
 #undef EXPECT
     if (st == HIPTS_OK) erase_missing(h, key);
+    if (st == HIPTS_OK) h->fold_dirty = true;
     if (st == HIPTS_OK && (key == "patch_embed.proj.weight" || key == "patch_embed.proj.bias") &&
         !h->h_patch_bias.empty() && !h->h_patch_rowsum.empty()) {
         std::vector<float> eff(D);
@@ -613,21 +632,49 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     }
 
     const int ln_blocks = ceil_div(M, 4);
+    // Folded LayerNorms (EPI_RESID_XG): the residual GEMM that produces a row also writes gamma * x as the next GEMM's 16-bit
+    // operand and the row's partial sums; the consumer applies rstd / mean / beta in its epilogue.  The separate LayerNorm
+    // pass over the fp32 stream (HBM-bound, 24 per forward) remains only for the first norm1, whose input the patch GEMM wrote.
+    const bool fold = h->fold_ln;
+    const int sblocks = (D + 255) / 256;                 // partial (sum, sum of squares) pairs per row: one per 256-column tile
+    float* stat_p = fold ? h->stat_part.as<float>() + 2 * (size_t)sblocks * r0 : nullptr;
+    auto folded = [&](GemmArgs& ga, const float* u, const float* cvec) {
+        ga.stat_in = stat_p; ga.stat_in_blocks = sblocks; ga.stat_in_stride = M; ga.ln_dim = D; ga.ln_eps = c.ln_eps;
+        ga.col_u = u; ga.bias = cvec;
+    };
+    auto layernorm = [&](const float* gamma, const float* beta) -> int {
+        ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
+        if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(x, gamma, beta, xn, M, D, c.ln_eps);
+        else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(x, gamma, beta, xn, M, D, c.ln_eps);
+        HIPTS_LAUNCH_CHECK();
+        return HIPTS_OK;
+    };
+    // x += A W^T + b; with next_gamma also xn = 16bit(gamma * x) and the row statistics of x for the consumer of that norm
+    auto residual = [&](const bf16_t* A, const bf16_t* W, const float* bias, int K, const float* next_gamma, double flops, double bytes) -> int {
+        GemmArgs r{};
+        r.f16 = f16;
+        r.shared_chip = shared_chip;
+        r.A = A; r.W = W; r.M = M; r.N = D; r.K = K; r.bias = bias; r.out_f32 = x;
+        if (next_gamma) {
+            r.out_bf16 = xn; r.ln_gamma = next_gamma; r.stat_part = stat_p; r.stat_stride = M;
+        }
+        {
+            ProfScope ps(h, s, PC_GEMM_RESID, flops, bytes + (next_gamma ? dM * dD * 2 : 0.0));
+            HIPTS_TRY(launch_gemm(next_gamma ? EPI_RESID_XG : EPI_RESID, r, s));
+        }
+        return HIPTS_OK;
+    };
     for (int li = 0; li < c.depth; ++li) {
         Layer& L = h->layers[li];
-        {
-            ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
-            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps);
-            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps);
-            HIPTS_LAUNCH_CHECK();
-        }
+        const bool ln1_folded = fold && li > 0;        // prepared by the previous layer's fc2 epilogue
+        if (!ln1_folded) HIPTS_TRY(layernorm(L.ln1_g.as<float>(), L.ln1_b.as<float>()));
         // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-    g.shared_chip = shared_chip;
         g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
         g.bias = L.qkv_b.as<float>(); g.out_bf16 = q; g.out2_bf16 = k;
+        if (ln1_folded) folded(g, L.qkv_u.as<float>(), L.qkv_c.as<float>());
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         g.qscale = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 (64^-0.5) * log2(e): attention works in base 2
         {
@@ -638,9 +685,9 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-    g.shared_chip = shared_chip;
         g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
         g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = vT;
+        if (ln1_folded) folded(g, L.qkv_u.as<float>() + 2 * D, L.qkv_c.as<float>() + 2 * D);
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         {
             ProfScope ps(h, s, PC_GEMM_VT, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 2);
@@ -650,43 +697,24 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
             ProfScope ps(h, s, PC_ATTENTION, 4.0 * nb * H * dT * dT * 64, dM * dD * 2 * 4);
             HIPTS_TRY(launch_attention(q, k, vT, att, nb, H, T, Tp, f16, s));
         }
-        // x += att Wp^T + b
+        // x += att Wp^T + b  (+ norm2 prepared)
+        HIPTS_TRY(residual(att, L.proj_w.as<bf16_t>(), L.proj_b.as<float>(), D, fold ? L.ln2_g.as<float>() : nullptr, 2.0 * dM * dD * dD,
+                           dM * dD * 2 + dM * dD * 8));
+        if (!fold) HIPTS_TRY(layernorm(L.ln2_g.as<float>(), L.ln2_b.as<float>()));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-    g.shared_chip = shared_chip;
-        g.A = att; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D;
-        g.bias = L.proj_b.as<float>(); g.out_f32 = x;
-        {
-            ProfScope ps(h, s, PC_GEMM_RESID, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 8);
-            HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
-        }
-        {
-            ProfScope ps(h, s, PC_LAYERNORM, 0.0, dM * dD * 6);
-            if (f16) layernorm_kernel<true><<<ln_blocks, 256, 0, s>>>(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps);
-            else layernorm_kernel<false><<<ln_blocks, 256, 0, s>>>(x, L.ln2_g.as<float>(), L.ln2_b.as<float>(), xn, M, D, c.ln_eps);
-            HIPTS_LAUNCH_CHECK();
-        }
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.shared_chip = shared_chip;
-    g.shared_chip = shared_chip;
         g.A = xn; g.W = L.fc1_w.as<bf16_t>(); g.M = M; g.N = c.mlp_dim; g.K = D;
         g.bias = L.fc1_b.as<float>(); g.out_bf16 = hmid; g.gelu_tanh = c.gelu_tanh;
+        if (fold) folded(g, L.fc1_u.as<float>(), L.fc1_c.as<float>());
         {
             ProfScope ps(h, s, PC_GEMM_GELU, 2.0 * dM * dD * dMlp, dM * dD * 2 + dM * dMlp * 2);
             HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
         }
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.shared_chip = shared_chip;
-    g.shared_chip = shared_chip;
-        g.A = hmid; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = c.mlp_dim;
-        g.bias = L.fc2_b.as<float>(); g.out_f32 = x;
-        {
-            ProfScope ps(h, s, PC_GEMM_RESID, 2.0 * dM * dD * dMlp, dM * dMlp * 2 + dM * dD * 8);
-            HIPTS_TRY(launch_gemm(EPI_RESID, g, s));
-        }
+        // x += hmid W2^T + b  (+ the next layer's norm1 prepared)
+        HIPTS_TRY(residual(hmid, L.fc2_w.as<bf16_t>(), L.fc2_b.as<float>(), c.mlp_dim,
+                           (fold && li + 1 < c.depth) ? h->layers[li + 1].ln1_g.as<float>() : nullptr, 2.0 * dM * dD * dMlp,
+                           dM * dMlp * 2 + dM * dD * 8));
     }
     // final norm + mean pool (+ hi/lo split)
     {
@@ -737,6 +765,16 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     const bool dev_out = out_memspace == HIPTS_DEVICE;
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
     float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
+    if (h->fold_ln && h->fold_dirty) {
+        const bool f16w = c.operand_f16 != 0;
+        for (auto& L : h->layers) {
+            HIPTS_TRY(launch_fold_ln(L.qkv_w.as<bf16_t>(), f16w, L.ln1_g.as<float>(), L.ln1_b.as<float>(), L.qkv_b.as<float>(), L.qkv_u.as<float>(),
+                                     L.qkv_c.as<float>(), 3 * c.dim, c.dim, s));
+            HIPTS_TRY(launch_fold_ln(L.fc1_w.as<bf16_t>(), f16w, L.ln2_g.as<float>(), L.ln2_b.as<float>(), L.fc1_b.as<float>(), L.fc1_u.as<float>(),
+                                     L.fc1_c.as<float>(), c.mlp_dim, c.dim, s));
+        }
+        h->fold_dirty = false;
+    }
 
     // Two half-batches on two internal streams: a GEMM grid's partial last round, an epilogue that is
     // waiting on HBM and every kernel boundary of one half are filled with work of the other half.
@@ -774,6 +812,76 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
 }  // namespace
 
 namespace hipts {
+namespace {
+// rowstat[m] = (rstd, rstd * mean) of row m from the per-64-column partial (sum, sum of squares) pairs an epilogue wrote:
+// part[b * stride + m].  64 rows x 4 quarters per workgroup: quarter q sums blocks q, q + 4, ..., then the quarters are
+// combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void rowstat_kernel(const float2* __restrict__ part, float2* __restrict__ rowstat, int M, int stride, int blocks,
+                                                      int D, float eps) {
+    const int q = threadIdx.x >> 6;
+    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ float2 red[4][64];
+    float s1 = 0.f, s2 = 0.f;
+    if (m < M) {
+#pragma unroll 4
+        for (int b = q; b < blocks; b += 4) {
+            const float2 v = part[(size_t)b * stride + m];
+            s1 += v.x;
+            s2 += v.y;
+        }
+    }
+    red[q][threadIdx.x & 63] = make_float2(s1, s2);
+    __syncthreads();
+    if (q != 0 || m >= M) return;
+    const float2 a = red[0][threadIdx.x], b2 = red[1][threadIdx.x], c = red[2][threadIdx.x], d = red[3][threadIdx.x];
+    s1 = (a.x + b2.x) + (c.x + d.x);
+    s2 = (a.y + b2.y) + (c.y + d.y);
+    const float mean = s1 / (float)D;
+    const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    rowstat[m] = make_float2(rstd, rstd * mean);
+}
+
+// u[n] = sum_k W[n][k] gamma[k], c[n] = sum_k W[n][k] beta[k] + bias[n] in float64 from the 16-bit operand values of W (so that the
+// mean term cancels against what the MFMA sums).  One wave per output row; runs once per checkpoint.
+template <bool F16>
+__global__ __launch_bounds__(256) void fold_ln_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias, float* __restrict__ u, float* __restrict__ c, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    double su = 0.0, sc = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double w = (double)from_op<F16>(W[(size_t)n * K + k]);
+        su += w * (double)gamma[k];
+        if (beta) sc += w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        su += __shfl_xor(su, o);
+        sc += __shfl_xor(sc, o);
+    }
+    if (lane == 0) {
+        u[n] = (float)su;
+        c[n] = (float)(sc + (bias ? (double)bias[n] : 0.0));
+    }
+}
+}  // namespace
+
+int launch_rowstat(const float* part, float* rowstat, int M, int stride, int blocks, int D, float eps, hipStream_t s) {
+    rowstat_kernel<<<(M + 63) / 64, 256, 0, s>>>(reinterpret_cast<const float2*>(part), reinterpret_cast<float2*>(rowstat), M, stride, blocks, D, eps);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+int launch_fold_ln(const bf16_t* W, bool f16, const float* gamma, const float* beta, const float* bias, float* u, float* c, int N, int K,
+                   hipStream_t s) {
+    if (f16) fold_ln_kernel<true><<<(N + 3) / 4, 256, 0, s>>>(W, gamma, beta, bias, u, c, N, K);
+    else fold_ln_kernel<false><<<(N + 3) / 4, 256, 0, s>>>(W, gamma, beta, bias, u, c, N, K);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
 int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,
                      hipStream_t s) {
     HIPTS_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d must be a multiple of 4, at most 1024", D);

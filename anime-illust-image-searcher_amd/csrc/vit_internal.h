@@ -201,8 +201,17 @@ enum GemmEpilogue {
     EPI_SWIGLU = 11,  // W rows interleaved per 32 hidden units [gate 0..31 | value 0..31]: out[m][u] = bf16(silu(gate + bias) * (value + bias)),
                       // N / 2 output columns (row stride ld_out).  Staged epilogue only.
     EPI_RESID_ROWSTAT = 12, // x[m][n] += rowstat[m].x * acc - rowstat[m].y * col_u[n] + bias[n]: the residual GEMM of a LayerNorm-ed operand with
-                            // the LayerNorm folded into the weights -- A holds the raw rows p, W holds W diag(gamma), col_u[n] = sum_k W'[n][k],
-                            // bias[n] = W beta + b, rowstat[m] = (rstd, rstd * mean) of row m (from the stat_part partials of EPI_SWIGLU)
+                            // the LayerNorm folded in -- A holds gamma * p (raw rows times the LayerNorm weight, written by the producer),
+                            // col_u[n] = sum_k W[n][k] gamma[k], bias[n] = W beta + b, rowstat[m] = (rstd, rstd * mean) of the raw row m
+                            // (from the stat_part partials of EPI_SWIGLU).  W itself is unchanged: folding gamma into W would round W again.
+    EPI_RESID_XG = 13, // the residual GEMM with the NEXT LayerNorm prepared in its epilogue (and optionally the fold of EPI_RESID_ROWSTAT on its
+                       // input): x[m][n] += rowstat[m].x * acc - rowstat[m].y * col_u[n] + bias[n] (rowstat null: += acc + bias), then
+                       // out_bf16[m][n] = 16bit(x[m][n] * ln_gamma[n]) and per (256-column tile, row) partial (sum x, sum x^2) into stat_part
+                       // (the four waves of a row reduce through LDS; persistent loop only).
+                       // A consumer GEMM (QK, QK_ROPE, VT, GELU, SWIGLU with rowstat / col_u set) then computes
+                       // W LN(x) + b = rstd (W (gamma x)) - rstd mean (W gamma) + (W beta + b) without a LayerNorm pass over x.
+    EPI_RESID_XGI = 14, // EPI_RESID_XG with the fold on its input (rowstat / stat_in + col_u); plain EPI_RESID_XG ignores them, which
+                        // leaves it the registers for four row blocks of residual loads in flight instead of two
     EPI_RESID_LN = 9 // x[m][n] = x[m][n] * (res_scale ? res_scale[n] : 1) + acc + bias[n]  (fp32 in/out), AND the LayerNorm
                      // of the new row: xn[m][n] = bf16((x - mean) * rstd * ln_gamma[n] (+ ln_beta[n])).  Needs the whole
                      // row in one tile: N <= 256.  Saves the separate LayerNorm pass over x (HBM-bound).
@@ -232,8 +241,12 @@ struct GemmArgs {
     float qscale = 1.0f;
     float* stat_part = nullptr;     // SWIGLU (optional): per (64-column block, row) partial (sum, sum of squares) of the fp32 products,
     int stat_stride = 0;            //   float2 at stat_part[2 * (block * stat_stride + m)]
-    const float* rowstat = nullptr; // RESID_ROWSTAT: float2 per row
-    const float* col_u = nullptr;   // RESID_ROWSTAT
+    const float* stat_in = nullptr; // folded LayerNorm on the A operand, statistics still as the producer's partials: float2 (sum x, sum x^2) at
+    int stat_in_blocks = 0;         //   stat_in[2 * (b * stat_in_stride + m)], b < stat_in_blocks; the epilogue finishes them (ln_dim columns, ln_eps)
+    int stat_in_stride = 0;
+    int ln_dim = 0;
+    const float* rowstat = nullptr; // ... or finished: folded LayerNorm on the A operand (RESID_ROWSTAT, RESID_XG, QK, QK_ROPE, VT, GELU, SWIGLU): float2 per row
+    const float* col_u = nullptr;   //   (rstd, rstd * mean), and W gamma per output column; `bias` then holds W beta + b
     const float* rope = nullptr;    // QK_ROPE: [rope_tokens][32] (sin, cos) pairs
     int rope_tokens = 0;
     int gelu_tanh = 1;
@@ -258,6 +271,11 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
 // out[row][:] = bf16((x[row][:] - mean) * rstd * g + b)  (b may be null: bias-free LayerNorm); D % 4 == 0, D <= 1024
 int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,
                      hipStream_t s);
+// rowstat[m] = (rstd, rstd * mean) from `blocks` partial (sum, sum of squares) pairs per row: part[2 * (b * stride + m)], D columns in all
+int launch_rowstat(const float* part, float* rowstat, int M, int stride, int blocks, int D, float eps, hipStream_t s);
+// u[n] = sum_k W[n][k] gamma[k], c[n] = sum_k W[n][k] beta[k] + bias[n] (beta / bias may be null) from the uploaded 16-bit W
+int launch_fold_ln(const bf16_t* W, bool f16, const float* gamma, const float* beta, const float* bias, float* u, float* c, int N, int K,
+                   hipStream_t s);
 // the same with e4m3 output bytes (the A operand of an op8 GEMM)
 int launch_layernorm8(const float* x, const float* g, const float* b, uint8_t* out, int64_t rows, int D, float eps, hipStream_t s);
 
