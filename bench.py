@@ -65,14 +65,16 @@ def pmc_traffic(kernel_name):
     correction; tools/pmc_traffic.py).  Counters cannot be read from inside the process, so this is
     None until that file exists."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    epi = {"EPI_PATCH": 0, "EPI_QK": 1, "EPI_VT": 2, "EPI_RESID": 3, "EPI_GELU": 4, "EPI_HEAD": 5}
+    # template indices of the category's kernels (EPI_RESID: the plain residual epilogue and EPI_RESID_XG, which also prepares the
+    # next LayerNorm and is what 23 of the 24 residual GEMMs of a forward run)
+    epi = {"EPI_PATCH": (0,), "EPI_QK": (1,), "EPI_VT": (2,), "EPI_RESID": (3, 13), "EPI_GELU": (4,), "EPI_HEAD": (5,)}
     try:
         k = json.load(open(path))["kernels"]
-        for tag, idx in epi.items():
+        for tag, idxs in epi.items():
             if tag in kernel_name:
                 best = None      # the template instance (tile height, operand type) with the most launches
                 for name, v in k.items():
-                    if name.startswith("gemm") and ("<%d>" % idx in name or "<%d," % idx in name):
+                    if name.startswith("gemm") and any("<%d>" % idx in name or "<%d," % idx in name for idx in idxs):
                         if best is None or v.get("launches_fetch_pass", 0) > best.get("launches_fetch_pass", 0):
                             best = v
                 if best:
