@@ -42,6 +42,8 @@ def main(arg_str: list) -> None:
     parser.add_argument('--checkpoint', default=None)
     parser.add_argument('--batch', type=int, default=64)
     parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--workers', type=int, default=0,
+                        help='decode / resize in this many processes (hiptagsearch/pipeline.py); the uint8 images go to the device u8 entry point')
     parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='bf16',
                         help='MFMA operand type of the encoder GEMMs (e4m3 = the fp8 mode: faster, 3 mantissa bits)')
     args = parser.parse_args(arg_str)
@@ -81,6 +83,19 @@ def main(arg_str: list) -> None:
 
     start = time.perf_counter()
     done = 0
+    if args.workers > 0:
+        from hiptagsearch import pipeline
+        with open(INDEX_PREFIX + '.csv', 'a', encoding='utf-8') as fcsv, \
+                pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP) as dpool:
+            for kept, images in dpool.batches(file_list):
+                cindex.add_features(kept, encoder.forward_u8(images))                # /255 and the CLIP normalisation on the device
+                for p in kept:
+                    fcsv.write(p + '\n')
+                done += len(kept)
+                el = time.perf_counter() - start
+                print(f'{done} files processed\n{el:.2f} seconds elapsed\n{el / max(done, 1):.4f} seconds per file\n', flush=True)
+        cindex.index.save(INDEX_PREFIX)
+        return
     with open(INDEX_PREFIX + '.csv', 'a', encoding='utf-8') as fcsv, \
             concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as pool:
         nxt = pool.map(gen_image_ndarray, file_list[:args.batch])                    # one batch of decode ahead of the device

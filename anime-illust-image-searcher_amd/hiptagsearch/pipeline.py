@@ -1,0 +1,187 @@
+"""Host input pipeline for the tagging / character-feature stages.
+
+Once the forward runs at thousands of images per second the corpus walk is bound by image decode and
+resize on the host, which the reference does on 8 threads inside the GIL (tagging.py:52,293-331).  Here:
+
+  DecodePool     N worker PROCESSES decode + composite + pad + resize (exactly `Predictor.prepare_image` /
+                 `gen_image_tensor`, tagging.py:100-120,234-252, or the CCIP variant gen_cfeatures.py:285-295
+                 before its float normalisation) straight into a shared-memory ring of uint8 HWC slots; the
+                 consumer gets [B,S,S,3] uint8 views, one batch ahead of the device, and hands them to the u8
+                 entry points (`hipts_vit_forward_u8` / `hipts_ccip_forward_u8`), where /255, normalisation and the
+                 BGR flip happen on the device.
+  write_shards   the `utility/make_tensor_files.py:164-197` idea (decode once, tag many times) with a packed
+  iter_shards    format: `shard-00000.npy` = uint8 [n,S,S,3] (memory-mappable) + `shard-00000.txt` = one path per
+                 row; the reference stores one float32 torch tensor file per image (2.4 MB each, 4x the bytes).
+
+Workers are started with the `forkserver` method so that no child is forked from a process that holds a GPU
+context; create the pool before or after the model, either is safe.
+"""
+import multiprocessing as mp
+import os
+from multiprocessing import shared_memory
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+TAGGER = "tagger"      # white composite, centred pad to square, bicubic resize (tagging.py:100-120 + timm eval transform)
+CCIP = "ccip"          # white composite, bilinear resize (gen_cfeatures.py:285-295, 106)
+
+
+def decode_image(path: str, size: int, mode: str = TAGGER) -> Optional[np.ndarray]:
+    """One image file -> uint8 [size,size,3] RGB, or None (error printed, like the reference's per-file handler)."""
+    from PIL import Image
+    img = None
+    try:
+        img = Image.open(path)
+        img.load()
+        if img.mode in ("RGBA", "LA"):
+            bg = Image.new("RGB", img.size, (255, 255, 255))
+            bg.paste(img, mask=img.split()[-1])
+            img = bg
+        else:
+            img = img.copy().convert("RGB") if mode == TAGGER else img.convert("RGB")
+        if mode == TAGGER:
+            w, h = img.size
+            m = max(w, h)
+            padded = Image.new("RGB", (m, m), (255, 255, 255))
+            padded.paste(img, ((m - w) // 2, (m - h) // 2))
+            img = padded
+            if img.size != (size, size):
+                img = img.resize((size, size), Image.BICUBIC)
+        else:
+            img = img.resize((size, size), resample=Image.BILINEAR)
+        return np.asarray(img, dtype=np.uint8)
+    except Exception as e:
+        if img is not None:
+            img.close()
+        print('%s: %s' % (type(e), str(e)))
+        return None
+
+
+_W = {}
+
+
+def _worker_init(shm_name: str, slots: int, size: int, mode: str) -> None:
+    shm = shared_memory.SharedMemory(name=shm_name)
+    _W["shm"] = shm
+    _W["ring"] = np.ndarray((slots, size, size, 3), dtype=np.uint8, buffer=shm.buf)
+    _W["size"] = size
+    _W["mode"] = mode
+
+
+def _worker_decode(task: Tuple[int, str]) -> bool:
+    slot, path = task
+    a = decode_image(path, _W["size"], _W["mode"])
+    if a is None:
+        return False
+    _W["ring"][slot] = a
+    return True
+
+
+class DecodePool:
+    """Multi-process decode into shared memory, one batch ahead of the consumer.
+
+        with DecodePool(workers=16, size=448, batch=64) as pool:
+            for paths, images_u8 in pool.batches(file_list):      # images_u8: uint8 [len(paths),448,448,3]
+                ...                                               # valid until the next iteration
+
+    Files that fail to decode are dropped from `paths` (message printed by the worker), like the reference."""
+
+    def __init__(self, workers: Optional[int] = None, size: int = 448, batch: int = 64, mode: str = TAGGER):
+        self.workers = max(1, workers or (os.cpu_count() or 1))
+        self.size, self.batch, self.mode = size, batch, mode
+        self.slots = 2 * batch
+        self._shm = shared_memory.SharedMemory(create=True, size=self.slots * size * size * 3)
+        self._ring = np.ndarray((self.slots, size, size, 3), dtype=np.uint8, buffer=self._shm.buf)
+        ctx = mp.get_context("forkserver")
+        self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self._shm.name, self.slots, size, mode))
+
+    def batches(self, paths: Sequence[str]) -> Iterator[Tuple[List[str], np.ndarray]]:
+        chunks = [list(paths[i:i + self.batch]) for i in range(0, len(paths), self.batch)]
+        if not chunks:
+            return
+
+        def submit(k: int):
+            base = (k & 1) * self.batch
+            return self._pool.map_async(_worker_decode, [(base + i, p) for i, p in enumerate(chunks[k])],
+                                        chunksize=max(1, len(chunks[k]) // (4 * self.workers)))
+        pending = submit(0)
+        for k, chunk in enumerate(chunks):
+            ok = pending.get()
+            if k + 1 < len(chunks):
+                pending = submit(k + 1)          # the other half of the ring: batch k - 1 has been consumed
+            base = (k & 1) * self.batch
+            view = self._ring[base:base + len(chunk)]
+            if all(ok):
+                yield chunk, view
+            else:
+                keep = [i for i, good in enumerate(ok) if good]
+                if keep:
+                    yield [chunk[i] for i in keep], np.ascontiguousarray(view[keep])
+
+    def close(self) -> None:
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool.join()
+            self._pool = None
+        if self._shm is not None:
+            self._ring = None
+            self._shm.close()
+            self._shm.unlink()
+            self._shm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_shards(paths: Sequence[str], out_dir: str, size: int = 448, mode: str = TAGGER, workers: Optional[int] = None,
+                 per_shard: int = 1024, batch: int = 64) -> int:
+    """Decode once: shard-%05d.npy (uint8 [n,size,size,3]) + shard-%05d.txt (paths, row aligned).  Returns the
+    number of images written."""
+    os.makedirs(out_dir, exist_ok=True)
+    total = 0
+    shard = 0
+    buf_paths: List[str] = []
+    buf = np.empty((per_shard, size, size, 3), dtype=np.uint8)
+
+    def flush():
+        nonlocal shard, buf_paths
+        if not buf_paths:
+            return
+        np.save(os.path.join(out_dir, "shard-%05d.npy" % shard), buf[:len(buf_paths)])
+        with open(os.path.join(out_dir, "shard-%05d.txt" % shard), "w", encoding="utf-8") as f:
+            f.write("".join(p + "\n" for p in buf_paths))
+        shard += 1
+        buf_paths = []
+    with DecodePool(workers, size, batch, mode) as pool:
+        for kept, images in pool.batches(paths):
+            for p, img in zip(kept, images):
+                buf[len(buf_paths)] = img
+                buf_paths.append(p)
+                total += 1
+                if len(buf_paths) == per_shard:
+                    flush()
+    flush()
+    return total
+
+
+def iter_shards(shard_dir: str, batch: int = 64) -> Iterator[Tuple[List[str], np.ndarray]]:
+    """Batches of (paths, uint8 [b,S,S,3]) from a directory written by write_shards; arrays are memory-mapped."""
+    names = sorted(f for f in os.listdir(shard_dir) if f.startswith("shard-") and f.endswith(".npy"))
+    for n in names:
+        arr = np.load(os.path.join(shard_dir, n), mmap_mode="r")
+        with open(os.path.join(shard_dir, n[:-4] + ".txt"), encoding="utf-8") as f:
+            paths = [l.rstrip("\n") for l in f]
+        if len(paths) != arr.shape[0]:
+            raise ValueError("%s: %d rows but %d paths" % (n, arr.shape[0], len(paths)))
+        for s in range(0, len(paths), batch):
+            yield paths[s:s + batch], np.ascontiguousarray(arr[s:s + batch])

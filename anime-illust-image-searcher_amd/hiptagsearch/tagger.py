@@ -284,9 +284,12 @@ class Predictor:
                 character_mcut_enabled: bool) -> List[str]:
         first = tensors[0]
         out: List[str] = []
+        packed = isinstance(tensors, np.ndarray) and tensors.dtype == np.uint8 and tensors.ndim == 4      # [B,S,S,3] from the decode pool / shards
         for s in range(0, len(tensors), self.max_batch):
             chunk = tensors[s:s + self.max_batch]
-            if hasattr(first, "dtype") and str(first.dtype) in ("uint8", "torch.uint8"):
+            if packed:
+                _, probs = self.tagger_model.forward_u8(chunk, want="probs")
+            elif hasattr(first, "dtype") and str(first.dtype) in ("uint8", "torch.uint8"):
                 batch = np.stack([np.asarray(t) for t in chunk])
                 _, probs = self.tagger_model.forward_u8(batch, want="probs")
             else:   # float32 CHW tensors exactly as the reference's transform produces (tagging.py:241-243)
@@ -304,8 +307,11 @@ class Predictor:
         return [p for p in file_list if datetime.date.fromtimestamp(os.stat(p).st_ctime) >= added_date]   # tagging.py:266-274
 
     # ---- tagging.py:276-359
-    def process_directory(self, dir_path: str, added_date: Optional[datetime.date] = None, batch_size: int = BATCH_SIZE) -> None:
-        file_list = self.list_files_recursive(dir_path)
+    def process_directory(self, dir_path: str, added_date: Optional[datetime.date] = None, batch_size: int = BATCH_SIZE,
+                          workers: int = 0, shards: Optional[str] = None) -> None:
+        """workers > 0: decode in that many processes (pipeline.DecodePool) instead of the reference's 8 threads;
+        shards: tag the pre-decoded shards of pipeline.write_shards in that directory instead of walking dir_path."""
+        file_list = [] if shards else self.list_files_recursive(dir_path)
         print(f'{len(file_list)} files found')
         if added_date is not None:
             file_list = self.filter_files_by_date(file_list, added_date)
@@ -322,6 +328,30 @@ class Predictor:
         start = time.perf_counter()
         done = 0
         last = 0
+        if (workers > 0 or shards) and not self.compat:
+            from . import pipeline
+            size = self.cfg["image_size"]
+            pool = None
+            if shards:
+                source = pipeline.iter_shards(shards, min(batch_size, self.max_batch))
+            else:
+                pool = pipeline.DecodePool(workers, size, min(batch_size, self.max_batch), pipeline.TAGGER)
+                source = pool.batches(file_list)
+            try:
+                for kept, images in source:
+                    for p, line in zip(kept, self.predict(images, 0.3, True, 0.3, True)):
+                        self.write_to_file(p + ',' + line)
+                    self.f.flush()
+                    done += len(kept)
+                    if done - last >= PROGRESS_INTERVAL:
+                        diff = time.perf_counter() - start
+                        print(f'{done} files processed\n{diff:.2f} seconds elapsed\n{diff / done:.4f} seconds per file\n', flush=True)
+                        last = done
+            finally:
+                if pool is not None:
+                    pool.close()
+            self.f.close()
+            return
         batches = [file_list[i:i + batch_size] for i in range(0, len(file_list), batch_size)]
         if self.compat and batches:
             batches = batches[:-1]      # the reference never consumes its last submitted batch (tagging.py:309)

@@ -3,7 +3,9 @@
 
 Extra switches: --model vit-b16|eva02-l14, --checkpoint model.safetensors (timm key layout) and --labels
 selected_tags.csv for a real wd tagger; without them the seeded synthetic stand-ins are used (no network here).
---compat reproduces the reference's dropped tail batch; --batch sets the device batch size."""
+--compat reproduces the reference's dropped tail batch; --batch sets the device batch size.
+Input pipeline (hiptagsearch/pipeline.py): --workers N decodes in N processes through shared memory; --write-shards DIR
+decodes the corpus once into packed uint8 shards and --shards DIR tags from them (utility/make_tensor_files.py's idea)."""
 import argparse
 import datetime
 import os
@@ -22,12 +24,15 @@ def main(arg_str: list) -> None:
     parser.add_argument('--model', choices=['vit-b16', 'eva02-l14'], default='vit-b16',
                         help='vit-b16: wd-vit-tagger-v3 geometry (BASELINE.json contract model); eva02-l14: wd-eva02-large-tagger-v3, the repo tagging.py:45 names')
     parser.add_argument('--batch', type=int, default=64)
+    parser.add_argument('--workers', type=int, default=0,
+                        help='decode / resize in this many processes (shared-memory pipeline) instead of 8 threads')
+    parser.add_argument('--write-shards', default=None, help='decode --dir once into packed uint8 shards in this directory and exit')
+    parser.add_argument('--shards', default=None, help='tag the pre-decoded shards in this directory (written by --write-shards)')
     parser.add_argument('--device', type=int, default=0)
     args = parser.parse_args(arg_str)
     from hiptagsearch.tagger import Predictor
     predictor = Predictor(device=args.device, max_batch=args.batch, compat=args.compat)
     from hiptagsearch import synth
-    predictor.load_model(args.checkpoint, args.labels, cfg=synth.EVA02_L14_448 if args.model == 'eva02-l14' else synth.VIT_B16_448)
     after_date = None
     if args.after is not None:
         try:
@@ -36,7 +41,17 @@ def main(arg_str: list) -> None:
             print('%s: %s' % (type(e), str(e)))
             print('Invalid date format. format is YYYY-MM-DD')
             raise SystemExit(1)
-    predictor.process_directory(args.dir[0], after_date, batch_size=10 if args.compat else args.batch)
+    if args.write_shards:
+        from hiptagsearch import pipeline
+        cfg = synth.EVA02_L14_448 if args.model == 'eva02-l14' else synth.VIT_B16_448
+        files = predictor.list_files_recursive(args.dir[0])
+        if after_date is not None:
+            files = predictor.filter_files_by_date(files, after_date)
+        n = pipeline.write_shards(files, args.write_shards, cfg["image_size"], pipeline.TAGGER, args.workers or None)
+        print(f'{n} of {len(files)} images written to {args.write_shards}')
+        return
+    predictor.load_model(args.checkpoint, args.labels, cfg=synth.EVA02_L14_448 if args.model == 'eva02-l14' else synth.VIT_B16_448)
+    predictor.process_directory(args.dir[0], after_date, batch_size=10 if args.compat else args.batch, workers=args.workers, shards=args.shards)
 
 
 if __name__ == "__main__":

@@ -32,6 +32,14 @@ def test_tagging_genmodel_query_pipeline(tmp_path, monkeypatch):
     assert len(lines) == n                                         # default mode writes every file (no tail drop)
     assert sorted(l.split(",")[0] for l in lines) == sorted(pred.list_files_recursive("imgs"))
     assert all(len(l.split(",")) >= 2 for l in lines)
+    # the multi-process decode pool and the pre-decoded shards give the same lines (same uint8 images, same device path)
+    from hiptagsearch import pipeline
+    for kw in ({"workers": 2}, {"shards": "shards"}):
+        if "shards" in kw:
+            assert pipeline.write_shards(pred.list_files_recursive("imgs"), "shards", size=pred.cfg["image_size"], workers=2, per_shard=10) == n
+        os.remove("tags-wd-tagger.txt")
+        pred.process_directory("imgs", batch_size=8, **kw)
+        assert open("tags-wd-tagger.txt", encoding="utf-8").read().splitlines() == lines
     # compat mode reproduces the reference's dropped tail batch: (ceil(23/10)-1)*10 = 20 lines
     os.remove("tags-wd-tagger.txt")
     pred2 = Predictor(max_batch=8, compat=True)
@@ -93,5 +101,13 @@ def test_gen_cfeatures_cli_builds_and_extends_the_feature_index(tmp_path, monkey
     for i, p in enumerate(paths):
         j = 7 + p2[7:].index(p)
         np.testing.assert_allclose(m2[j], m[i], atol=1e-6)
+    # --workers: multi-process decode to uint8, normalisation on the device -- the same features again
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "2000-01-01", "--batch", "4", "--workers", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m3 = Similarity.load("charactor-featues-idx").matrix()
+    p3 = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
+    assert len(p3) == 21
+    for i, p in enumerate(paths):
+        np.testing.assert_allclose(m3[14 + p3[14:].index(p)], m[i], atol=1e-5)
     r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "not-a-date"], capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid date format" in r.stdout

@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_e2e.py tests/test_pipeline.py -x -q 2>&1 | tail -15
