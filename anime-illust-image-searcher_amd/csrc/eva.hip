@@ -116,36 +116,6 @@ __global__ __launch_bounds__(256) void eva_assemble_kernel(const float* __restri
     reinterpret_cast<float4*>(x)[idx] = v;
 }
 
-// rowstat[m] = (rstd, rstd * mean) of the hidden row m from the per-64-column partial (sum, sum of squares) pairs the
-// SwiGLU epilogue wrote: part[(block * stride + m)], blocks summed in index order (deterministic).
-__global__ __launch_bounds__(256) void eva_rowstat_kernel(const float2* __restrict__ part, float2* __restrict__ rowstat, int M, int stride,
-                                                          int blocks, int Hd, float eps) {
-    // 64 rows x 4 quarters per workgroup: quarter q sums blocks q, q + 4, ... (8 loads in flight), then the quarters are
-    // combined in a fixed order -- the loop over 86 dependent-latency loads by one thread took 45 us
-    const int q = threadIdx.x >> 6;
-    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
-    __shared__ float2 red[4][64];
-    float s1 = 0.f, s2 = 0.f;
-    if (m < M) {
-#pragma unroll 8
-        for (int b = q; b < blocks; b += 4) {
-            const float2 v = part[(size_t)b * stride + m];
-            s1 += v.x;
-            s2 += v.y;
-        }
-    }
-    red[q][threadIdx.x & 63] = make_float2(s1, s2);
-    __syncthreads();
-    if (q != 0 || m >= M) return;
-    const float2 a = red[0][threadIdx.x], b2 = red[1][threadIdx.x], c = red[2][threadIdx.x], d = red[3][threadIdx.x];
-    s1 = (a.x + b2.x) + (c.x + d.x);
-    s2 = (a.y + b2.y) + (c.y + d.y);
-    const float mean = s1 / (float)Hd;
-    const float var = fmaxf(s2 / (float)Hd - mean * mean, 0.f);
-    const float rstd = 1.0f / sqrtf(var + eps);
-    rowstat[m] = make_float2(rstd, rstd * mean);
-}
-
 // part[b][split][:] = sum of the patch-token rows of split `split` of image b (grid (POOL_SPLITS, batch)): the whole chip
 // reads the 4 MB an image's tokens occupy instead of one workgroup per image (312 -> ~20 us at batch 32).
 constexpr int POOL_SPLITS = 16;
@@ -339,9 +309,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.ln_gamma = L.mn_g.as<float>();
         if (fold) folded(g, L.gx_u.as<float>(), L.gx_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_SWIGLU, g, s));
-        eva_rowstat_kernel<<<ceil_div(M, 64), 256, 0, s>>>(reinterpret_cast<const float2*>(stat_p), reinterpret_cast<float2*>(rowstat_p), M, M, sblocks,
-                                                           c.mlp_hidden, c.ln_eps);
-        HIPTS_LAUNCH_CHECK();
+        HIPTS_TRY(launch_rowstat(stat_p, rowstat_p, M, M, sblocks, c.mlp_hidden, c.ln_eps, s));      // 86 partial pairs per row -> (rstd, rstd * mean)
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;

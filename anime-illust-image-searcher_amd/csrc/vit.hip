@@ -61,7 +61,7 @@ struct hipts_vit {
     std::vector<float> h_patch_bias, h_patch_rowsum;   // bias and sum_k W[n][k] (of the bf16 values)
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
-    DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs, stat_part, rowstat;
+    DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs, stat_part;
     bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default when dim % 64 == 0; HIPTS_LN_FOLD=0 turns it off)
     bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
     int pool_splits = 1;
@@ -372,7 +372,7 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     h->fold_ln = D % 64 == 0 && h->tokens % 8 == 0 && cfg->mlp_dim % 8 == 0 && !getenv("HIPTS_GEMM") &&
                  !(getenv("HIPTS_LN_FOLD") && atoi(getenv("HIPTS_LN_FOLD")) == 0);
     if (h->fold_ln) {
-        if ((st = h->stat_part.alloc(2 * ((D + 255) / 256) * M * 8))) {      // two sets: norm1 and norm2 statistics alternate
+        if ((st = h->stat_part.alloc(((D + 255) / 256) * M * 8))) {      // (sum x, sum x^2) per row and 256-column tile
             delete h;
             return st;
         }

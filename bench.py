@@ -404,7 +404,11 @@ def main():
                 "all_gemm_tflops": sum(c["flops"] for c in gemms) / (sum(c["total_ms"] for c in gemms) * 1e9),
                 "note": "timed region: 2 sub-batch streams, each launch (32 images) shares the chip with the other stream's "
                         "kernel, so achieved/frac are per launch UNDER that concurrency (rocprofv3 durations agree); "
-                        "'exclusive' = the same kernel over the whole batch with the chip to itself, measured after the timed region"}
+                        "'exclusive' = the same kernel over the whole batch with the chip to itself, measured after the timed region. "
+                        "Since the LayerNorm fold this kernel (EPI_RESID_XG, 23 of 24 residual GEMMs) also writes the 16-bit gamma*x "
+                        "operand and the row sums of the next LayerNorm, work that used to be 47 separate HBM-bound launches per "
+                        "forward: its own flop rate fell (178 -> 208 us per launch for the same algorithmic flops) while the "
+                        "forward got faster (model_mfma_frac 0.292 -> 0.299); HIPTS_LN_FOLD=0 restores the separate kernels"}
     ex = [c for c in excl if c["kernel"] == dom["kernel"]]
     if ex:
         egemms = [c for c in excl if c["kernel"].startswith("gemm_kernel")]
