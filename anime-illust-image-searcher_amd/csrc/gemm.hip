@@ -534,39 +534,71 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             // read-modify-write of the fp32 residual stream: RB x 4 loads of 16 B per lane in flight before the
             // first dependent add (RB 16-row blocks; the fragment registers of the main loop are free here),
             // so a CU keeps RB x 32 KB outstanding -- the epilogue is bound by HBM latency x bytes in flight.
+            // A tile that lies inside the matrix (all but the last row / column of tiles) takes the branch-free copy of the
+            // loop: with per-lane `if (valid) store` every store sits in its own exec-masked basic block, and the compiler
+            // opens each block with s_waitcnt vmcnt(0) -- CDNA4 counts stores in vmcnt, so each of the 32 stores waited for
+            // the previous one to be acknowledged.
             constexpr int RB = 4;
+            auto rmw = [&](auto interior_tag) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-            for (int i2 = 0; i2 < MR; i2 += RB) {
-                f32x4 xv[RB][4];
+                for (int i2 = 0; i2 < MR; i2 += RB) {
+                    f32x4 xv[RB][4];
 #pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    if (i2 + u >= MR) continue;
-                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
-                    const float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+                    for (int u = 0; u < RB; ++u) {
+                        if (i2 + u >= MR) continue;
+                        const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
+                        const float* row = a.out_f32 + (size_t)((INTERIOR || m < a.M) ? m : a.M - 1) * ld;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                        for (int j = 0; j < 4; ++j)
+                            xv[u][j] = (INTERIOR || nv[j]) ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    if (i2 + u >= MR) continue;
-                    const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
-                    if (m >= a.M) continue;
-                    float* row = a.out_f32 + (size_t)m * ld;
-                    float2 st = make_float2(1.f, 0.f);
-                    if constexpr (EPI == EPI_RESID_ROWSTAT) st = *reinterpret_cast<const float2*>(a.rowstat + 2 * (size_t)m);
+                    for (int u = 0; u < RB; ++u) {
+                        if (i2 + u >= MR) continue;
+                        const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
+                        const int mc = (INTERIOR || m < a.M) ? m : a.M - 1;
+                        float* row = a.out_f32 + (size_t)mc * ld;
+                        float2 st = make_float2(1.f, 0.f);
+                        if constexpr (EPI == EPI_RESID_ROWSTAT) st = *reinterpret_cast<const float2*>(a.rowstat + 2 * (size_t)mc);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!nv[j]) continue;
-                        if constexpr (EPI == EPI_RESCALE)
-                            *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] * rs[j] + (acc[i2 + u][j] + bv[j]);
-                        else if constexpr (EPI == EPI_RESID_ROWSTAT)
-                            *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + ((acc[i2 + u][j] * st.x - rs[j] * st.y) + bv[j]);
-                        else
-                            *reinterpret_cast<f32x4*>(row + nc[j]) = xv[u][j] + (acc[i2 + u][j] + bv[j]);
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 v;
+                            if constexpr (EPI == EPI_RESCALE)
+                                v = xv[u][j] * rs[j] + (acc[i2 + u][j] + bv[j]);
+                            else if constexpr (EPI == EPI_RESID_ROWSTAT)
+                                v = xv[u][j] + ((acc[i2 + u][j] * st.x - rs[j] * st.y) + bv[j]);
+                            else
+                                v = xv[u][j] + (acc[i2 + u][j] + bv[j]);
+                            if (INTERIOR || (nv[j] && m < a.M)) *reinterpret_cast<f32x4*>(row + nc[j]) = v;
+                        }
                     }
                 }
-            }
+            };
+            if (m0 + 2 * MR * 16 <= a.M && n0 + BN <= a.N) rmw(std::true_type{});      // uniform over the workgroup
+            else rmw(std::false_type{});
             return;
+        }
+        if constexpr (EPI == EPI_PATCH || EPI == EPI_BIAS) {
+            // interior tiles: branch-free (see the residual epilogue above)
+            if (m0 + 2 * MR * 16 <= a.M && n0 + BN <= a.N) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    const int m = m0 + wave_m * (MR * 16) + i * 16 + lr;
+                    f32x4 pv[4];
+                    if constexpr (EPI == EPI_PATCH) {
+                        const int t = m % a.tokens;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pv[j] = *reinterpret_cast<const f32x4*>(a.pos + (size_t)t * a.N + nc[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (EPI == EPI_PATCH) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] * a.qscale + bv[j] + pv[j];
+                        else *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] + bv[j];
+                    }
+                }
+                return;
+            }
         }
 #pragma unroll
         for (int i = 0; i < MR; ++i) {

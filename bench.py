@@ -405,10 +405,8 @@ def main():
                 "note": "timed region: 2 sub-batch streams, each launch (32 images) shares the chip with the other stream's "
                         "kernel, so achieved/frac are per launch UNDER that concurrency (rocprofv3 durations agree); "
                         "'exclusive' = the same kernel over the whole batch with the chip to itself, measured after the timed region. "
-                        "Since the LayerNorm fold this kernel (EPI_RESID_XG, 23 of 24 residual GEMMs) also writes the 16-bit gamma*x "
-                        "operand and the row sums of the next LayerNorm, work that used to be 47 separate HBM-bound launches per "
-                        "forward: its own flop rate fell (178 -> 208 us per launch for the same algorithmic flops) while the "
-                        "forward got faster (model_mfma_frac 0.292 -> 0.299); HIPTS_LN_FOLD=0 restores the separate kernels"}
+                        "HIPTS_LN_FOLD=1 folds the LayerNorms into the GEMM epilogues (+1.4 % images/s; this kernel then also writes the "
+                        "next LayerNorm's operand and row sums, 178 -> 215 us per launch): off by default for this model"}
     ex = [c for c in excl if c["kernel"] == dom["kernel"]]
     if ex:
         egemms = [c for c in excl if c["kernel"].startswith("gemm_kernel")]

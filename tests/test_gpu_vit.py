@@ -124,3 +124,42 @@ def test_deferred_join_gives_the_same_outputs():
     _lib.call("hipts_vit_set_deferred_join", model._h, 0)
     for c, wnt in zip(copies, want):
         np.testing.assert_array_equal(c.cpu().numpy(), wnt)
+
+
+def test_folded_layernorm_path_matches_the_separate_kernels():
+    """HIPTS_LN_FOLD=1 (read when the handle is created, hence the child interpreter): LayerNorms prepared by the residual
+    GEMM epilogues and applied in the consumer epilogues.  Same tolerance against the oracle as the default path, run to run
+    identical, and close to the default path's logits (both round the same operands, in a different place)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from hiptagsearch import synth
+from hiptagsearch.tagger import ViTTagger
+from oracle import vit as ov
+cfg = dict(synth.VIT_B16_448); cfg["depth"] = 4
+w = synth.vit_weights(cfg, seed=7)
+imgs = synth.images_u8(20, 448, seed=8)            # 20 images: two sub-batch streams of 10
+m = ViTTagger(cfg, w, max_batch=32)
+got, _ = m.forward_u8(imgs)
+again, _ = m.forward_u8(imgs)
+assert np.array_equal(got, again)
+one, _ = m.forward_u8(imgs[3:4])
+assert np.array_equal(one[0], got[3])
+want = ov.vit_forward(ov.to_torch(w), ov.preprocess_u8_nhwc(imgs[:2]), patch=cfg["patch"], heads=cfg["heads"], eps=cfg["ln_eps"]).numpy()
+err = np.abs(got[:2] - want).max()
+print("FOLD", float(err))
+np.save(sys.argv[1], got)
+assert err <= 1e-3, err
+""" % (root, os.path.join(root, "anime-illust-image-searcher_amd"))
+    import tempfile
+    outs = []
+    for fold in ("1", "0"):
+        f = tempfile.mktemp(suffix=".npy")
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, env=dict(os.environ, HIPTS_LN_FOLD=fold), timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        outs.append(np.load(f))
+        os.remove(f)
+    assert not np.array_equal(outs[0], outs[1])               # the folded path really ran
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-3
