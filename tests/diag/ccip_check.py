@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: CCIP encoder vs oracle, bf16 and half operands (gpurun only)."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
 import numpy as np
 from hiptagsearch import synth

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: ViT-B/16 logit error vs the fp32 oracle for a few weight / image seeds."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
 import numpy as np, torch
 torch.set_num_threads(16)
