@@ -46,6 +46,34 @@ int use_device(int device);
     } while (0)
 
 // Device allocation owned by a handle.
+// Pinned host staging memory (grow-only): async copies to / from it neither block the caller nor need a bounce buffer.
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    int reserve(size_t n) {
+        if (n <= bytes) return HIPTS_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        n = (n + 4095) / 4096 * 4096;
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_error(HIPTS_ERR_OOM, "hipHostMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        }
+        bytes = n;
+        return HIPTS_OK;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;

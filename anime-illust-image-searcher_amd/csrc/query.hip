@@ -36,7 +36,8 @@ struct hipts_bm25 {
     std::vector<double> h_idf;
     DevBuf d_ptr, d_term, d_tf, d_dl, d_idf;   // int64[D+1], int32[nnz], int32[nnz], int32[D], double[V]
     DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
-    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark;
+    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out;
+    PinBuf pin_in, pin_out;                    // hipts_search: one H2D of the packed queries, one D2H of the packed results
 };
 
 namespace {
@@ -1062,14 +1063,30 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     HIPTS_TRY(use_device(bm25->device));
     hipStream_t s = (hipStream_t)stream;
     const int64_t D = bm25->D;
-    const int32_t* qt;
-    const double* qw;
-    const int32_t* qp;
-    HIPTS_TRY(stage_queries(bm25, q_terms, q_weights, q_ptr, nq, &qt, &qw, &qp, s));
+    // queries, weights, offsets and the query vectors travel as ONE packed copy from pinned memory (no bounce buffer, no
+    // synchronisation before the kernels); the results come back the same way
+    const int nt = q_ptr[nq];
+    HIPTS_REQUIRE(q_ptr[0] == 0 && nt >= 0, "q_ptr must start at 0 and be non-decreasing");
+    const size_t off_w = ((size_t)nt * 4 + 15) / 16 * 16;
+    const size_t off_p = off_w + (size_t)nt * 8;
+    const size_t off_v = (off_p + (size_t)(nq + 1) * 4 + 15) / 16 * 16;
+    const size_t in_bytes = off_v + (size_t)nq * index->dim * 4;
+    HIPTS_TRY(bm25->pin_in.reserve(in_bytes));
+    HIPTS_TRY(bm25->ws_q.reserve(in_bytes));
+    char* hin = bm25->pin_in.as<char>();
+    if (nt) {
+        memcpy(hin, q_terms, (size_t)nt * 4);
+        memcpy(hin + off_w, q_weights, (size_t)nt * 8);
+    }
+    memcpy(hin + off_p, q_ptr, (size_t)(nq + 1) * 4);
+    memcpy(hin + off_v, q_vectors, (size_t)nq * index->dim * 4);
+    HIPTS_HIP(hipMemcpyAsync(bm25->ws_q.p, hin, in_bytes, hipMemcpyHostToDevice, s));
+    const int32_t* qt = bm25->ws_q.as<int32_t>();
+    const double* qw = reinterpret_cast<const double*>(bm25->ws_q.as<char>() + off_w);
+    const int32_t* qp = reinterpret_cast<const int32_t*>(bm25->ws_q.as<char>() + off_p);
+    const float* qvec = reinterpret_cast<const float*>(bm25->ws_q.as<char>() + off_v);
     HIPTS_TRY(bm25->ws_scores.reserve((size_t)nq * D * 8));
     HIPTS_TRY(bm25->ws_sims.reserve((size_t)nq * D * 4));
-    HIPTS_TRY(index->ws_q.reserve((size_t)nq * index->dim * 4));
-    HIPTS_HIP(hipMemcpyAsync(index->ws_q.p, q_vectors, (size_t)nq * index->dim * 4, hipMemcpyHostToDevice, s));
     double* final_dev = final_out_device;
     if (!final_dev) {
         HIPTS_TRY(bm25->ws_final.reserve((size_t)nq * D * 8));
@@ -1082,7 +1099,7 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     double* ma = bm25->ws_max.as<double>();
     float* mb = reinterpret_cast<float*>(ma + nq);
     HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
-    HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, index->ws_q.as<float>(), nq, bm25->ws_sims.as<float>(), D, s));
+    HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s));
     rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
     HIPTS_LAUNCH_CHECK();
     {
@@ -1091,7 +1108,25 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
                                             mb, nullptr, final_dev);
         HIPTS_LAUNCH_CHECK();
     }
-    return hipts_topk(final_dev, nq, D, k, ids_out, vals_out, HIPTS_HOST, bm25->device, stream);
+    HIPTS_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "hipts_search: k must be in [1, %d]", TOPK_MAX_K);
+    const int kk = (int)std::min<int64_t>(k, D);
+    const size_t out_bytes = (size_t)nq * kk * 12;
+    HIPTS_TRY(bm25->ws_out.reserve(out_bytes + 64));
+    HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 64));
+    double* ov = bm25->ws_out.as<double>();
+    int32_t* oi = reinterpret_cast<int32_t*>(ov + (size_t)nq * kk);
+    topk_kernel<<<nq, 1024, 0, s>>>(final_dev, D, kk, oi, ov);
+    HIPTS_LAUNCH_CHECK();
+    HIPTS_HIP(hipMemcpyAsync(bm25->pin_out.p, ov, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPTS_HIP(hipStreamSynchronize(s));
+    const double* hv = bm25->pin_out.as<double>();
+    const int32_t* hi = reinterpret_cast<const int32_t*>(hv + (size_t)nq * kk);
+    for (int q = 0; q < nq; ++q)
+        for (int i = 0; i < k; ++i) {
+            ids_out[(size_t)q * k + i] = i < kk ? hi[(size_t)q * kk + i] : -1;
+            vals_out[(size_t)q * k + i] = i < kk ? hv[(size_t)q * kk + i] : -INFINITY;
+        }
+    return HIPTS_OK;
 }
 
 }  // extern "C"

@@ -102,8 +102,10 @@ inline uint8_t f32_to_e4m3_rne(float f) {
 inline float e4m3_bits_to_f32(uint8_t v) {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
     float f;
-    if (e == 15 && m == 7) f = NAN;
-    else if (e == 0) f = ldexpf((float)m, -9);
+    if (e == 15 && m == 7) {
+        const uint32_t qnan = 0x7fc00000u;      // (not the NAN macro: attn.hip is built with -fno-honor-nans)
+        memcpy(&f, &qnan, 4);
+    } else if (e == 0) f = ldexpf((float)m, -9);
     else f = ldexpf(1.0f + (float)m / 8.0f, e - 7);
     return s ? -f : f;
 }
