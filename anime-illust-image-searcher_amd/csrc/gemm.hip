@@ -33,6 +33,12 @@ namespace hipts {
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
+#ifndef HIPTS_STAGE_W_EARLY
+#define HIPTS_STAGE_W_EARLY 0         // 1: W-high in phase 0 as well (3 phases to land instead of 2): 8192^3 943 -> 1074 TFLOP/s but K = 3072 / 4096 shapes 5 % slower
+#endif
+#ifndef HIPTS_STAGE_ORDER_OLD
+#define HIPTS_STAGE_ORDER_OLD 0       // 1: the previous staging order of the ping-pong loop (A/B builds)
+#endif
 constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 128 KiB
@@ -1084,17 +1090,38 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                     if (mh * 4 + i < MR) af[i] = read_frag(cur, wave_m * MR + mh * 4 + i, kk, lane);
                 }
                 if (more) {
-                    glds16(src[2 * p], nxt + dst[2 * p]);
-                    src[2 * p] += BK;
-                    if (p < 3 || n_hi == 2) {
-                        glds16(src[2 * p + 1], nxt + dst[2 * p + 1]);
-                        src[2 * p + 1] += BK;
-                    }
-                    if (p == 3) {           // W and A-low of tile t+1 landed; only this phase's A-high may be in flight
-                        if (n_hi == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                    } else if (p == 1) {
-                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                    // Issue order of the next K-tile's eight sub-tile loads (slots: 0,1 W-low  2,3 W-high  4,5 A-low  6,7 A-high):
+                    // what the next tile reads first goes first -- A-low and W-low in phase 0, W-high in phase 1 (all read in the
+                    // next phase 0: 4, 4 and 3 phases to land), A-high in phase 2 (read in the next phase 2: 4 phases; its region
+                    // was last read in the previous tile's phase 3, restaged 3 phases later).  With the former order (W, W, A-low,
+                    // A-high over phases 0..3) A-low had only 2 phases = ~300 ns, less than an L2 round trip.
+                    auto issue = [&](int k) {
+                        glds16(src[k], nxt + dst[k]);
+                        src[k] += BK;
+                    };
+                    if (HIPTS_STAGE_ORDER_OLD) {
+                        issue(2 * p);
+                        if (p < 3 || n_hi == 2) issue(2 * p + 1);
+                        if (p == 3) {           // W and A-low of tile t+1 landed; only this phase's A-high may be in flight
+                            if (n_hi == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        } else if (p == 1) {
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                        }
+                    } else {
+                        if (p == 0) {
+                            issue(4); issue(5); issue(0); issue(1);
+                            if (HIPTS_STAGE_W_EARLY) { issue(2); issue(3); }
+                        } else if (p == 1) {
+                            if (!HIPTS_STAGE_W_EARLY) { issue(2); issue(3); }
+                            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A-high of this tile (issued in its predecessor's phase 2) landed
+                        } else if (p == 2) {
+                            issue(6);
+                            if (n_hi == 2) issue(7);
+                        } else {                // W and A-low of tile t+1 landed; only its A-high may be in flight
+                            if (n_hi == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        }
                     }
                 } else if (p == 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

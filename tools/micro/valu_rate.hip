@@ -1,7 +1,8 @@
-// Development aid: issue rate of v_exp_f32 / v_rcp_f32 / v_pk_fma_f32 / v_fma_f32 on gfx950 (one wave per SIMD).
+// Development aid: issue rate of v_exp_f32 / v_rcp_f32 / v_pk_fma_f32 / v_fma_f32 / v_dot2c_f32_bf16 / v_perm_b32 on gfx950 (one wave per SIMD).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <int OP>
 __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* cyc) {
     float a[24];
@@ -16,6 +17,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
             if (OP == 2) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
             if (OP == 3) p[i] = __builtin_elementwise_fma(p[i], f32x2{1.0001f, 1.0001f}, f32x2{0.5f, 0.5f});
             if (OP == 4) a[i] = fmaxf(fmaxf(a[i], a[i]), 0.25f);
+            if (OP == 5) a[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p[i][0]), __builtin_bit_cast(bf16x2, p[(i + 1) % 24][1]), a[i], false);
+            if (OP == 6) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, a[i]), __builtin_bit_cast(unsigned, a[(i + 1) % 24]), 0x05040100u));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -28,13 +31,13 @@ int main() {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 64);
     const int iters = 4096;
-    const char* names[] = {"v_exp_f32", "v_rcp_f32", "v_fma_f32", "v_pk_fma_f32", "v_max3_f32"};
+    const char* names[] = {"v_exp_f32", "v_rcp_f32", "v_fma_f32", "v_pk_fma_f32", "v_max3_f32", "v_dot2c_f32_bf16", "v_perm_b32"};
     for (int rep = 0; rep < 2; ++rep) {
         k<0><<<256, 256>>>(out, iters, cyc); k<1><<<256, 256>>>(out, iters, cyc); k<2><<<256, 256>>>(out, iters, cyc);
-        k<3><<<256, 256>>>(out, iters, cyc); k<4><<<256, 256>>>(out, iters, cyc);
+        k<3><<<256, 256>>>(out, iters, cyc); k<4><<<256, 256>>>(out, iters, cyc); k<5><<<256, 256>>>(out, iters, cyc); k<6><<<256, 256>>>(out, iters, cyc);
         hipDeviceSynchronize();
     }
     unsigned long long h[8]; hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 5; ++i) printf("%-14s %.2f cycles per wave instruction (1 wave/SIMD)\n", names[i], (double)h[i] / (iters * 24.0));
+    for (int i = 0; i < 7; ++i) printf("%-14s %.2f cycles per wave instruction (1 wave/SIMD)\n", names[i], (double)h[i] / (iters * 24.0));
     return 0;
 }
