@@ -33,6 +33,11 @@ namespace hipts {
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
+#ifndef HIPTS_STAGE_AHEAD
+#define HIPTS_STAGE_AHEAD 0           // 1: regions are restaged as soon as they are free, up to two K-tiles ahead (see the loop): one more
+                                      // phase for every load.  Measured: 8192^3 952 -> 1074 TFLOP/s (operands from HBM), the ViT's K = 768 / 3072
+                                      // shapes (operands from L2) 2-4 % slower, the forward within noise -- built with -DHIPTS_STAGE_AHEAD=1
+#endif
 #ifndef HIPTS_STAGE_W_EARLY
 #define HIPTS_STAGE_W_EARLY 0         // 1: W-high in phase 0 as well (3 phases to land instead of 2): 8192^3 943 -> 1074 TFLOP/s but K = 3072 / 4096 shapes 5 % slower
 #endif
@@ -952,6 +957,21 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a, int tiles_m
 // ---------------------------------------------------------------------------------------------
 // MR = 16-row blocks per wave: 8 -> 256-row tiles, 7 -> 224-row tiles (50176 = 224 * 224: for N = 768 the
 // grid becomes 672 tiles = 3 rounds of 0.875-size tiles instead of 588 = 3 rounds (2.3 needed) of full ones).
+// s_waitcnt vmcnt(n) for a run-time n in 0..8 (the counts of the ping-pong loop differ in its first and last K-tiles)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
 // OP8: e4m3 operands.  A K-tile is the same 256 rows x 128 B (now 128 elements), staged by the same code with the
 // matrices seen as 16-bit ones of K / 2 columns; one 16x16x128 MFMA (32 cycles) replaces the two 16x16x32 (16 each)
 // of a (row block, column block), so the four phases split the column blocks instead of the K halves --
@@ -1059,6 +1079,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
         if (wave_m == 1) __builtin_amdgcn_s_barrier();      // stagger group 1 by one interval
         PPSTAMP(2);
         if (a.stamps && blockIdx.x == 8 && stamp_tile < 8 && lane == 0) a.stamps[wave * 64 + stamp_tile * 8 + 6] = wall_clock64();
+        if (HIPTS_STAGE_AHEAD && !HIPTS_STAGE_ORDER_OLD && nt > 1) {
+            // "phase 3 of K-tile -1": A-low and W-low of K-tile 1 into the other stage (the previous epilogue's scratch, free now)
+            char* st1 = smem + ((par + 1) & 1) * STAGE_BYTES;
+            for (int k : {4, 5, 0, 1}) {
+                glds16(src[k], st1 + dst[k]);
+                src[k] += BK;
+            }
+        }
 
         bf16x8 wf[2][4];
         i32x8 wf8[4], af8[4];
@@ -1107,6 +1135,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
                             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                         } else if (p == 1) {
                             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A-high of this tile landed
+                        }
+                    } else if (HIPTS_STAGE_AHEAD) {
+                        // A region is restaged as soon as it is free (>= 2 phases after its last ds_read, >= 3 where the reader
+                        // may be the staggered group): W-high and A-high of K-tile t+1 go to the other stage in phases 0 and 1, and
+                        // A-low / W-low of K-tile t+2 go into THIS stage in phase 3 (last read in phase 1).  Every load then has
+                        // >= 3 phases (W-high) or 4 (the rest) before the counted wait that retires it:
+                        //   end of R(1): A-high of this tile -- issued since: A-low/W-low(t+1) 4, W-high(t+1) 2, A-high(t+1) n_hi
+                        //   end of R(3): all of tile t+1 but its A-high -- issued since: A-high(t+1) n_hi, A-low/W-low(t+2) 4
+                        if (p == 0) {
+                            issue(2); issue(3);
+                        } else if (p == 1) {
+                            issue(6);
+                            if (n_hi == 2) issue(7);
+                            wait_vmcnt(6 + n_hi);
+                        } else if (p == 3) {
+                            if (t + 2 < nt) {
+                                for (int k : {4, 5, 0, 1}) {
+                                    glds16(src[k], const_cast<char*>(cur) + dst[k]);
+                                    src[k] += BK;
+                                }
+                                wait_vmcnt(n_hi + 4);
+                            } else {
+                                wait_vmcnt(n_hi);
+                            }
                         }
                     } else {
                         if (p == 0) {
