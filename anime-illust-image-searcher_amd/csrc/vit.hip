@@ -968,6 +968,23 @@ int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int ba
 // Development aid (not part of the public ABI, not declared in include/hip_tagsearch.h): time one
 // GEMM shape with random bf16 operands.  Used by tools/gemm_bench.py under gpurun.
 // ---------------------------------------------------------------------------------------------
+static float g_last_loop_ghz = 0.f;     // hiptsdbg_gemm_clock: shader clock during the main loop of the last stamped launch
+
+extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out);
+
+// Diagnostic (bench.py): the shader clock the chip sustains inside the GEMM main loop -- cycle counter against the 100 MHz
+// wall clock between the loop's first and last barrier, one workgroup's stamps of the last of `iters` back-to-back launches.
+extern "C" int hiptsdbg_gemm_clock(int M, int N, int K, int epi, int iters, float* ms_out, float* loop_ghz) {
+    HIPTS_REQUIRE(ms_out && loop_ghz, "null argument");
+    const char* had = getenv("HIPTS_GEMM_STAMPS");
+    setenv("HIPTS_GEMM_STAMPS", "quiet", 1);
+    g_last_loop_ghz = 0.f;
+    const int st = hiptsdbg_gemm_time(M, N, K, epi, iters, ms_out);
+    if (!had) unsetenv("HIPTS_GEMM_STAMPS");
+    *loop_ghz = g_last_loop_ghz;
+    return st;
+}
+
 extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out) {
     HIPTS_TRY(use_device(0));
     const int Np = round_up(N, 256);
@@ -1042,9 +1059,12 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
             for (int w = 0; w < 4; ++w)
                 fprintf(stderr, "dw wave %d: loop %lld cycles, waitcnt %lld, barrier %lld, wall %lld x 10 ns -> %.2f GHz\n", w, (long long)h[w * 64],
                         (long long)h[w * 64 + 1], (long long)h[w * 64 + 2], (long long)h[w * 64 + 3], h[w * 64] / (h[w * 64 + 3] * 10.0));
-        } else
-        fprintf(stderr, "stamps of workgroup 8 (cycles since first): per tile [top, K-tile 0 landed, loop start, loop end, next prologue issued, epilogue issued]\n");
-        for (int w = 0; w < 8; w += 4) {
+        }
+        const bool quiet = strcmp(getenv("HIPTS_GEMM_STAMPS"), "quiet") == 0 || getenv("HIPTS_GEMM_TRACE") ||
+                           (getenv("HIPTS_GEMM") && strcmp(getenv("HIPTS_GEMM"), "dw") == 0);
+        if (h[2] && h[7] > h[6]) g_last_loop_ghz = (float)((h[3] - h[2]) / ((h[7] - h[6]) * 10.0));      // wave 0, tile 0
+        if (!quiet) fprintf(stderr, "stamps of workgroup 8 (cycles since first): per tile [top, K-tile 0 landed, loop start, loop end, next prologue issued, epilogue issued]\n");
+        for (int w = 0; w < 8 && !quiet; w += 4) {
             for (int t = 0; t < 8; ++t) {
                 if (!h[w * 64 + t * 8]) continue;
                 fprintf(stderr, "wave %d tile %d:", w, t);

@@ -407,6 +407,25 @@ def main():
                         "'exclusive' = the same kernel over the whole batch with the chip to itself, measured after the timed region. "
                         "HIPTS_LN_FOLD=1 folds the LayerNorms into the GEMM epilogues (+1.4 % images/s; this kernel then also writes the "
                         "next LayerNorm's operand and row sums, 178 -> 215 us per launch): off by default for this model"}
+    # the shader clock the chip sustains inside the GEMM main loop (in-kernel cycle counter against the 100 MHz wall clock): the
+    # nominal peak assumes 2.4 GHz, dense MFMA work runs power-limited well below it
+    try:
+        lib = _lib.load()
+        lib.hiptsdbg_gemm_clock.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)] * 2
+        clocks = {}
+        for tag, (gm, gn, gk, ge) in {"resid_k768": (BATCH * 784, 768, 768, 3), "resid_k3072": (BATCH * 784, 768, 3072, 3),
+                                      "gelu_k768": (BATCH * 784, 3072, 768, 4)}.items():
+            ms_, ghz = ctypes.c_float(), ctypes.c_float()
+            if lib.hiptsdbg_gemm_clock(gm, gn, gk, ge, 20, ctypes.byref(ms_), ctypes.byref(ghz)) == 0 and ghz.value > 0:
+                clocks[tag] = round(ghz.value, 3)
+        if clocks:
+            lo = min(clocks.values())
+            roofline["clock"] = {"nominal_ghz": 2.4, "main_loop_ghz": clocks,
+                                 "peak_at_measured_clock_tflops": MFMA_BF16_PEAK_TFLOPS * lo / 2.4,
+                                 "note": "20 back-to-back launches per shape, standalone; peak_at_measured_clock scales the 2.5 PF "
+                                         "nominal peak by the lowest of these clocks"}
+    except Exception as e:
+        roofline["clock"] = {"error": repr(e)}
     ex = [c for c in excl if c["kernel"] == dom["kernel"]]
     if ex:
         egemms = [c for c in excl if c["kernel"].startswith("gemm_kernel")]
