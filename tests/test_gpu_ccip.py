@@ -122,3 +122,17 @@ def test_ccip_e4m3_operands_noise_is_the_formats(which):
     # the 16-bit mode of the same weights is far closer: the e4m3 path really ran
     ref16 = CCIPEncoder(dict(base, operand_f16=1), w, max_batch=n).forward_u8(imgs)
     assert cos(ref16, want) > 0.99999 and not np.array_equal(ref16, got)
+
+
+def test_ccip_two_sub_batch_streams_match_single_stream():
+    """batch >= 32 runs as two sub-batches on two internal streams; rows must equal the single-stream results."""
+    from hiptagsearch import synth
+    from hiptagsearch.cfeatures import CCIPEncoder
+    cfg = dict(synth.CCIP_TINY)
+    w = synth.ccip_weights(cfg, seed=6)
+    imgs = synth.images_u8(37, cfg["image_size"], seed=50)
+    enc = CCIPEncoder(cfg, w, max_batch=40)
+    got = enc.forward_u8(imgs)
+    np.testing.assert_array_equal(enc.forward_u8(imgs), got)
+    small = CCIPEncoder(cfg, w, max_batch=8)                      # batches of 8: one stream
+    np.testing.assert_array_equal(small.forward_u8(imgs), got)

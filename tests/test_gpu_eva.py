@@ -73,3 +73,18 @@ def test_eva_missing_tensor_is_reported():
     w.pop("blocks.1.attn.k_proj.weight")
     with pytest.raises(_lib.HipTagSearchError, match="not set"):
         EvaTagger(cfg, w, max_batch=2).forward_u8(synth.images_u8(1, cfg["image_size"], seed=3))
+
+
+def test_eva_two_sub_batch_streams_match_single_stream():
+    """batch >= 16 runs as two sub-batches on two internal streams (per-image workspace offsets, folded-LayerNorm statistics
+    per sub-batch): every image must come out exactly as when it is computed alone."""
+    from hiptagsearch import synth
+    from hiptagsearch.tagger import EvaTagger
+    cfg = dict(synth.EVA02_TINY)
+    w = synth.eva_weights(cfg, seed=4)
+    imgs = synth.images_u8(19, cfg["image_size"], seed=5)
+    model = EvaTagger(cfg, w, max_batch=32)
+    logits, _ = model.forward_u8(imgs)
+    np.testing.assert_array_equal(model.forward_u8(imgs)[0], logits)
+    for i in (0, 9, 10, 18):                                      # both halves, including their first and last images
+        np.testing.assert_array_equal(model.forward_u8(imgs[i:i + 1])[0][0], logits[i])
