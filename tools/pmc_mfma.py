@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Parse a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (with --kernel-trace for the durations) into
+per-kernel matrix-pipe utilisation and effective clock, as MI355X_MICROARCH.md prescribes: SQ_VALU_MFMA_BUSY_CYCLES counts
+shader cycles (16 per v_mfma_f32_16x16x32_bf16) summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+so elapsed cycles = GRBM_GUI_ACTIVE / 8 and effective clock = that / kernel wall time (reads high on dispatches < 0.3 ms)."""
+import csv, glob, json, os, sys, collections
+root, out = sys.argv[1], sys.argv[2]
+SIMDS = 256 * 4
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+n = collections.defaultdict(int)
+dur = collections.defaultdict(float)
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    seen = set()
+    for row in csv.DictReader(open(f)):
+        name = (row.get("Kernel_Name") or row.get("Kernel Name")).replace("void ", "").replace("hipts::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+        agg[name][row["Counter_Name"]] += float(row["Counter_Value"])
+        key = (row.get("Dispatch_Id"), name)
+        if key not in seen:
+            seen.add(key)
+            n[name] += 1
+            if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                dur[name] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+res = {}
+for k, c in agg.items():
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    if gui <= 0:
+        continue
+    res[k] = {"launches": n[k], "mfma_busy_frac": busy / (gui * SIMDS), "elapsed_cycles_per_launch": gui / max(n[k], 1),
+              "effective_clock_ghz": (gui / dur[k]) if dur[k] > 0 else None}
+json.dump({"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+                     "--no-query --no-exclusive`; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): the share of "
+                     "SIMD-cycles AT THE CLOCK THE KERNEL RAN AT in which the matrix pipe was busy (two-stream forward: a launch shares the chip)",
+           "kernels": res}, open(out, "w"), indent=1)
+for k, v in sorted(res.items(), key=lambda kv: -kv[1]["mfma_busy_frac"])[:12]:
+    print("%-44s n=%4d  MFMA busy %5.1f %%  clock %s GHz" % (k[:44], v["launches"], 100 * v["mfma_busy_frac"],
+                                                           ("%.2f" % v["effective_clock_ghz"]) if v["effective_clock_ghz"] else "-"))
