@@ -265,6 +265,37 @@ __device__ __forceinline__ void staged_store_rows8(char* region, int lane, int m
     }
 }
 
+// One or two 16-row blocks (32 rows x 64 columns) of 16-bit values through a 4 KB wave-private image: the per-block form of
+// staged_store_rows for epilogues that finish their rows two blocks at a time (EPI_RESID_XG).
+template <bool F16, typename ValueOf>
+__device__ __forceinline__ void staged_store_2blocks(char* image, int lane, int mrow_first, int nblk, int M, bf16_t* out, int ld, int ncol0, int N,
+                                                     ValueOf value_of) {
+    const int lr = lane & 15, lq = lane >> 4, lc = lane & 7, lrow = lane >> 3;
+    const bool nvl = ncol0 + lc * 8 < N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nblk) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = u * 16 + lr;
+            const int pc = (j * 2 + (lq >> 1)) ^ ((row >> 1) & 7);
+            const f32x4 v = value_of(u, j);
+            *reinterpret_cast<bf16x4*>(image + row * 128 + pc * 16 + (lq & 1) * 8) = pack4<F16>(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r8 = 0; r8 < 4; ++r8) {
+        const int row = r8 * 8 + lrow;
+        const int m = mrow_first + row;
+        const uint4 v = *reinterpret_cast<const uint4*>(image + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+        if (row < nblk * 16 && m < M && nvl) *reinterpret_cast<uint4*>(out + (size_t)m * ld + ncol0 + lc * 8) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // A (16 MR) x 32 block of 16-bit values (the SwiGLU product: half as many output columns as accumulator columns):
 // 64 B per row, the image geometry of staged_store_rows8 with 8 B per (row block, column block) -- lane (lr, lq) writes
 // columns 16 jj + 4 lq ..+3 of row 16 i + lr; bank = 16 (row & 3) + 4 (chunk ^ (row >> 2) & 3) + 2 (lq & 1) per half wave.
@@ -455,14 +486,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
         }
         if constexpr (EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) {
             constexpr bool fold = EPI == EPI_RESID_XGI;
-            // (A software-pipelined form -- loads of rows 64..127 in flight under the LDS-staged copy of rows 0..63 -- needs the
-            // 64 load registers, 128 accumulators, gamma and bias at once: it spilled 95 registers and ran 242 vs 215 us.)
+            // (A software-pipelined form with FOUR row blocks per step -- loads of rows 64..127 in flight under the LDS-staged copy
+            // of rows 0..63 -- needs 64 load registers, 128 accumulators, gamma and bias at once: 95 spilled registers, 242 us.)
             f32x4 uv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) uv[j] = (fold && nv[j]) ? *reinterpret_cast<const f32x4*>(a.col_u + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            // ---- the residual read-modify-write; the new row values stay in acc (two row blocks of loads in flight: four
-            // measured the same, 215 us, with 24 B of spills)
+            // ---- two 16-row blocks at a time: residual read-modify-write, then -- while the next blocks' loads are issued -- this
+            // pair's share of the row sums and its gamma-scaled 16-bit copy through a 4 KB wave-private LDS image.  (With the copy
+            // and the statistics after the whole read-modify-write the 16-bit stores formed a tail of their own: 215 us per
+            // launch; two row blocks of loads in flight and four measure the same.)
             constexpr int RB = 2;
+            const int ncol0 = n0 + wave_n * 64;
+            const bool copy = a.out_bf16 != nullptr;
+            f32x4 gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = (copy && nv[j]) ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            char* image = scratch + (wave_m * 4 + wave_n) * 4096;                     // 8 x 4 KB
+            float2* red = reinterpret_cast<float2*>(scratch + 8 * 4096);              // [256 rows][4 waves] behind the images
 #pragma unroll
             for (int i2 = 0; i2 < MR; i2 += RB) {
                 f32x4 xv[RB][4];
@@ -491,26 +531,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                         if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(row + nc[j]) = acc[i2 + u][j];
                     }
                 }
-            }
-            if (!a.out_bf16) return;
-            // ---- what the next LayerNorm needs: the row sums over this tile's 256 columns (the four waves that hold a row meet
-            // in LDS, like EPI_RESID_LN), and the gamma-scaled 16-bit copy
-            const int ncol0 = n0 + wave_n * 64;
-            if (a.stat_part) {
-                float2* red = reinterpret_cast<float2*>(scratch);
+                if (!copy) continue;
+                if (a.stat_part) {
 #pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    f32x4 t = acc[i][0], q = acc[i][0] * acc[i][0];
+                    for (int u = 0; u < RB; ++u) {
+                        const int i = i2 + u;
+                        if (i >= MR) continue;
+                        f32x4 t = acc[i][0], q = acc[i][0] * acc[i][0];
 #pragma unroll
-                    for (int j = 1; j < 4; ++j) {
-                        t = t + acc[i][j];
-                        q = q + acc[i][j] * acc[i][j];
+                        for (int j = 1; j < 4; ++j) {
+                            t = t + acc[i][j];
+                            q = q + acc[i][j] * acc[i][j];
+                        }
+                        float s1 = (t[0] + t[1]) + (t[2] + t[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+                        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                        if (lq == 0) red[(wave_m * (MR * 16) + i * 16 + lr) * 4 + wave_n] = make_float2(s1, s2);      // columns past N hold zeros
                     }
-                    float s1 = (t[0] + t[1]) + (t[2] + t[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
-                    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                    if (lq == 0) red[(wave_m * (MR * 16) + i * 16 + lr) * 4 + wave_n] = make_float2(s1, s2);      // columns past N hold zeros
                 }
+                staged_store_2blocks<F16>(image, lane, m0 + wave_m * (MR * 16) + i2 * 16, (MR - i2) < RB ? (MR - i2) : RB, a.M, a.out_bf16, ld, ncol0, a.N,
+                                          [&](int u, int j) { return acc[i2 + u][j] * gv[j]; });
+            }
+            if (copy && a.stat_part) {
+                // the four waves that hold a row meet (uniform); red is written again only after the next tile's main loop
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -523,13 +566,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                         *reinterpret_cast<float2*>(a.stat_part + 2 * ((size_t)(n0 >> 8) * a.stat_stride + m)) =
                             make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
                 }
-                __builtin_amdgcn_s_barrier();       // red is overwritten by the staging images below
             }
-            f32x4 gv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gv[j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            staged_store_rows<MR, F16>(scratch + (wave_m * 4 + wave_n) * 8192, lane, m0 + wave_m * (MR * 16), a.M, a.out_bf16, ld, ncol0, a.N,
-                                       [&](int i, int j) { return acc[i][j] * gv[j]; });
             return;
         }
         if constexpr (EPI == EPI_RESID || EPI == EPI_RESCALE || EPI == EPI_RESID_ROWSTAT) {

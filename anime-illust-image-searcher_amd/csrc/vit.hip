@@ -62,7 +62,7 @@ struct hipts_vit {
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs, stat_part;
-    bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (HIPTS_LN_FOLD=1)
+    bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default; HIPTS_LN_FOLD=0 turns it off)
     bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
     int pool_splits = 1;
     static constexpr int kMaxSub = 4;
@@ -369,11 +369,11 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
         delete h;
         return st;
     }
-    // Opt-in for this model (HIPTS_LN_FOLD=1): measured +1.4 % images/s (five A/B pairs), while the residual GEMM -- the
-    // kernel the roofline is reported on -- gets the LayerNorm preparation added to its epilogue (178 -> 215 us per launch for
-    // the same flops).  The EVA02 forward, where it is worth +6 % at the reference's batch of 10, has it on by default.
-    h->fold_ln = D % 64 == 0 && h->tokens % 8 == 0 && cfg->mlp_dim % 8 == 0 && !getenv("HIPTS_GEMM") && getenv("HIPTS_LN_FOLD") &&
-                 atoi(getenv("HIPTS_LN_FOLD")) != 0;
+    // On by default (HIPTS_LN_FOLD=0 restores the separate LayerNorm kernels): +3.4 % images/s (4.57 -> 4.73 k, two A/B pairs on one
+    // box) once the residual epilogue interleaved the 16-bit copy with its read-modify-write; the residual GEMM's own launch
+    // grows from 174 to 207 us for the same flops, which is what `roofline` in the bench line then shows for that kernel.
+    h->fold_ln = D % 64 == 0 && h->tokens % 8 == 0 && cfg->mlp_dim % 8 == 0 && !getenv("HIPTS_GEMM") &&
+                 !(getenv("HIPTS_LN_FOLD") && atoi(getenv("HIPTS_LN_FOLD")) == 0);
     if (h->fold_ln) {
         if ((st = h->stat_part.alloc(((D + 255) / 256) * M * 8))) {      // (sum x, sum x^2) per row and 256-column tile
             delete h;

@@ -405,8 +405,10 @@ def main():
                 "note": "timed region: 2 sub-batch streams, each launch (32 images) shares the chip with the other stream's "
                         "kernel, so achieved/frac are per launch UNDER that concurrency (rocprofv3 durations agree); "
                         "'exclusive' = the same kernel over the whole batch with the chip to itself, measured after the timed region. "
-                        "HIPTS_LN_FOLD=1 folds the LayerNorms into the GEMM epilogues (+1.4 % images/s; this kernel then also writes the "
-                        "next LayerNorm's operand and row sums, 178 -> 215 us per launch): off by default for this model"}
+                        "The LayerNorms are folded into the GEMM epilogues (+3.4 % images/s): this kernel (EPI_RESID_XG, 23 of the 24 "
+                        "residual GEMMs of a forward) also writes the next LayerNorm's 16-bit gamma*x operand and row sums, work that "
+                        "used to be 47 separate HBM-bound launches per forward, so its own launch takes 207 instead of 174 us for the "
+                        "same algorithmic flops while the forward is faster; HIPTS_LN_FOLD=0 restores the separate kernels"}
     # the shader clock the chip sustains inside the GEMM main loop (in-kernel cycle counter against the 100 MHz wall clock): the
     # nominal peak assumes 2.4 GHz, dense MFMA work runs power-limited well below it
     try:
