@@ -512,7 +512,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     if (i2 + u >= MR) continue;
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     const int mc = m < a.M ? m : a.M - 1;
-                    const float* row = a.out_f32 + (size_t)mc * ld;
+                    // a.pos: the patch embedding as the first "residual" GEMM -- x = acc * qscale + bias + pos[token] instead of x += ...
+                    const float* row = a.pos ? a.pos + (size_t)(mc % a.tokens) * a.N : a.out_f32 + (size_t)mc * ld;
                     st[u] = fold ? row_stat(a, mc) : make_float2(1.f, 0.f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -527,7 +528,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                         if constexpr (fold)
                             acc[i2 + u][j] = nv[j] ? xv[u][j] + (acc[i2 + u][j] * st[u].x + (bv[j] - uv[j] * st[u].y)) : f32x4{0.f, 0.f, 0.f, 0.f};
                         else
-                            acc[i2 + u][j] = nv[j] ? xv[u][j] + (acc[i2 + u][j] + bv[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            acc[i2 + u][j] = nv[j] ? (a.pos ? acc[i2 + u][j] * a.qscale + bv[j] + xv[u][j] : xv[u][j] + (acc[i2 + u][j] + bv[j]))
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
                         if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(row + nc[j]) = acc[i2 + u][j];
                     }
                 }

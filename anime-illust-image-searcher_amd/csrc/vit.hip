@@ -629,18 +629,23 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     } else {       // hi | lo split of the float input against [W | W]
         g.W = h->patch_w2.as<bf16_t>(); g.K = 2 * h->patch_k; g.bias = h->patch_b.as<float>(); g.qscale = 1.0f;
     }
+    const bool fold = h->fold_ln;
+    const int sblocks = (D + 255) / 256;                 // partial (sum, sum of squares) pairs per row: one per 256-column tile
+    float* stat_p = fold ? h->stat_part.as<float>() + 2 * (size_t)sblocks * r0 : nullptr;
     {
-        ProfScope ps(h, s, PC_GEMM_PATCH, 2.0 * dM * dD * h->patch_k, dM * h->patch_k * 2 + dM * dD * 4);
-        HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+        ProfScope ps(h, s, PC_GEMM_PATCH, 2.0 * dM * dD * h->patch_k, dM * h->patch_k * 2 + dM * dD * 4 + (fold ? dM * dD * 2 : 0.0));
+        if (fold) {      // the first norm1 is prepared by this epilogue as well (EPI_RESID_XG with `pos`: x = acc * qscale + bias + pos)
+            g.out_bf16 = xn; g.ln_gamma = h->layers[0].ln1_g.as<float>(); g.stat_part = stat_p; g.stat_stride = M;
+            HIPTS_TRY(launch_gemm(EPI_RESID_XG, g, s));
+        } else {
+            HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
+        }
     }
 
     const int ln_blocks = ceil_div(M, 4);
     // Folded LayerNorms (EPI_RESID_XG): the residual GEMM that produces a row also writes gamma * x as the next GEMM's 16-bit
-    // operand and the row's partial sums; the consumer applies rstd / mean / beta in its epilogue.  The separate LayerNorm
-    // pass over the fp32 stream (HBM-bound, 24 per forward) remains only for the first norm1, whose input the patch GEMM wrote.
-    const bool fold = h->fold_ln;
-    const int sblocks = (D + 255) / 256;                 // partial (sum, sum of squares) pairs per row: one per 256-column tile
-    float* stat_p = fold ? h->stat_part.as<float>() + 2 * (size_t)sblocks * r0 : nullptr;
+    // operand and the row's partial sums; the consumer applies rstd / mean / beta in its epilogue.  No LayerNorm pass over the
+    // fp32 stream (HBM-bound, 24 per forward) remains: the first norm1 is prepared by the patch GEMM's epilogue.
     auto folded = [&](GemmArgs& ga, const float* u, const float* cvec) {
         ga.stat_in = stat_p; ga.stat_in_blocks = sblocks; ga.stat_in_stride = M; ga.ln_dim = D; ga.ln_eps = c.ln_eps;
         ga.col_u = u; ga.bias = cvec;
@@ -669,7 +674,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     };
     for (int li = 0; li < c.depth; ++li) {
         Layer& L = h->layers[li];
-        const bool ln1_folded = fold && li > 0;        // prepared by the previous layer's fc2 epilogue
+        const bool ln1_folded = fold;                  // prepared by the previous layer's fc2 epilogue (layer 0: by the patch GEMM's)
         if (!ln1_folded) HIPTS_TRY(layernorm(L.ln1_g.as<float>(), L.ln1_b.as<float>()));
         // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
         g = GemmArgs{};
