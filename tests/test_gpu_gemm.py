@@ -56,7 +56,9 @@ def test_gemm_default_dispatch_persistent_and_underfilled():
     goes to the two-per-CU kernel; (300, 272, 128) stays a plain one-tile-per-workgroup launch."""
     env = {k: v for k, v in os.environ.items() if k != "HIPTS_GEMM"}
     code = _CHILD % {"pkg": os.path.join(ROOT, "anime-illust-image-searcher_amd"),
-                     "shapes": [(70000, 768, 128), (11520, 512, 512), (300, 272, 128), (50000, 208, 64)]}
+                     "shapes": [(70000, 768, 128), (11520, 512, 512), (300, 272, 128), (50000, 208, 64),
+                                # odd and even K-tile counts on persistent grids (the two-K-tiles-ahead staging toggles its LDS stage per tile)
+                                (66000, 768, 192), (66000, 1024, 320), (40000, 768, 1536)]}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
