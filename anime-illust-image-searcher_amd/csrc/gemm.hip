@@ -37,7 +37,8 @@ constexpr int BM = 256, BN = 256, BK = 64;
 #define HIPTS_STAGE_AHEAD 1           // regions are restaged as soon as they are free, up to two K-tiles ahead (see the loop): one more phase
                                       // for every load.  Measured against 0 (one K-tile ahead): 8192^3 952 -> 1074 TFLOP/s (operands from HBM), the
                                       // isolated K = 768 shapes 2-4 % slower, but the forwards faster: ViT +2.2 % (4841 -> 4946 images/s, ABA
-                                      // runs on one box), EVA02-L +3 % at batch 32, CCIP +1.5 %
+                                      // runs on one box), EVA02-L +3 % at batch 32, CCIP +1.5 %.  (Moving W-high into the phase-3 group as well
+                                      // -- six loads in one phase, four phases for everything -- measured 1.5 % slower.)
 #endif
 #ifndef HIPTS_STAGE_W_EARLY
 #define HIPTS_STAGE_W_EARLY 0         // 1: W-high in phase 0 as well (3 phases to land instead of 2): 8192^3 943 -> 1074 TFLOP/s but K = 3072 / 4096 shapes 5 % slower
