@@ -367,7 +367,8 @@ int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u
         h->fold_dirty = false;
     }
     static const int want_streams = getenv("HIPTS_EVA_STREAMS") ? atoi(getenv("HIPTS_EVA_STREAMS")) : 2;
-    const int ns = std::min({want_streams, 2, batch / 8});
+    static const int min_sub = getenv("HIPTS_EVA_MINSUB") ? atoi(getenv("HIPTS_EVA_MINSUB")) : 5;      // images per sub-batch needed to split (the reference batch of 10 as two halves: 980 -> 1005 images/s)
+    const int ns = std::min({want_streams, 2, batch / (min_sub > 0 ? min_sub : 5)});
     if (ns >= 2) {
         // two sub-batches on two internal streams, as in the ViT forward (partial last rounds of the persistent GEMMs)
         if (!h->ev_fork) {

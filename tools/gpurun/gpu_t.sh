@@ -1,4 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
-timeout -k 10 900 python -m pytest tests/test_gpu_gemm.py -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 900 python -m pytest tests/test_gpu_eva.py -m gpu -x -q 2>&1 | tail -2
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
