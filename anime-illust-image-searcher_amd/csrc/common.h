@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/hip_tagsearch.h"
@@ -113,6 +114,17 @@ inline int upload(void* dst, const void* src, size_t bytes, hipStream_t s = null
     HIPTS_HIP(hipStreamSynchronize(s));
     return HIPTS_OK;
 }
+
+// Once-per-device initialisation (function attributes are a property of the device's copy of a kernel): usage
+//     static PerDevice once;  std::lock_guard<std::mutex> lk(once.mu);  if (!once.done(dev)) { ...; once.mark(dev); }
+struct PerDevice {
+    std::mutex mu;
+    uint64_t mask = 0;
+    bool done(int dev) const { return dev >= 0 && dev < 64 && ((mask >> dev) & 1); }
+    void mark(int dev) { if (dev >= 0 && dev < 64) mask |= (uint64_t)1 << dev; }
+};
+// Compute units of the CURRENT device (cached per device); 256 if the runtime does not say.
+int current_device_cus(int* dev_out = nullptr);
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -1,6 +1,9 @@
 // common.hip -- error state, device selection, misc ABI entry points.
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace hipts {
 
 std::string& last_error_ref() {
@@ -19,6 +22,17 @@ int set_error(int status, const char* fmt, ...) {
 }
 
 int use_device(int device) {
+    // The checks (device count, index, architecture) are made once per device and process; afterwards a call costs one
+    // hipSetDevice -- this sits on the path of every entry point, the single-query path included.
+    static std::mutex mu;
+    static std::vector<char> checked;         // 1 = validated gfx950 device
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (device >= 0 && device < (int)checked.size() && checked[device]) {
+            HIPTS_HIP(hipSetDevice(device));
+            return HIPTS_OK;
+        }
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -35,7 +49,27 @@ int use_device(int device) {
         return set_error(HIPTS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                          prop.gcnArchName);
     HIPTS_HIP(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if ((int)checked.size() < n) checked.resize(n, 0);
+        checked[device] = 1;
+    }
     return HIPTS_OK;
+}
+
+int current_device_cus(int* dev_out) {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev_out) *dev_out = dev;
+    std::lock_guard<std::mutex> lock(mu);
+    const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+    if (!cus[slot]) {
+        hipDeviceProp_t prop;
+        cus[slot] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[slot];
 }
 
 }  // namespace hipts
@@ -51,6 +85,16 @@ int hipts_last_error(char* buf, size_t n) {
     memcpy(buf, e.data(), m);
     buf[m] = 0;
     return HIPTS_OK;
+}
+
+int hipts_sizeof_config(int kind, size_t* bytes) {
+    if (!bytes) return HIPTS_ERR_INVALID;
+    switch (kind) {
+        case 0: *bytes = sizeof(hipts_vit_config_t); return HIPTS_OK;
+        case 1: *bytes = sizeof(hipts_eva_config_t); return HIPTS_OK;
+        case 2: *bytes = sizeof(hipts_ccip_config_t); return HIPTS_OK;
+        default: return hipts::set_error(HIPTS_ERR_INVALID, "hipts_sizeof_config: kind %d (0 vit, 1 eva, 2 ccip)", kind);
+    }
 }
 
 int hipts_device_count(int* count) {

@@ -1765,8 +1765,12 @@ int gemm_variant() {
 
 template <int EPI>
 int launch_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    int dev = 0;
+    const int cus_dev = current_device_cus(&dev);
+    static PerDevice attr;
+    {
+      std::lock_guard<std::mutex> lk(attr.mu);
+      if (!attr.done(dev)) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -1776,26 +1780,23 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_dw_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_dw_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS));
-        attr = true;
+        attr.mark(dev);
+      }
     }
     const int tiles_m = (a.M + BM - 1) / BM;
     if (a.op8) {
         // e4m3 operands: the persistent ping-pong loop with full tiles only
         if constexpr (EPI == EPI_STAR || EPI == EPI_RESID || EPI == EPI_RESCALE || EPI == EPI_RESID_LN || EPI == EPI_QK || EPI == EPI_VT ||
                       EPI == EPI_BIAS) {
-            static bool attr8 = false;
-            if (!attr8) {
-                HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-                attr8 = true;
+            static PerDevice attr8;
+            {
+                std::lock_guard<std::mutex> lk(attr8.mu);
+                if (!attr8.done(dev)) {
+                    HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                    attr8.mark(dev);
+                }
             }
-            static int cus8 = 0;
-            if (!cus8) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                HIPTS_HIP(hipGetDevice(&dev));
-                HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
-                cus8 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            }
+            const int cus8 = cus_dev;
             const int tiles_n = (a.N + BN - 1) / BN;
             const int ntile = tiles_m * tiles_n;
             const int slots = cus8 >= 8 ? cus8 / 8 * 8 : cus8;
@@ -1813,14 +1814,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         // A launch with fewer 256 x 256 tiles than CUs (the CAFormer's late stages: 11 520 tokens x 512 columns
         // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
-        static int cus0 = 0;
-        if (!cus0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            HIPTS_HIP(hipGetDevice(&dev));
-            HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
-            cus0 = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
+        const int cus0 = cus_dev;
         if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && a.stat_part)) variant = 4;
     }
     HIPTS_REQUIRE(!a.f16 || variant == 1 || variant == 4, "half-precision operands are only built for the pp and dw GEMM loops");
@@ -1846,14 +1840,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         }
         else if (variant == 1) {
             // 256- or 224-row tiles, whichever needs fewer (size-weighted) rounds over the CUs
-            static int cus = 0;
-            if (!cus) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                HIPTS_HIP(hipGetDevice(&dev));
-                HIPTS_HIP(hipGetDeviceProperties(&prop, dev));
-                cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            }
+            const int cus = cus_dev;
             static const bool allow224 = !(getenv("HIPTS_GEMM_BM") && strcmp(getenv("HIPTS_GEMM_BM"), "256") == 0);
             const int tiles_m7 = (a.M + 223) / 224;
             const long r8 = ((long)tiles_m * tiles_n + cus - 1) / cus * 256;

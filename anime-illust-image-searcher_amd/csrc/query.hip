@@ -38,6 +38,15 @@ struct hipts_bm25 {
     DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
     DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out;
     PinBuf pin_in, pin_out;                    // hipts_search: one H2D of the packed queries, one D2H of the packed results
+    DevBuf s1_state, s1_cand;                  // one-query path: Search1State; candidate keys u64[CAP] then ids u32[CAP]
+    bool s1_dirty = true;                      // s1_state may hold leftovers (first use, or a call that failed half way)
+    // per-kernel HIP-event timing (hipts_query_profile_*): events on the stream each kernel is launched on
+    bool prof = false;
+    struct ProfRec { int cat; hipEvent_t a, b; double bytes; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[HIPTS_QUERY_PROF_CATEGORIES] = {0}, prof_bytes[HIPTS_QUERY_PROF_CATEGORIES] = {0};
+    int64_t prof_n[HIPTS_QUERY_PROF_CATEGORIES] = {0};
 };
 
 namespace {
@@ -377,8 +386,14 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool active
 constexpr int TOPK_U = 16;
 constexpr int TOPK_SORT_TARGET = 256;
 
+struct Search1State;
+__device__ void search1_state_clear(Search1State* st);
+__device__ uint32_t search1_state_count(const Search1State* st);
+
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
-                                                    int32_t* __restrict__ ids_out, double* __restrict__ vals_out) {
+                                                    int32_t* __restrict__ ids_out, double* __restrict__ vals_out,
+                                                    Search1State* __restrict__ pre = nullptr, const unsigned long long* __restrict__ pre_key = nullptr,
+                                                    const uint32_t* __restrict__ pre_id = nullptr) {
     __shared__ uint32_t hist[4096];
     __shared__ uint64_t ckey[TOPK_CAP];
     __shared__ uint32_t cid[TOPK_CAP];
@@ -395,7 +410,22 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     // the score, so the collected set is exactly "all scores >= a pivot": if it has at least k and at most CAP
     // members it contains the top k and the sort below finishes the job; otherwise the exact path runs.
     bool done_fast = false;
-    if (n >= 8192) {
+    if (pre) {
+        // candidates collected by search1_collect_kernel: every score whose digit is at or above a threshold digit, i.e. all
+        // scores >= a pivot; with at least k and at most CAP of them the top k are among them
+        const int c = (int)search1_state_count(pre);
+        done_fast = c >= k && c <= TOPK_CAP;
+        if (done_fast) {
+            for (int i = tid; i < c; i += 1024) {
+                ckey[i] = pre_key[i];
+                cid[i] = pre_id[i];
+            }
+            if (tid == 0) sh_cnt = c;
+        }
+        __syncthreads();
+        search1_state_clear(pre);               // all zero again for the next query (every read of it is behind the barrier above)
+    }
+    if (!done_fast && n >= 8192) {
         for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
@@ -593,6 +623,25 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     }
     }
     const int cnt = sh_cnt;
+    if (cnt <= 640) {
+        // few candidates: rank by counting -- rank(i) = #{j : j before i in (key desc, id asc)} -- no barriers, LDS broadcasts
+        __syncthreads();
+        if (tid < cnt) {
+            const uint64_t ki = ckey[tid];
+            const uint32_t ii = cid[tid];
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const uint64_t kj = ckey[j];
+                const uint32_t ij = cid[j];
+                rank += (kj > ki || (kj == ki && ij < ii)) ? 1 : 0;
+            }
+            if (rank < k) {
+                ids_out[(int64_t)blockIdx.x * k + rank] = (int32_t)ii;
+                vals_out[(int64_t)blockIdx.x * k + rank] = key_value(ki);
+            }
+        }
+        return;
+    }
     int np2 = 64;
     while (np2 < cnt) np2 <<= 1;
     for (int i = cnt + tid; i < np2; i += 1024) {
@@ -624,6 +673,222 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     }
 }
 
+// =============================================================================================
+// One query at a time -- the reference's real call (webui.py:586: find_similar_documents(query, topn=800)).
+// The batched kernels above give one workgroup to a query for BM25, the row maxima and the top-k: at nq = 1 that is
+// one CU of 256 busy for ~120 of the ~170 us a query took.  Here every step runs over the whole chip, thread per
+// document, and the query itself travels in the kernel arguments (no staging copy):
+//   search1_score    BM25 in the reference's own shape (webui.py:139-170: for each query term a pass over the documents,
+//                    here the document's own (term, tf) list, document-major CSR) + the index product as the k-ordered
+//                    fmaf chain (bit-equal to the exact-f32 MFMA chain of sim_mfma_kernel and to the oracle) from the
+//                    tile-major copy; per-workgroup maxima into 64 slots
+//   search1_combine  webui.py:377-383 with the global maxima; histogram of a 1/8 sample over the value-uniform digit
+//   search1_collect  threshold digit from the sample, candidates (score digit >= threshold) into one buffer
+//   topk_kernel      takes the candidates (sort, or rank by counting when few); if the sample misjudged (fewer than k or
+//                    more than the buffer) the exact radix select runs instead -- same kernel, same results
+// Algorithmic bytes per query: D * dim * 4 (index) + nnz * 8 + D * 12 (CSR) + D * (8 + 4) * 2 + D * 8 * 2 (scores, final).
+// =============================================================================================
+constexpr int S1_MAX_TERMS = 16;
+constexpr int S1_MAX_DIM = 768;
+constexpr int S1_THREADS = 128;
+constexpr int S1_SLOTS = 64;
+constexpr int S1_MIN_DOCS = 8192;
+
+struct Search1Query {            // passed by value: 3.3 KB of the 4 KB kernel-argument segment
+    int32_t nt, n_required, masking, dim;
+    int32_t terms[S1_MAX_TERMS];
+    double weights[S1_MAX_TERMS];
+    float q[S1_MAX_DIM];
+};
+
+struct Search1State {            // device resident, all zero between queries (the last kernel of a query clears it)
+    uint32_t hist[4096];
+    unsigned long long max_a[S1_SLOTS];      // order_key images of the per-workgroup BM25 maxima
+    uint32_t max_b[S1_SLOTS];                // float_order_key images of the index-product maxima
+    uint32_t cnt;                            // candidates collected
+    uint32_t pad[3];
+};
+
+__device__ void search1_state_clear(Search1State* st) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(st);
+    for (int i = threadIdx.x; i < (int)(sizeof(Search1State) / 4); i += blockDim.x) w[i] = 0;
+}
+__device__ uint32_t search1_state_count(const Search1State* st) { return st->cnt; }
+
+__global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1Query Q, const float4* __restrict__ tiled, int64_t D,
+                                                                   const int64_t* __restrict__ ptr, const int32_t* __restrict__ term,
+                                                                   const int32_t* __restrict__ tf, const int32_t* __restrict__ dl,
+                                                                   const double* __restrict__ idf, int32_t V, double avgdl,
+                                                                   double* __restrict__ bm_out, float* __restrict__ sim_out,
+                                                                   Search1State* __restrict__ st) {
+    const int tid = threadIdx.x;
+    const int64_t d = (int64_t)blockIdx.x * S1_THREADS + tid;
+    const bool valid = d < D;
+    const int64_t dd = valid ? d : D - 1;
+    // ---- index product: acc = fmaf(row[k], q[k], acc), k ascending (the order of sim_mfma_kernel's chain and of the oracle)
+    const int KQ = Q.dim >> 2;
+    const float4* __restrict__ p = tiled + ((dd >> 5) * KQ) * 32 + (dd & 31);
+    float acc = 0.0f;
+    int kq = 0;
+    constexpr int U = 15;        // 15 x 16 B per lane in flight (dim 300 = 5 x 15 float4)
+    for (; kq + U <= KQ; kq += U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[(int64_t)(kq + u) * 32];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* qq = Q.q + 4 * (kq + u);
+            acc = fmaf(v[u].x, qq[0], acc);
+            acc = fmaf(v[u].y, qq[1], acc);
+            acc = fmaf(v[u].z, qq[2], acc);
+            acc = fmaf(v[u].w, qq[3], acc);
+        }
+    }
+    for (; kq < KQ; ++kq) {
+        const float4 v = p[(int64_t)kq * 32];
+        const float* qq = Q.q + 4 * kq;
+        acc = fmaf(v.x, qq[0], acc);
+        acc = fmaf(v.y, qq[1], acc);
+        acc = fmaf(v.z, qq[2], acc);
+        acc = fmaf(v.w, qq[3], acc);
+    }
+    // ---- BM25 (webui.py:139-170), the arithmetic of bm25_score_kernel
+    const int64_t b = ptr[dd], e = ptr[dd + 1];
+    const double dlv = (double)dl[dd];
+    const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv / avgdl));
+    double s = 0.0;
+    bool masked = false;
+    for (int j = 0; j < Q.nt; ++j) {
+        const int32_t t = Q.terms[j];
+        const double w = Q.weights[j];
+        int32_t tfv = 0;
+        for (int64_t i = b; i < e; ++i)
+            if (term[i] == t) tfv = tf[i];
+        const double idf_t = (t >= 0 && t < V) ? idf[t] : 0.0;
+        const double tfd = (double)tfv;
+        const double sc = idf_t * ((tfd * (BM25_K1 + 1.0)) / (tfd + nrm));
+        if (w < 0.0) {
+            if (tfv > 0) masked = true;
+        } else if (w > REQUIRE_MAGIC) {
+            s += (w - REQUIRE_MAGIC) * sc;
+            if (tfv == 0) masked = true;
+        } else {
+            s += w * sc;
+        }
+    }
+    if (masked) s = -INFINITY;
+    if (valid) {
+        bm_out[d] = s;
+        sim_out[d] = acc;
+    }
+    // ---- per-workgroup maxima -> one of 64 slots (atomicMax on order-preserving images; 0 is below every value)
+    double ma = valid ? s : -INFINITY;
+    float mb = valid ? acc : -INFINITY;
+    for (int o = 32; o >= 1; o >>= 1) {
+        ma = fmax(ma, __shfl_xor(ma, o));
+        mb = fmaxf(mb, __shfl_xor(mb, o));
+    }
+    __shared__ double pa[S1_THREADS / 64];
+    __shared__ float pb[S1_THREADS / 64];
+    if ((tid & 63) == 0) {
+        pa[tid >> 6] = ma;
+        pb[tid >> 6] = mb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < S1_THREADS / 64; ++w) {
+            ma = fmax(ma, pa[w]);
+            mb = fmaxf(mb, pb[w]);
+        }
+        atomicMax(&st->max_a[blockIdx.x % S1_SLOTS], (unsigned long long)order_key(ma));
+        atomicMax(&st->max_b[blockIdx.x % S1_SLOTS], float_order_key(mb));
+    }
+}
+
+__device__ __forceinline__ void search1_maxima(const Search1State* __restrict__ st, double* ma, float* mb) {
+    // every workgroup folds the 64 slots itself (1 KB from L2)
+    const int lane = threadIdx.x & 63;
+    unsigned long long ka = st->max_a[lane];
+    uint32_t kb = st->max_b[lane];
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long oa = __shfl_xor(ka, o);
+        const uint32_t ob = __shfl_xor(kb, o);
+        ka = oa > ka ? oa : ka;
+        kb = ob > kb ? ob : kb;
+    }
+    *ma = ka ? key_value(ka) : -INFINITY;
+    *mb = kb ? float_from_key(kb) : -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void search1_combine_kernel(const double* __restrict__ bm, const float* __restrict__ sim, int64_t D, double wa,
+                                                              float wb, double* __restrict__ final_out, Search1State* __restrict__ st) {
+    double ma;
+    float mb;
+    search1_maxima(st, &ma, &mb);
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    double A = bm[d];
+    float B = sim[d];
+    if (ma > 0.0) A = A / ma;                    // webui.py:379-380
+    if (mb > 0.0f) B = B / mb;                   // webui.py:377-378
+    const float wB = wb * B;
+    const double f = wa * A + (double)wB;        // webui.py:383
+    final_out[d] = f;
+    if ((d & 7) == 0) atomicAdd(&st->hist[value_digit(f)], 1u);       // the 1/8 sample
+}
+
+__global__ __launch_bounds__(256) void search1_collect_kernel(const double* __restrict__ final_in, int64_t D, int k, Search1State* __restrict__ st,
+                                                              unsigned long long* __restrict__ cand_key, uint32_t* __restrict__ cand_id) {
+    __shared__ int scan[5];
+    __shared__ int sh_dmin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // threshold digit: walking down from the top bin, the first digit at which the sample holds `want` entries
+    const int want = k / 8 + 3 * (int)ceilf(sqrtf((float)k / 8.0f)) + 4;
+    int own[16], ssum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        own[j] = (int)st->hist[4095 - (16 * tid + j)];
+        ssum += own[j];
+    }
+    int incl = ssum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) scan[wave] = incl;
+    if (tid == 0) sh_dmin = 0;                   // fewer sampled entries than `want`: everything is a candidate (-> exact path)
+    __syncthreads();
+    int excl = incl - ssum;
+    for (int w = 0; w < wave; ++w) excl += scan[w];
+    if (excl < want && want <= excl + ssum) {
+        int run = excl;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (run < want && want <= run + own[j]) sh_dmin = 4095 - (16 * tid + j);
+            run += own[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t dmin = (uint32_t)sh_dmin;
+    const int64_t d = (int64_t)blockIdx.x * 256 + tid;
+    const double f = d < D ? final_in[d] : 0.0;
+    const bool take = d < D && value_digit(f) >= dmin;
+    const uint64_t m = __ballot(take);
+    if (m == 0) return;
+    uint32_t base = 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&st->cnt, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (take) {
+        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (slot < (uint32_t)TOPK_CAP) {
+            cand_key[slot] = order_key(f);
+            cand_id[slot] = (uint32_t)d;
+        }
+    }
+}
+
 // Handle-less entry points (hipts_combine / hipts_topk) keep their small scratch here: one slot
 // per (device, purpose), intentionally never freed (freeing at static-destruction time would
 // race the HIP runtime's own teardown).  Callers are single-threaded per device by contract.
@@ -642,6 +907,41 @@ int copy_out(void* dst, const void* src_dev, size_t bytes, int memspace, hipStre
     }
     return HIPTS_OK;
 }
+
+enum QueryProfCat { QP_BM25 = 0, QP_SIM, QP_ROWMAX, QP_COMBINE, QP_TOPK, QP_S1_SCORE, QP_S1_COMBINE, QP_S1_COLLECT, QP_S1_TOPK, QP_COUNT };
+static_assert(QP_COUNT == HIPTS_QUERY_PROF_CATEGORIES, "category count");
+const char* const kQueryProfNames[QP_COUNT] = {"bm25_postings_kernel", "sim_mfma_kernel", "rowmax_kernel<float>", "combine_kernel", "topk_kernel",
+                                               "search1_score_kernel", "search1_combine_kernel", "search1_collect_kernel", "topk_kernel<candidates>"};
+
+struct QueryProfScope {
+    hipts_bm25* h;
+    hipStream_t s;
+    hipts_bm25::ProfRec r{};
+    bool on;
+    QueryProfScope(hipts_bm25* h_, hipStream_t s_, int cat, double bytes) : h(h_), s(s_), on(h_ && h_->prof) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!h->prof_pool.empty()) {
+                e = h->prof_pool.back();
+                h->prof_pool.pop_back();
+            } else if (hipEventCreate(&e) != hipSuccess) {
+                e = nullptr;
+            }
+            return e;
+        };
+        r.cat = cat;
+        r.bytes = bytes;
+        r.a = get();
+        r.b = get();
+        if (r.a) (void)hipEventRecord(r.a, s);
+    }
+    ~QueryProfScope() {
+        if (!on) return;
+        if (r.b) (void)hipEventRecord(r.b, s);
+        h->prof_recs.push_back(r);
+    }
+};
 
 }  // namespace
 
@@ -663,11 +963,16 @@ int launch_sim(const float* index, const float* tiled, int64_t D, int K, const f
                hipStream_t s) {
     const size_t lds = (size_t)K * 32 * sizeof(float);
     HIPTS_REQUIRE(lds <= 160 * 1024, "index dim %d too large for the query tile in LDS", K);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static PerDevice attr_set;
+    {
+        int dev = 0;
+        HIPTS_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(attr_set.mu);
+        if (!attr_set.done(dev)) {
+            HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)sim_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set.mark(dev);
+        }
     }
     static const bool use_tiled = !(getenv("HIPTS_SIM") && strcmp(getenv("HIPTS_SIM"), "rows") == 0);
     const int64_t ntiles = (D + 31) / 32;
@@ -727,9 +1032,119 @@ int stage_queries(hipts_bm25* h, const int32_t* q_terms, const double* q_weights
     return HIPTS_OK;
 }
 
+// hipts_search for ONE query (webui.py:345-383 + the ranking of :191-192): four launches, no staging copy, results written by the
+// last kernel straight into pinned host memory, one synchronisation.
+int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, const double* q_weights, int nt, const float* q_vector,
+               double w_bm25, double w_sim, int k, int32_t* ids_out, double* vals_out, double* final_out_device, hipStream_t s) {
+    const int64_t D = bm25->D;
+    Search1Query Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.nt = nt;
+    Q.dim = index->dim;
+    for (int j = 0; j < nt; ++j) {
+        Q.terms[j] = q_terms[j];
+        Q.weights[j] = q_weights[j];
+    }
+    memcpy(Q.q, q_vector, (size_t)index->dim * 4);
+    HIPTS_TRY(bm25->ws_scores.reserve((size_t)D * 8));
+    HIPTS_TRY(bm25->ws_sims.reserve((size_t)D * 4));
+    double* final_dev = final_out_device;
+    if (!final_dev) {
+        HIPTS_TRY(bm25->ws_final.reserve((size_t)D * 8));
+        final_dev = bm25->ws_final.as<double>();
+    }
+    if (!bm25->s1_state.p) {
+        HIPTS_TRY(bm25->s1_state.alloc(sizeof(Search1State)));
+        HIPTS_TRY(bm25->s1_cand.alloc((size_t)TOPK_CAP * 12));
+        bm25->s1_dirty = true;
+    }
+    Search1State* st = bm25->s1_state.as<Search1State>();
+    if (bm25->s1_dirty) HIPTS_HIP(hipMemsetAsync(st, 0, sizeof(Search1State), s));
+    bm25->s1_dirty = true;                    // until the last kernel (which clears the state) has been enqueued
+    unsigned long long* ckey = bm25->s1_cand.as<unsigned long long>();
+    uint32_t* cid = reinterpret_cast<uint32_t*>(ckey + TOPK_CAP);
+    const int kk = (int)std::min<int64_t>(k, D);
+    const size_t out_bytes = (size_t)kk * 12;
+    HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 64));
+    double* hv = bm25->pin_out.as<double>();                  // pinned + mapped: the last kernel stores the results here
+    int32_t* hi = reinterpret_cast<int32_t*>(hv + kk);
+    {
+        QueryProfScope ps(bm25, s, QP_S1_SCORE, (double)D * index->dim * 4.0 + (double)bm25->nnz * 8.0 + (double)D * (8 + 4 + 8 + 4));
+        search1_score_kernel<<<ceil_div(D, S1_THREADS), S1_THREADS, 0, s>>>(Q, index->tiled.as<float4>(), D, bm25->d_ptr.as<int64_t>(),
+                                                                            bm25->d_term.as<int32_t>(), bm25->d_tf.as<int32_t>(),
+                                                                            bm25->d_dl.as<int32_t>(), bm25->d_idf.as<double>(), bm25->V, bm25->avgdl,
+                                                                            bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), st);
+        HIPTS_LAUNCH_CHECK();
+    }
+    {
+        QueryProfScope ps(bm25, s, QP_S1_COMBINE, (double)D * 20.0);
+        search1_combine_kernel<<<ceil_div(D, 256), 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim,
+                                                                final_dev, st);
+        HIPTS_LAUNCH_CHECK();
+    }
+    {
+        QueryProfScope ps(bm25, s, QP_S1_COLLECT, (double)D * 8.0);
+        search1_collect_kernel<<<ceil_div(D, 256), 256, 0, s>>>(final_dev, D, kk, st, ckey, cid);
+        HIPTS_LAUNCH_CHECK();
+    }
+    {
+        QueryProfScope ps(bm25, s, QP_S1_TOPK, (double)kk * 24.0);
+        topk_kernel<<<1, 1024, 0, s>>>(final_dev, D, kk, hi, hv, st, ckey, cid);
+        HIPTS_LAUNCH_CHECK();
+    }
+    bm25->s1_dirty = false;
+    HIPTS_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < k; ++i) {
+        ids_out[i] = i < kk ? hi[i] : -1;
+        vals_out[i] = i < kk ? hv[i] : -INFINITY;
+    }
+    return HIPTS_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int hipts_query_profile_enable(hipts_bm25_t* h, int enable) {
+    HIPTS_REQUIRE(h, "null handle");
+    h->prof = enable != 0;
+    if (enable) {
+        for (int c = 0; c < QP_COUNT; ++c) {
+            h->prof_ms[c] = 0.0;
+            h->prof_bytes[c] = 0.0;
+            h->prof_n[c] = 0;
+        }
+    }
+    return HIPTS_OK;
+}
+
+int hipts_query_profile_read(hipts_bm25_t* h, int category, double* total_ms, int64_t* launches, double* total_bytes) {
+    HIPTS_REQUIRE(h && category >= 0 && category < QP_COUNT, "hipts_query_profile_read: bad arguments");
+    HIPTS_TRY(use_device(h->device));
+    for (auto& r : h->prof_recs) {
+        if (r.a && r.b) {
+            HIPTS_HIP(hipEventSynchronize(r.b));
+            float ms = 0.f;
+            HIPTS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+            h->prof_ms[r.cat] += ms;
+            h->prof_n[r.cat] += 1;
+            h->prof_bytes[r.cat] += r.bytes;
+        }
+        if (r.a) h->prof_pool.push_back(r.a);
+        if (r.b) h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+    if (total_ms) *total_ms = h->prof_ms[category];
+    if (launches) *launches = h->prof_n[category];
+    if (total_bytes) *total_bytes = h->prof_bytes[category];
+    return HIPTS_OK;
+}
+
+int hipts_query_profile_name(int category, char* buf, size_t n) {
+    HIPTS_REQUIRE(buf && n > 0 && category >= 0 && category < QP_COUNT, "hipts_query_profile_name: bad arguments");
+    snprintf(buf, n, "%s", kQueryProfNames[category]);
+    return HIPTS_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 int hipts_bm25_build(const int64_t* doc_ptr, const int32_t* term_ids, int64_t num_docs, int32_t vocab, int device,
@@ -943,6 +1358,16 @@ int hipts_index_vector_by_id(const hipts_index_t* h, int64_t id, float* out_host
     return HIPTS_OK;
 }
 
+int hipts_index_export(const hipts_index_t* h, int64_t first, int64_t nrows, float* out_host) {
+    HIPTS_REQUIRE(h && first >= 0 && nrows >= 0 && first + nrows <= h->len, "hipts_index_export: rows [%lld, %lld) out of range (len %lld)",
+                  (long long)first, (long long)(first + nrows), (long long)h->len);
+    if (nrows == 0) return HIPTS_OK;
+    HIPTS_REQUIRE(out_host, "hipts_index_export: null output");
+    HIPTS_TRY(use_device(h->device));
+    HIPTS_HIP(hipMemcpy(out_host, h->rows.as<float>() + first * h->dim, (size_t)nrows * h->dim * 4, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}
+
 int hipts_index_data(const hipts_index_t* h, void** device_ptr) {
     HIPTS_REQUIRE(h && device_ptr, "null argument");
     *device_ptr = h->rows.p;
@@ -1063,10 +1488,14 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     HIPTS_TRY(use_device(bm25->device));
     hipStream_t s = (hipStream_t)stream;
     const int64_t D = bm25->D;
-    // queries, weights, offsets and the query vectors travel as ONE packed copy from pinned memory (no bounce buffer, no
-    // synchronisation before the kernels); the results come back the same way
+    HIPTS_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "hipts_search: k must be in [1, %d]", TOPK_MAX_K);
     const int nt = q_ptr[nq];
     HIPTS_REQUIRE(q_ptr[0] == 0 && nt >= 0, "q_ptr must start at 0 and be non-decreasing");
+    static const bool allow_one = !(getenv("HIPTS_SEARCH1") && strcmp(getenv("HIPTS_SEARCH1"), "0") == 0);       // A/B switch
+    if (nq == 1 && allow_one && nt <= S1_MAX_TERMS && index->dim <= S1_MAX_DIM && index->dim % 4 == 0 && index->tiled.p && D >= S1_MIN_DOCS)
+        return search_one(bm25, index, q_terms, q_weights, nt, q_vectors, w_bm25, w_sim, k, ids_out, vals_out, final_out_device, s);
+    // queries, weights, offsets and the query vectors travel as ONE packed copy from pinned memory (no bounce buffer, no
+    // synchronisation before the kernels); the results come back the same way
     const size_t off_w = ((size_t)nt * 4 + 15) / 16 * 16;
     const size_t off_p = off_w + (size_t)nt * 8;
     const size_t off_v = (off_p + (size_t)(nq + 1) * 4 + 15) / 16 * 16;
@@ -1098,25 +1527,42 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     HIPTS_TRY(bm25->ws_max.reserve((size_t)nq * 16));
     double* ma = bm25->ws_max.as<double>();
     float* mb = reinterpret_cast<float*>(ma + nq);
-    HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
-    HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s));
-    rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
-    HIPTS_LAUNCH_CHECK();
     {
+        // algorithmic bytes: the posting lists of the queries' terms (8 B per entry + the document length gathered with it) and the
+        // three passes over each query's score row (clear, mask / maximum) -- DESIGN.md section 4
+        double pb = 0.0;
+        for (int j = 0; j < nt; ++j)
+            if (q_terms[j] >= 0 && q_terms[j] < bm25->V) pb += (double)bm25->h_df[q_terms[j]] * 12.0;
+        QueryProfScope ps(bm25, s, QP_BM25, pb + (double)nq * D * 8.0 * 3);
+        HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
+    }
+    {
+        QueryProfScope ps(bm25, s, QP_SIM, (double)((nq + 31) / 32) * D * index->dim * 4.0 + (double)nq * D * 4.0);
+        HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s));
+    }
+    {
+        QueryProfScope ps(bm25, s, QP_ROWMAX, (double)nq * D * 4.0);
+        rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
+        HIPTS_LAUNCH_CHECK();
+    }
+    {
+        QueryProfScope ps(bm25, s, QP_COMBINE, (double)nq * D * 20.0);
         dim3 grid(ceil_div(D, 256), nq);
         combine_kernel<<<grid, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, ma,
                                             mb, nullptr, final_dev);
         HIPTS_LAUNCH_CHECK();
     }
-    HIPTS_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "hipts_search: k must be in [1, %d]", TOPK_MAX_K);
     const int kk = (int)std::min<int64_t>(k, D);
     const size_t out_bytes = (size_t)nq * kk * 12;
     HIPTS_TRY(bm25->ws_out.reserve(out_bytes + 64));
     HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 64));
     double* ov = bm25->ws_out.as<double>();
     int32_t* oi = reinterpret_cast<int32_t*>(ov + (size_t)nq * kk);
-    topk_kernel<<<nq, 1024, 0, s>>>(final_dev, D, kk, oi, ov);
-    HIPTS_LAUNCH_CHECK();
+    {
+        QueryProfScope ps(bm25, s, QP_TOPK, (double)nq * D * 8.0);
+        topk_kernel<<<nq, 1024, 0, s>>>(final_dev, D, kk, oi, ov);
+        HIPTS_LAUNCH_CHECK();
+    }
     HIPTS_HIP(hipMemcpyAsync(bm25->pin_out.p, ov, out_bytes, hipMemcpyDeviceToHost, s));
     HIPTS_HIP(hipStreamSynchronize(s));
     const double* hv = bm25->pin_out.as<double>();

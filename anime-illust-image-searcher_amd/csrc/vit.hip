@@ -9,6 +9,7 @@
 // The residual stream, LN statistics, softmax and every accumulation are float32; only MFMA
 // operands are bf16.
 #include <algorithm>
+#include "../../include/hip_tagsearch_debug.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -69,6 +70,7 @@ struct hipts_vit {
     int want_sub = 0;                             // hipts_vit_set_sub_batches; 0 = default
     bool deferred_join = false;                   // hipts_vit_set_deferred_join
     int last_ns = 0;                              // sub-batch streams the last forward used (0: none to join)
+    int pend_ns = 0, pend_batch = 0;              // an UNJOINED forward (deferred join) of pend_batch images on pend_ns streams may still run
     hipStream_t sub[kMaxSub] = {};                // internal streams of the sub-batches
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
 };
@@ -763,6 +765,17 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     const auto& c = h->cfg;
     const int S = c.image_size;
 
+    // Two half-batches on two internal streams: a GEMM grid's partial last round, an epilogue that is
+    // waiting on HBM and every kernel boundary of one half are filled with work of the other half.
+    static const int want_streams = getenv("HIPTS_VIT_STREAMS") ? atoi(getenv("HIPTS_VIT_STREAMS")) : 2;
+    const int ns = std::min({h->want_sub > 0 ? h->want_sub : want_streams, (int)hipts_vit::kMaxSub, batch / 8});
+    // Workspaces are carved by image offset, not by sub-batch stream.  A previous forward left unjoined (deferred join) is
+    // ordered against this one only stream by stream, which is enough exactly when sub-batch i covers the same images as
+    // before and nothing is staged through the shared input buffer; otherwise this call waits for all of it first.
+    if (h->pend_ns > 0 && (h->pend_ns != ns || h->pend_batch != batch || in_memspace != HIPTS_DEVICE))
+        for (int i = 0; i < h->pend_ns; ++i) HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+    h->pend_ns = 0;
+
     const void* in_dev = input;
     if (in_memspace != HIPTS_DEVICE) {
         const size_t bytes = (size_t)batch * S * S * 3 * (is_u8 ? 1 : 4);
@@ -784,10 +797,6 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         h->fold_dirty = false;
     }
 
-    // Two half-batches on two internal streams: a GEMM grid's partial last round, an epilogue that is
-    // waiting on HBM and every kernel boundary of one half are filled with work of the other half.
-    static const int want_streams = getenv("HIPTS_VIT_STREAMS") ? atoi(getenv("HIPTS_VIT_STREAMS")) : 2;
-    const int ns = std::min({h->want_sub > 0 ? h->want_sub : want_streams, (int)hipts_vit::kMaxSub, batch / 8});
     if (ns >= 2) {
         if (!h->ev_fork) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < ns; ++i)
@@ -804,6 +813,8 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
             if (!h->deferred_join || !dev_out) HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
         h->last_ns = (h->deferred_join && dev_out) ? ns : 0;
+        h->pend_ns = h->last_ns;
+        h->pend_batch = batch;
     } else {
         HIPTS_TRY(vit_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s, false));
         h->last_ns = 0;
@@ -975,7 +986,6 @@ int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int ba
 // ---------------------------------------------------------------------------------------------
 static float g_last_loop_ghz = 0.f;     // hiptsdbg_gemm_clock: shader clock during the main loop of the last stamped launch
 
-extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out);
 
 // Diagnostic (bench.py): the shader clock the chip sustains inside the GEMM main loop -- cycle counter against the 100 MHz
 // wall clock between the loop's first and last barrier, one workgroup's stamps of the last of `iters` back-to-back launches.

@@ -5,17 +5,25 @@ Builds the character-feature index: every image under D is resized to 384x384 (b
 normalised on 8 host threads (gen_cfeatures.py:100-110,285-295), encoded in batches by the device CCIP
 encoder (hiptagsearch.cfeatures.CCIPEncoder, replacing the onnxruntime session of :112-118,158), the
 path is appended to charactor-featues-idx.csv (:376) and the unit-normalised feature row to the device
-index `charactor-featues-idx` (:307-315), saved at the end (:459).  With --after, only files modified on
-or after the date are encoded and appended to the existing index (the reference copies the old index into
-a new revision first, :340-368; here the index file is loaded and extended in place, a .bak copy is kept).
+index `charactor-featues-idx` (:307-315), saved at the end (:459).
+
+--after (gen_cfeatures.py:340-370): every `charactor-featues-idx*` file is first copied into a directory named
+YYYYmmdd_HHMMSS, the latest revision N (`charactor-featues-idx` = 0, `charactor-featues-idxN`) is loaded and copied into
+the new revision `charactor-featues-idx<N+1>` (in one block here, vector by vector in the reference), the
+new features are appended and THAT revision is saved; the query side loads the highest revision (webui.py:272-277,
+cfeatures.CharacterFeatureIndex.load_latest).  The paths csv is shared by all revisions and appended in place.
+
+Multi-GPU (one process per GPU): under
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P gen_cfeatures.py --dir D
+rank r encodes a contiguous block of the file list, ONE all-gather of the float32[768] rows puts them in file order,
+rank 0 owns the index and the csv: the files written are those of the single-process run.
 
 Extra switches: --checkpoint ccip.safetensors (timm MetaFormer key layout; without it the seeded synthetic
-stand-in is used -- there is no network here to fetch deepghs/ccip_onnx), --batch, --device."""
+stand-in is used -- there is no network here to fetch deepghs/ccip_onnx), --batch, --device, --arch tiny (test geometry)."""
 import argparse
 import concurrent.futures
 import datetime
 import os
-import shutil
 import sys
 import time
 
@@ -35,6 +43,23 @@ def list_files_recursive(dir_path: str):
     return out
 
 
+def encode_files(file_list, batch, cindex_encode, on_batch, size=384):
+    """The decode-ahead loop of gen_cfeatures.py:386-424: 8 threads prepare batch i+1 while the device encodes batch i.
+    on_batch(paths_kept, features) is called per batch; failed loads are skipped (:392-395)."""
+    import functools
+    from hiptagsearch import cfeatures
+    gen_image_ndarray = functools.partial(cfeatures.gen_image_ndarray, size=size)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as pool:
+        nxt = pool.map(gen_image_ndarray, file_list[:batch])
+        for s in range(0, len(file_list), batch):
+            arrs = list(nxt)
+            if s + batch < len(file_list):
+                nxt = pool.map(gen_image_ndarray, file_list[s + batch: s + 2 * batch])
+            keep = [(s + j, a) for j, a in enumerate(arrs) if a is not None]
+            if keep:
+                on_batch([i for i, _ in keep], cindex_encode([a for _, a in keep]))
+
+
 def main(arg_str: list) -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument('--dir', nargs=1, required=True, help='tagging target directory path')
@@ -46,6 +71,7 @@ def main(arg_str: list) -> None:
                         help='decode / resize in this many processes (hiptagsearch/pipeline.py); the uint8 images go to the device u8 entry point')
     parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='bf16',
                         help='MFMA operand type of the encoder GEMMs (e4m3 = the fp8 mode: faster, 3 mantissa bits)')
+    parser.add_argument('--arch', choices=['b36', 'tiny'], default='b36', help='b36: CAFormer-B36 widths @384 (the CCIP encoder); tiny: test geometry')
     args = parser.parse_args(arg_str)
     after_date = None
     if args.after is not None:
@@ -56,64 +82,100 @@ def main(arg_str: list) -> None:
             print('Invalid date format. format is YYYY-MM-DD')
             raise SystemExit(1)
 
+    from hiptagsearch import dist as hdist
+    dist, rank, world, device = hdist.init_from_env(args.device)          # before any GPU call
     import numpy as np
     from hiptagsearch import synth
-    from hiptagsearch.cfeatures import CCIPEncoder, CharacterFeatureIndex, gen_image_ndarray
+    from hiptagsearch import cfeatures as cf
     from hiptagsearch.index import Similarity
-    cfg = dict(synth.CCIP_B36_384, operand_f16={'bf16': 0, 'half': 1, 'e4m3': 2}[args.operands])
+    base = synth.CCIP_TINY if args.arch == 'tiny' else synth.CCIP_B36_384
+    cfg = dict(base, operand_f16={'bf16': 0, 'half': 1, 'e4m3': 2}[args.operands])
     if args.checkpoint:
-        encoder = CCIPEncoder.from_safetensors(args.checkpoint, cfg, max_batch=args.batch, device=args.device)
+        encoder = cf.CCIPEncoder.from_safetensors(args.checkpoint, cfg, max_batch=args.batch, device=device)
     else:
-        print('no --checkpoint: using the seeded synthetic CCIP weights')
-        encoder = CCIPEncoder(cfg, synth.ccip_weights(cfg), max_batch=args.batch, device=args.device)
-    cindex = CharacterFeatureIndex(encoder, device=args.device, prefix=INDEX_PREFIX)
+        if rank == 0:
+            print('no --checkpoint: using the seeded synthetic CCIP weights')
+        encoder = cf.CCIPEncoder(cfg, synth.ccip_weights(cfg), max_batch=args.batch, device=device)
+    feat_dim = encoder.out_dim
 
-    file_list = list_files_recursive(args.dir[0])
-    print(f'{len(file_list)} files found')
-    if after_date is not None:
-        file_list = [p for p in file_list if datetime.date.fromtimestamp(os.path.getmtime(p)) >= after_date]
-        print(f'{len(file_list)} files found after {after_date}')
-        if os.path.exists(INDEX_PREFIX):
-            for f in (INDEX_PREFIX, INDEX_PREFIX + '.npy', INDEX_PREFIX + '.csv'):
-                if os.path.exists(f):
-                    shutil.copy2(f, f + '.bak')
-            cindex.index = Similarity.load(INDEX_PREFIX, device=args.device)
-            if os.path.exists(INDEX_PREFIX + '.csv'):
-                cindex.paths = [l.rstrip('\n') for l in open(INDEX_PREFIX + '.csv', encoding='utf-8')]
+    # ---- rank 0: file list, backup, revision bookkeeping ----------------------------------------------------------
+    file_list, save_name, cindex = None, INDEX_PREFIX, None
+    if rank == 0:
+        file_list = list_files_recursive(args.dir[0])
+        print(f'{len(file_list)} files found')
+        cindex = cf.CharacterFeatureIndex(encoder, device=device, prefix=INDEX_PREFIX)
+        if feat_dim != 768:
+            cindex.index = Similarity(INDEX_PREFIX, None, feat_dim, device)
+        if after_date is not None:
+            file_list = [p for p in file_list if datetime.date.fromtimestamp(os.path.getmtime(p)) >= after_date]
+            print(f'{len(file_list)} files found after {after_date}')
+            cf.backup_index_files('.')                                                  # :346-352
+            max_number = cf.get_current_cfeature_number('.')                            # :354 (ValueError without an index, like the reference)
+            print('copying index files to new index files')
+            old = cf.CharacterFeatureIndex.load_latest(encoder, device, '.')            # :359-362 (+ csv alignment check)
+            save_name = cf.revision_name(max_number + 1)
+            cindex.index = Similarity(save_name, None, old.index.num_features, device, capacity=len(old.index) + len(file_list))
+            cindex.index.add_matrix(old.index.matrix())                                 # :364-368 in one block
+            cindex.paths = list(old.paths)
+            if len(cindex.paths) != sum(1 for _ in open(INDEX_PREFIX + '.csv', encoding='utf-8')):
+                with open(INDEX_PREFIX + '.csv', 'w', encoding='utf-8') as f:           # drop the surplus lines load_latest warned about
+                    f.writelines(p + '\n' for p in cindex.paths)
+            print('copying index files to new index files done')
+    file_list = hdist.broadcast_object(file_list, dist)
 
     start = time.perf_counter()
-    done = 0
-    if args.workers > 0:
-        from hiptagsearch import pipeline
-        with open(INDEX_PREFIX + '.csv', 'a', encoding='utf-8') as fcsv, \
-                pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP) as dpool:
-            for kept, images in dpool.batches(file_list):
-                cindex.add_features(kept, encoder.forward_u8(images))                # /255 and the CLIP normalisation on the device
-                for p in kept:
-                    fcsv.write(p + '\n')
-                done += len(kept)
-                el = time.perf_counter() - start
-                print(f'{done} files processed\n{el:.2f} seconds elapsed\n{el / max(done, 1):.4f} seconds per file\n', flush=True)
-        cindex.index.save(INDEX_PREFIX)
+    done = [0]
+
+    def progress(k):
+        done[0] += k
+        el = time.perf_counter() - start
+        print(f'{done[0]} files processed\n{el:.2f} seconds elapsed\n{el / max(done[0], 1):.4f} seconds per file\n', flush=True)
+
+    def extract(arrs):                                                                  # :133-159
+        return np.asarray(encoder(np.stack(arrs).astype(np.float32)), dtype=np.float32)
+
+    if dist is not None:
+        # ---- one process per GPU: contiguous blocks, one all-gather of feature rows --------------------------------
+        import torch
+        from hiptagsearch.shard import gather_rows, padded_rows_per_rank, shard_range
+        n = len(file_list)
+        lo, hi = shard_range(n, rank, world)
+        per = padded_rows_per_rank(n, world)
+        rows = np.full((max(per, 1), feat_dim + 1), np.nan, dtype=np.float32)           # column 0: 1 = encoded, NaN = padding / failed load
+
+        def keep_rows(idx, feats):
+            rows[idx, 0] = 1.0
+            rows[idx, 1:] = feats
+        encode_files(file_list[lo:hi], args.batch, extract, keep_rows, cfg['image_size'])
+        cdev = hdist.collective_device(dist, device)
+        full = gather_rows(torch.from_numpy(rows[:per] if per else rows[:0]).to(cdev), n, dist).cpu().numpy()
+        if rank == 0:
+            ok = full[:, 0] == 1.0
+            kept = [p for p, k in zip(file_list, ok) if k]
+            with open(INDEX_PREFIX + '.csv', 'a', encoding='utf-8') as fcsv:
+                for s in range(0, len(kept), 4096):
+                    cindex.add_features(kept[s:s + 4096], full[ok][s:s + 4096, 1:])
+                    fcsv.writelines(p + '\n' for p in kept[s:s + 4096])
+            progress(len(kept))
+            cindex.index.save(save_name)
+        hdist.finish(dist)
         return
-    with open(INDEX_PREFIX + '.csv', 'a', encoding='utf-8') as fcsv, \
-            concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as pool:
-        nxt = pool.map(gen_image_ndarray, file_list[:args.batch])                    # one batch of decode ahead of the device
-        for s in range(0, len(file_list), args.batch):
-            arrs = list(nxt)
-            if s + args.batch < len(file_list):
-                nxt = pool.map(gen_image_ndarray, file_list[s + args.batch: s + 2 * args.batch])
-            keep = [(p, a) for p, a in zip(file_list[s:s + args.batch], arrs) if a is not None]      # failed loads are skipped (:392-395)
-            if not keep:
-                continue
-            feats = cindex.ccip_batch_extract_features([a for _, a in keep])
-            cindex.add_features([p for p, _ in keep], feats)
-            for p, _ in keep:
-                fcsv.write(p + '\n')                                                 # :376
-            done += len(keep)
-            el = time.perf_counter() - start
-            print(f'{done} files processed\n{el:.2f} seconds elapsed\n{el / max(done, 1):.4f} seconds per file\n', flush=True)
-    cindex.index.save(INDEX_PREFIX)
+
+    with open(INDEX_PREFIX + '.csv', 'a', encoding='utf-8') as fcsv:
+
+        def add(paths, feats):
+            cindex.add_features(paths, feats)
+            fcsv.writelines(p + '\n' for p in paths)                                    # :376,419
+            fcsv.flush()
+            progress(len(paths))
+        if args.workers > 0:
+            from hiptagsearch import pipeline
+            with pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP) as dpool:
+                for kept, images in dpool.batches(file_list):
+                    add(kept, encoder.forward_u8(images))                               # /255 and the CLIP normalisation on the device
+        else:
+            encode_files(file_list, args.batch, extract, lambda idx, feats: add([file_list[i] for i in idx], feats), cfg['image_size'])
+    cindex.index.save(save_name)                                                        # :459
 
 
 if __name__ == "__main__":

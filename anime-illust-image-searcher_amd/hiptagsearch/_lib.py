@@ -44,6 +44,7 @@ _SIGNATURES = {
     "hipts_abi_version": [],
     "hipts_last_error": [c_char_p, c_size_t],
     "hipts_device_count": [POINTER(c_int)],
+    "hipts_sizeof_config": [c_int, POINTER(c_size_t)],
     "hipts_vit_create": [POINTER(VitConfig), c_int, POINTER(c_void_p)],
     "hipts_vit_destroy": [c_void_p],
     "hipts_vit_set_tensor": [c_void_p, c_char_p, c_void_p, c_int64],
@@ -86,6 +87,7 @@ _SIGNATURES = {
     "hipts_index_len": [c_void_p, POINTER(c_int64)],
     "hipts_index_vector_by_id": [c_void_p, c_int64, c_void_p],
     "hipts_index_data": [c_void_p, POINTER(c_void_p)],
+    "hipts_index_export": [c_void_p, c_int64, c_int64, c_void_p],
     "hipts_index_query": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     "hipts_combine": [c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_int, c_int, c_void_p, c_int, c_void_p],
     "hipts_rowmax": [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p],
@@ -93,6 +95,9 @@ _SIGNATURES = {
     "hipts_topk": [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                      c_void_p, c_void_p, c_void_p, c_void_p],
+    "hipts_query_profile_enable": [c_void_p, c_int],
+    "hipts_query_profile_read": [c_void_p, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double)],
+    "hipts_query_profile_name": [c_int, c_char_p, c_size_t],
     "hipts_d2v_create": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_int, POINTER(c_void_p)],
     "hipts_d2v_destroy": [c_void_p],
     "hipts_d2v_infer": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p,
@@ -123,6 +128,12 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the header and the library disagree
         fn.argtypes = argtypes
         fn.restype = c_int
+    # the three configuration structures are passed by pointer: a layout that differs from the library's would be read past
+    for kind, st in enumerate((VitConfig, EvaConfig, CcipConfig)):
+        n = c_size_t(0)
+        if lib.hipts_sizeof_config(kind, ctypes.byref(n)) != 0 or n.value != ctypes.sizeof(st):
+            raise ImportError("%s is %d bytes here but %d in libhip_tagsearch.so: binding and library are out of step"
+                              % (st.__name__, ctypes.sizeof(st), n.value))
     _lib = lib
     return lib
 

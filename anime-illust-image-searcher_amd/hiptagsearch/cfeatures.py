@@ -21,7 +21,47 @@ from .index import Similarity
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)          # gen_cfeatures.py:100
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 BATCH_SIZE = 20                                          # gen_cfeatures.py:50
-DEFAULT_THRESHOLD = 0.17847511429108218                  # docstring value, gen_cfeatures.py:195-196
+DEFAULT_THRESHOLD = 0.17847511429108218                  # docstring value, gen_cfeatures.py:195-196 (metric model's scale)
+# The reference cuts at metrics.json's threshold / 1.5 (gen_cfeatures.py:298-299) on the output of its METRIC MODEL.  That
+# constant is calibrated for that model's difference scale and does not transfer to 1 - cosine of the encoder features,
+# which is what BASELINE.json configs[4] restates the rerank as.  The cosine cut is therefore its own parameter
+# (CharacterFeatureIndex.cosine_diff_threshold); the default below only reuses the reference's number as a placeholder and
+# must be calibrated on same-character / different-character pairs of a real checkpoint (none is reachable here).
+DEFAULT_COSINE_DIFF_THRESHOLD = DEFAULT_THRESHOLD / 1.5
+INDEX_PREFIX = 'charactor-featues-idx'                   # gen_cfeatures.py:311 (the reference's spelling)
+
+
+def get_current_cfeature_number(dirpath: str = '.') -> int:
+    """gen_cfeatures.py:317-335 / webui.py:272-277: the highest revision N among `charactor-featues-idx` (N = 0) and
+    `charactor-featues-idxN`; ValueError (max of an empty list) when there is none, like the reference."""
+    import os
+    import re
+    pattern = re.compile(r'^charactor-featues-idx(\d*)$')
+    numbers = []
+    for file in os.listdir(dirpath):
+        m = pattern.match(file)
+        if m:
+            numbers.append(int(m.group(1)) if m.group(1) else 0)
+    return max(numbers)
+
+
+def revision_name(number: int) -> str:
+    return INDEX_PREFIX if number == 0 else INDEX_PREFIX + str(number)
+
+
+def backup_index_files(dirpath: str = '.') -> str:
+    """gen_cfeatures.py:346-352: copy every `charactor-featues-idx*` file into a directory named by the current time."""
+    import datetime
+    import os
+    import shutil
+    from pathlib import Path
+    backup_dir = os.path.join(dirpath, datetime.datetime.now().strftime('%Y%m%d_%H%M%S'))
+    os.makedirs(backup_dir, exist_ok=True)
+    for file in Path(dirpath).glob('charactor-featues-idx*'):
+        if file.is_file():
+            shutil.copy2(file, Path(backup_dir) / file.name)
+            print(f'Backed up {file} to {backup_dir}')
+    return backup_dir
 
 
 def _normalize(data, mean=CLIP_MEAN, std=CLIP_STD):
@@ -36,7 +76,7 @@ def _preprocess_image(image, size: int = 384):
     return _normalize(data)
 
 
-def gen_image_ndarray(file_path: str) -> Optional[np.ndarray]:
+def gen_image_ndarray(file_path: str, size: int = 384) -> Optional[np.ndarray]:
     """gen_cfeatures.py:285-295 (imgutils.load_images(mode='RGB') = alpha composited on white)."""
     from PIL import Image
     try:
@@ -48,7 +88,7 @@ def gen_image_ndarray(file_path: str) -> Optional[np.ndarray]:
             img = bg
         else:
             img = img.convert("RGB")
-        return _preprocess_image(img, 384)
+        return _preprocess_image(img, size)
     except Exception as e:
         print('%s: %s' % (type(e), str(e)))
         return None
@@ -130,9 +170,31 @@ class CharacterFeatureIndex:
 
     def __init__(self, encoder: Callable[[np.ndarray], np.ndarray], device: int = 0, prefix: str = "charactor-featues-idx"):
         self.encoder = encoder
+        self.image_size = int(getattr(encoder, "cfg", {}).get("image_size", 384)) if hasattr(encoder, "cfg") else 384   # gen_cfeatures.py:101
         self.index = Similarity(prefix, None, 768, device)
         self.paths: List[str] = []
-        self.threshold = DEFAULT_THRESHOLD
+        self.threshold = DEFAULT_THRESHOLD                       # the reference's metric-model threshold (kept for completeness)
+        self.cosine_diff_threshold = DEFAULT_COSINE_DIFF_THRESHOLD  # the cut actually applied to 1 - cosine (see the note above)
+
+    @classmethod
+    def load_latest(cls, encoder, device: int = 0, dirpath: str = '.') -> "CharacterFeatureIndex":
+        """webui.py:265-277: the paths csv and the latest index revision.  The csv is appended per batch while the index is
+        saved at the end of a run (gen_cfeatures.py:419,459): after a crash the csv is longer than the index.  Rows and paths
+        must stay aligned, so surplus csv lines are dropped here (with a warning); a csv SHORTER than the index is an error."""
+        import os
+        self = cls(encoder, device)
+        name = revision_name(get_current_cfeature_number(dirpath))
+        self.index = Similarity.load(os.path.join(dirpath, name), device)
+        csv = os.path.join(dirpath, INDEX_PREFIX + '.csv')
+        paths = [l.rstrip('\n') for l in open(csv, encoding='utf-8')] if os.path.exists(csv) else []
+        n = len(self.index)
+        if len(paths) < n:
+            raise ValueError('%s lists %d paths but %s holds %d rows' % (csv, len(paths), name, n))
+        if len(paths) > n:
+            print('warning: %s lists %d paths, %s holds %d rows: ignoring the last %d paths (an interrupted run?)'
+                  % (csv, len(paths), name, n, len(paths) - n))
+        self.paths = paths[:n]
+        return self
 
     def ccip_batch_extract_features(self, images: Sequence[np.ndarray]) -> np.ndarray:      # :133-159
         data = np.stack(images).astype(np.float32)
@@ -169,7 +231,7 @@ def cfeatures_rerank(final_scores_top10: Sequence[Tuple[int, float]], top10_feat
     """webui.py:283-335: mean feature of the top-10 images, difference to every indexed image,
     keep those below the threshold that carry all required and no excluded tags, best first; the
     original top-10 lead the list (returned without topn cut or gap filter, like the reference)."""
-    threshold = cindex.threshold if threshold is None else threshold
+    threshold = cindex.cosine_diff_threshold if threshold is None else threshold
     mean = np.average(np.stack(top10_features), axis=0)                               # :303
     diffs = cindex.differences(mean)                                                  # :306-309 on the device
     out: List[Tuple[int, float]] = []

@@ -96,24 +96,37 @@ class Similarity:
         return self.query(v)[0]
 
     # --- persistence ---------------------------------------------------------------------
-    def matrix(self) -> np.ndarray:
+    def matrix(self, first: int = 0, nrows: int = None) -> np.ndarray:
+        """Rows [first, first + nrows) as one host array: a single device-to-host copy (hipts_index_export)."""
         n = len(self)
-        out = np.empty((n, self.num_features), dtype=np.float32)
-        for i in range(n):     # small indexes only; bulk export goes through torch / hipts_index_data
-            out[i] = self.vector_by_id(i)
+        nrows = n - first if nrows is None else nrows
+        out = np.empty((nrows, self.num_features), dtype=np.float32)
+        _lib.call("hipts_index_export", self._h, c_int64(first), c_int64(nrows), _lib.ptr(out))
         return out
 
     def save(self, fname: str = None):
+        """Manifest `fname` (JSON) + `fname.npy`.  NOT gensim's pickle layout (unreadable / unwritable without gensim,
+        SURVEY.md T1): index files are not interchangeable with the reference's in either direction.
+        Written to temporary names and renamed, so a crash leaves the previous pair intact."""
+        import os
         fname = fname or self.output_prefix
-        np.save(fname + ".npy", self.matrix())
-        json.dump({"format": "hiptagsearch-dense-index-v1", "num_features": self.num_features, "rows": len(self)},
-                  open(fname, "w"))
+        with open(fname + ".npy.tmp", "wb") as f:
+            np.save(f, self.matrix())
+        with open(fname + ".tmp", "w") as f:
+            json.dump({"format": "hiptagsearch-dense-index-v1", "num_features": self.num_features, "rows": len(self)}, f)
+        os.replace(fname + ".npy.tmp", fname + ".npy")
+        os.replace(fname + ".tmp", fname)
 
     @classmethod
     def load(cls, fname: str, device: int = 0, mmap=None) -> "Similarity":
         meta = json.load(open(fname))
+        rows = np.load(fname + ".npy", mmap_mode="r")
+        if rows.shape != (meta["rows"], meta["num_features"]):
+            raise ValueError("%s.npy is %r but the manifest says %d x %d" % (fname, rows.shape, meta["rows"], meta["num_features"]))
         idx = cls(fname, None, meta["num_features"], device, capacity=meta["rows"])
-        idx.add_matrix(np.load(fname + ".npy"))
+        step = max(1, (256 << 20) // (4 * meta["num_features"]))            # stream large matrices in 256 MB blocks
+        for s0 in range(0, meta["rows"], step):
+            idx.add_matrix(np.ascontiguousarray(rows[s0:s0 + step]))
         return idx
 
     def close(self):

@@ -158,14 +158,14 @@ class SearchEngine:
         feats = []
         for doc_id, _ in top10:                                                       # :292-301
             path = self.image_files_name_tags_arr[doc_id].split(",")[0]
-            arr = gen_image_ndarray(path)
+            arr = gen_image_ndarray(path, self.cindex.image_size)
             if arr is None:
                 continue
             feats.append(self.cindex.ccip_batch_extract_features([arr])[0])
         if not feats:
             return top10
         return cfeatures_rerank(top10, feats, self.cindex, self.file_tag_index_dict, self.filepath_docid_dict, required, exclude,
-                                self.cindex.threshold / 1.5)                          # gen_cfeatures.py:298-299
+                                self.cindex.cosine_diff_threshold)        # own parameter: gen_cfeatures.py:298-299's constant is the metric model's
 
     # ---- webui.py:189-253 -----------------------------------------------------------------------
     def _doc_tags(self, doc_id: int) -> List[str]:

@@ -27,6 +27,8 @@ def gather_rows(local_rows, n_items: int, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local_rows[:n_items]
     world = dist.get_world_size()
+    if dist.get_backend() != "nccl":            # gloo (tests, ranks sharing a GPU) moves host tensors; RCCL moves device tensors
+        local_rows = local_rows.cpu()
     out = torch.empty((world * local_rows.shape[0], local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
     dist.all_gather_into_tensor(out, local_rows.contiguous())
     per = local_rows.shape[0]

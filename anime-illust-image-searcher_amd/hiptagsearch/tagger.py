@@ -300,6 +300,87 @@ class Predictor:
             out.extend(format_lines(self.tag_names, counts, ids))
         return out
 
+    # ---- multi-GPU form of tagging.py:276-359 --------------------------------------------------
+    ROW_WIDTH = 2 + 254          # int32 {n_general, n_character, ids[254]}: 1 KiB per image on the wire
+
+    def process_directory_sharded(self, dir_path: str, added_date: Optional[datetime.date], batch_size: int, dist, rank: int,
+                                  world: int) -> None:
+        """One process per GPU (launched by torch.distributed.run; hiptagsearch.dist.init_from_env ran first).  Rank r tags
+        the contiguous block shard_range(n, r, world) of the file list with its own copy of the model, keeps fixed-width
+        tag rows on its device (hipts_tagsel_run_rows), ONE all-gather puts them in rank order == file order, rank 0 formats
+        and appends the lines.  The file written is the file the single-process loop writes."""
+        import torch
+        from . import dist as hdist
+        from .shard import gather_rows, padded_rows_per_rank, rows_to_lines, shard_range
+        file_list = None
+        if rank == 0:
+            file_list = self.list_files_recursive(dir_path)
+            print(f'{len(file_list)} files found')
+            if added_date is not None:
+                file_list = self.filter_files_by_date(file_list, added_date)
+                print(f'{len(file_list)} files found after {added_date}')
+                if os.path.exists('tags-wd-tagger.txt'):
+                    with open('tags-wd-tagger.txt', 'r', encoding='utf-8') as f, \
+                            open('tags-wd-tagger.txt.bak', 'w', encoding='utf-8') as f_bak:
+                        f_bak.write(f.read())
+                else:
+                    print('tags-wd-tagger.txt not found')
+                    file_list = 1                                   # every rank leaves with the reference's exit code
+        file_list = hdist.broadcast_object(file_list, dist)
+        if file_list == 1:
+            raise SystemExit(1)
+        if self.compat and file_list:
+            file_list = file_list[:(max(0, (len(file_list) + 9) // 10 - 1)) * 10]     # the reference's dropped tail (tagging.py:309), batch 10
+        self.load_model()
+        n = len(file_list)
+        lo, hi = shard_range(n, rank, world)
+        per = padded_rows_per_rank(n, world)
+        dev = torch.device("cuda", self.device)
+        W = self.ROW_WIDTH
+        rows = torch.full((max(per, 1), W), -1, dtype=torch.int32, device=dev)        # sentinel rows: padding and failed loads
+        bs = min(batch_size, self.max_batch)
+        probs = torch.empty((bs, self.tagger_model.num_classes), dtype=torch.float32, device=dev)
+        tmp = torch.empty((bs, W), dtype=torch.int32, device=dev)
+        start = time.perf_counter()
+        mine = file_list[lo:hi]
+        batches = [mine[i:i + bs] for i in range(0, len(mine), bs)]
+        with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as ex:
+            nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[0]] if batches else []
+            for bi, paths in enumerate(batches):
+                futs = nxt
+                nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[bi + 1]] if bi + 1 < len(batches) else []
+                imgs, pos = [], []
+                for j, fu in enumerate(futs):
+                    t = fu.result()
+                    if t is not None:
+                        imgs.append(t)
+                        pos.append(bi * bs + j)
+                if not imgs:
+                    continue
+                k = len(imgs)
+                self.tagger_model.forward_u8(np.stack(imgs), probs=probs[:k], want="probs")
+                self.selector.run_device(probs[:k], tmp[:k], 0.3, True, 0.3, True)     # tagging.py:333
+                rows[torch.as_tensor(pos, device=dev)] = tmp[:k]
+                if rank == 0 and (bi + 1) % max(1, PROGRESS_INTERVAL // bs) == 0:
+                    diff = time.perf_counter() - start
+                    print(f'{(bi + 1) * bs * world} files processed (all ranks)\n{diff:.2f} seconds elapsed\n', flush=True)
+        full = gather_rows(rows[:per] if per else rows[:0], n, dist)                   # [n, W] in file order, on every rank
+        if rank == 0:
+            full = full.cpu().numpy()
+            ok = full[:, 0] >= 0
+            over = np.nonzero(ok & (full[:, 0] + full[:, 1] > W - 2))[0]             # more tags than the row holds: redo those few in full
+            redo = {}
+            for i in over:
+                t = self.gen_image_tensor(file_list[int(i)])
+                if t is not None:
+                    redo[int(i)] = self.predict([t], 0.3, True, 0.3, True)[0]
+            with open('tags-wd-tagger.txt', 'a', encoding='utf-8') as f:              # tagging.py:293
+                lines = rows_to_lines(full, self.tag_names, file_list)
+                for i in range(n):
+                    if ok[i]:
+                        f.write((file_list[i] + ',' + redo[i] if i in redo else lines[i]) + '\n')
+            print(f'{int(ok.sum())} of {n} files tagged by {world} ranks in {time.perf_counter() - start:.2f} seconds', flush=True)
+
     def write_to_file(self, csv_line: str) -> None:
         self.f.write(csv_line + '\n')
 

@@ -5,7 +5,11 @@ Extra switches: --model vit-b16|eva02-l14, --checkpoint model.safetensors (timm 
 selected_tags.csv for a real wd tagger; without them the seeded synthetic stand-ins are used (no network here).
 --compat reproduces the reference's dropped tail batch; --batch sets the device batch size.
 Input pipeline (hiptagsearch/pipeline.py): --workers N decodes in N processes through shared memory; --write-shards DIR
-decodes the corpus once into packed uint8 shards and --shards DIR tags from them (utility/make_tensor_files.py's idea)."""
+decodes the corpus once into packed uint8 shards and --shards DIR tags from them (utility/make_tensor_files.py's idea).
+
+Multi-GPU (one process per GPU, RCCL all-gather of fixed-width tag rows restores file order):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 tagging.py --dir D
+writes the same tags-wd-tagger.txt as the single-process run (tests/test_gpu_multirank.py)."""
 import argparse
 import datetime
 import os
@@ -21,7 +25,7 @@ def main(arg_str: list) -> None:
     parser.add_argument('--checkpoint', default=None)
     parser.add_argument('--labels', default=None)
     parser.add_argument('--compat', action='store_true')
-    parser.add_argument('--model', choices=['vit-b16', 'eva02-l14'], default='vit-b16',
+    parser.add_argument('--model', choices=['vit-b16', 'eva02-l14', 'vit-tiny'], default='vit-b16',
                         help='vit-b16: wd-vit-tagger-v3 geometry (BASELINE.json contract model); eva02-l14: wd-eva02-large-tagger-v3, the repo tagging.py:45 names')
     parser.add_argument('--batch', type=int, default=64)
     parser.add_argument('--workers', type=int, default=0,
@@ -30,9 +34,13 @@ def main(arg_str: list) -> None:
     parser.add_argument('--shards', default=None, help='tag the pre-decoded shards in this directory (written by --write-shards)')
     parser.add_argument('--device', type=int, default=0)
     args = parser.parse_args(arg_str)
+    # under torch.distributed.run (WORLD_SIZE > 1): one process per GPU, the process group comes up before any GPU call
+    from hiptagsearch import dist as hdist
+    dist, rank, world, device = hdist.init_from_env(args.device)
     from hiptagsearch.tagger import Predictor
-    predictor = Predictor(device=args.device, max_batch=args.batch, compat=args.compat)
+    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat)
     from hiptagsearch import synth
+    model_cfg = {'vit-b16': synth.VIT_B16_448, 'eva02-l14': synth.EVA02_L14_448, 'vit-tiny': synth.VIT_TINY}[args.model]   # vit-tiny: test geometry
     after_date = None
     if args.after is not None:
         try:
@@ -43,14 +51,20 @@ def main(arg_str: list) -> None:
             raise SystemExit(1)
     if args.write_shards:
         from hiptagsearch import pipeline
-        cfg = synth.EVA02_L14_448 if args.model == 'eva02-l14' else synth.VIT_B16_448
+        cfg = model_cfg
         files = predictor.list_files_recursive(args.dir[0])
         if after_date is not None:
             files = predictor.filter_files_by_date(files, after_date)
         n = pipeline.write_shards(files, args.write_shards, cfg["image_size"], pipeline.TAGGER, args.workers or None)
         print(f'{n} of {len(files)} images written to {args.write_shards}')
         return
-    predictor.load_model(args.checkpoint, args.labels, cfg=synth.EVA02_L14_448 if args.model == 'eva02-l14' else synth.VIT_B16_448)
+    predictor.load_model(args.checkpoint, args.labels, cfg=model_cfg)
+    if dist is not None:
+        if args.workers or args.shards:
+            print('--workers / --shards are single-process input pipelines; under torch.distributed.run every rank decodes its own block on 8 threads')
+        predictor.process_directory_sharded(args.dir[0], after_date, 10 if args.compat else args.batch, dist, rank, world)
+        hdist.finish(dist)
+        return
     predictor.process_directory(args.dir[0], after_date, batch_size=10 if args.compat else args.batch, workers=args.workers, shards=args.shards)
 
 

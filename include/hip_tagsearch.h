@@ -44,6 +44,10 @@ int hipts_abi_version(void);
 /* copies the calling thread's last error message (NUL terminated, truncated to n) */
 int hipts_last_error(char* buf, size_t n);
 int hipts_device_count(int* count);
+/* sizeof() of a configuration structure as THIS LIBRARY was compiled: kind 0 = hipts_vit_config_t, 1 = hipts_eva_config_t,
+ * 2 = hipts_ccip_config_t.  A binding in another language compares its own structure's size with it before the first
+ * hipts_*_create (tests/test_abi.py does, for the ctypes structures and for the stubs printed in INTEGRATION.md). */
+int hipts_sizeof_config(int kind, size_t* bytes);
 
 /* ------------------------------------------------------------------------------------------
  * ViT tagger forward.   Replaces timm `model.forward(x)` + `F.sigmoid`      tagging.py:174,176
@@ -110,8 +114,10 @@ int hipts_vit_set_sub_batches(hipts_vit_t* h, int n);
  * outputs of the most recent forward.  A tagging loop joins on the stream that consumes the probabilities
  * and keeps submitting forwards on the other: the sub-batch streams then run from one batch straight into
  * the next, and the low-occupancy first and last kernels of a forward (patch matrix, pooling, head) overlap
- * the other half's bulk.  Each sub-batch stream stays in order, so workspace reuse is safe; the caller
- * double-buffers what it hands in as outputs. */
+ * the other half's bulk.  Each sub-batch stream stays in order and workspaces are carved by image, so consecutive
+ * forwards of the SAME batch size from device-resident input reuse them safely; a forward whose batch size, sub-batch
+ * count or input memspace differs from the unjoined one before it first waits (on `stream`) for all of that forward.
+ * The caller double-buffers what it hands in as outputs. */
 int hipts_vit_set_deferred_join(hipts_vit_t* h, int on);
 int hipts_vit_join(hipts_vit_t* h, void* stream);
 /* algorithmic FLOPs of one image's forward (2*M*N*K of every contraction), for roofline use */
@@ -266,6 +272,9 @@ int hipts_index_len(const hipts_index_t* h, int64_t* nrows);
 int hipts_index_vector_by_id(const hipts_index_t* h, int64_t id, float* out_host);
 /* device address of the row-major [len][dim] float32 matrix (for zero-copy producers) */
 int hipts_index_data(const hipts_index_t* h, void** device_ptr);
+/* rows [first, first + nrows) as one block into host memory (bulk form of vector_by_id: Similarity.save,
+ * genmodel.py:175, gen_cfeatures.py:459, and the revision copy of gen_cfeatures.py:360-368) */
+int hipts_index_export(const hipts_index_t* h, int64_t first, int64_t nrows, float* out_host);
 int hipts_index_query(hipts_index_t* h, const float* queries, int queries_memspace, int nq,
                       float* scores_out, int out_memspace, void* stream);
 
@@ -293,10 +302,24 @@ int hipts_topk(const double* vals, int nq, int64_t n, int k, int32_t* ids_out, d
 /* the fused query of webui.py:352-383 for nq queries: BM25 + index product + normalise +
  * w_bm25/w_sim combine + top-k.  final_out (optional, device, float64 [nq][len]) receives the
  * combined scores for the rerank stage (webui.py:189-253). */
+/* With nq == 1 -- the reference's only real usage (webui.py:586: one query, topn = 800) -- the call takes the one-query path:
+ * the query travels in the kernel arguments, every step runs thread-per-document over the whole chip (BM25 in the reference's
+ * own document-major form, the index product as the k-ordered fmaf chain = the same bits as the batched MFMA chain), and the
+ * results are stored straight into pinned host memory.  Same results as the batched path, bit for bit. */
 int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index,
                  const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr,
                  const float* q_vectors, int nq, double w_bm25, double w_sim, int k,
                  int32_t* ids_out, double* vals_out, double* final_out_device, void* stream);
+
+/* Per-kernel timing of the query path for roofline accounting (bench.py), as hipts_vit_profile_* above: while enabled, every
+ * kernel hipts_search launches is bracketed by HIP events on the stream it is launched on.  read() resolves them (synchronises) and
+ * returns, for one kernel category, the summed device time, the launches and the ALGORITHMIC bytes those launches stand for
+ * (DESIGN.md section 4).  Categories 0-4: the batched path (bm25_postings, sim_mfma, rowmax, combine, topk); 5-8: the
+ * one-query path (search1_score, search1_combine, search1_collect, topk on collected candidates). */
+#define HIPTS_QUERY_PROF_CATEGORIES 9
+int hipts_query_profile_enable(hipts_bm25_t* bm25, int enable);
+int hipts_query_profile_read(hipts_bm25_t* bm25, int category, double* total_ms, int64_t* launches, double* total_bytes);
+int hipts_query_profile_name(int category, char* buf, size_t n);
 
 /* ------------------------------------------------------------------------------------------
  * Doc2Vec PV-DBOW inference.   Replaces gensim Doc2Vec.infer_vector      genmodel.py:169,

@@ -1,0 +1,36 @@
+/* hip_tagsearch_debug.h -- diagnostic entry points of libhip_tagsearch.so.
+ *
+ * NOT part of the drop-in boundary (include/hip_tagsearch.h): nothing in the reference binds to these.  They exist for
+ * the kernel tests (tests/test_gpu_gemm.py), the standalone GEMM timers (tools/gemm_bench.py) and bench.py's clock probe.
+ * They may change or disappear between versions; HIPTS_ABI_VERSION does not cover them.
+ */
+#ifndef HIP_TAGSEARCH_DEBUG_H
+#define HIP_TAGSEARCH_DEBUG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hip_tagsearch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Average device time of `iters` back-to-back launches of the bf16 GEMM [M,K] x [N,K]^T with epilogue `epi`
+ * (the GemmEpilogue enumerator of csrc/vit_internal.h) on synthetic operands. */
+int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out);
+/* The same, and the shader clock (GHz) held inside the main loop of the stamped workgroup (s_memtime against the
+ * 100 MHz s_memrealtime); 0 when the library was built without HIPTS_GEMM_STAMPS support for that epilogue. */
+int hiptsdbg_gemm_clock(int M, int N, int K, int epi, int iters, float* ms_out, float* loop_ghz);
+/* out_host float32 [M][N] = A W^T for bf16 bit patterns a_bf16 [M][K], w_bf16 [N][K] (plain epilogue). */
+int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host);
+/* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in
+ * w_exp); kind 0: float32 output, 1: e4m3 output through the StarReLU epilogue's store path. */
+int hiptsdbg_gemm8_run(int M, int N, int K, const float* a_f32, const float* w_f32, int kind, void* out_host, int* w_exp);
+/* Copies a named workspace tensor of the last forward ("x", "xn", "q", "k", "vT", "att", "hmid") to the host. */
+int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_TAGSEARCH_DEBUG_H */

@@ -164,3 +164,37 @@ def rerank(final_scores: np.ndarray, topn: int, rerank_sims_fn: Callable[[np.nda
         return final[:min(topn, len(final))]
     sims = filter_searched_result(sims)
     return sims[:min(topn, len(sims))]
+
+
+def cfeatures_rerank(final_scores: np.ndarray, topn: int, required_tags: Sequence[str], exclude_tags: Sequence[str],
+                     image_files_name_tags_arr: Sequence[str], cfeature_filepath_idx: Sequence[str], cfeature_rows: np.ndarray,
+                     get_image_feature: Callable[[str], Optional[np.ndarray]], threshold: float) -> List[Tuple[int, float]]:
+    """webui.py:255-342 'character oriented' mode, with the CCIP metric model's difference (an opaque ONNX graph,
+    gen_cfeatures.py:212-274) restated as BASELINE.json configs[4] does: difference := 1 - cosine(feature row, query), the
+    rows being the unit vectors the feature index stores (gen_cfeatures.py:310-314) and the product the k-ordered chain of
+    similarity().  `get_image_feature(path)` stands for predictor.get_image_feature (:296-301; None = failed load)."""
+    file_tag_index_dict = {l.split(",")[0]: {t: True for t in l.split(",")[1:]} for l in image_files_name_tags_arr}   # webui.py:623-646
+    filepath_docid_dict = {l.split(",")[0]: i for i, l in enumerate(image_files_name_tags_arr)}
+    order = stable_rank(final_scores)                                                   # :282-283
+    sims = [(int(i), float(final_scores[i])) for i in order]
+    if len(sims) > 10:
+        top10 = sims[:10]
+        feats = []
+        for doc_id, _ in top10:                                                         # :289-301
+            f = get_image_feature(image_files_name_tags_arr[doc_id].split(",")[0])
+            if f is not None:
+                feats.append(f)
+        mean = np.average(np.stack(feats), axis=0).astype(np.float32)                   # :303
+        n = np.float32(np.sqrt(np.sum(mean * mean)))
+        q = mean / n if n > 0 else mean
+        diffs = np.float32(1.0) - similarity(cfeature_rows, q)                          # :306-309 restated as cosine
+        out = []
+        for idx, path in enumerate(cfeature_filepath_idx):                              # :311-328
+            if path not in file_tag_index_dict:
+                continue
+            tags = file_tag_index_dict[path]
+            if diffs[idx] < threshold and all(t in tags for t in required_tags) and all(t not in tags for t in exclude_tags):
+                out.append((filepath_docid_dict[path], float(np.float32(1.0) - diffs[idx])))
+        return top10 + sorted(out, key=lambda it: -it[1])                               # :330-335
+    sims = filter_searched_result(sims)                                                 # :336-342
+    return sims[:min(topn, len(sims))]

@@ -195,6 +195,64 @@ def test_search_rank_equal(corpus20k):
         assert vals[i].tobytes() == wv.tobytes()
 
 
+def test_search_one_query_path_is_bit_equal_to_the_batched_path(corpus20k):
+    """hipts_search with nq == 1 takes the one-query path (thread-per-document BM25 in the reference's document-major form,
+    fmaf-chain index product, sampled threshold + candidate ranking): ids, scores and the combined score row must equal the
+    batched kernels' bit for bit -- plain, required and excluded terms, k = 100 and k = 1024, and the cases that defeat the
+    sampled threshold (everything -inf, massive exact ties), which fall through to the exact radix select."""
+    import ctypes
+    import torch
+    from hiptagsearch import _lib, synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from oracle import bm25 as obm25
+    from oracle import search as osearch
+    ptr, terms, V = corpus20k
+    D = len(ptr) - 1
+    rows = synth.index_vectors(D, 300, seed=46)
+    rows[5000:9000] = rows[4999]                                   # 4001 identical rows: exact ties in the index product
+    bm = BM25Index(ptr, terms, V)
+    index = Similarity("idx", None, 300, capacity=D)
+    index.add_matrix(rows)
+    eng = SearchEngine(None, index, {}, bm, [])
+    qs = [dict(q) for q in synth.queries(40, V, seed=44, head=300)]
+    qs.append({7: 1.0, V + 5: 1001.0})                             # a required term nobody has: every score -inf (webui.py:161-168)
+    qs.append({})                                                  # no BM25 term at all: the index product alone, ties included
+    rng = np.random.default_rng(5)
+    qv = rng.standard_normal((len(qs), 300))
+    qv = (qv / np.linalg.norm(qv, axis=1, keepdims=True)).astype(np.float32)
+    for k in (100, 1024):
+        fb = torch.empty((len(qs), D), dtype=torch.float64, device="cuda")
+        bi, bv = eng.score_topk(qs, qv, k, final_out=fb)           # batched kernels
+        fb = fb.cpu().numpy()
+        _lib.call("hipts_query_profile_enable", bm._h, 1)
+        for i, q in enumerate(qs):
+            f1 = torch.empty((1, D), dtype=torch.float64, device="cuda")
+            oi, ov = eng.score_topk([q], qv[i:i + 1], k, final_out=f1)
+            assert f1.cpu().numpy()[0].tobytes() == fb[i].tobytes(), "query %d combined scores" % i
+            np.testing.assert_array_equal(oi[0], bi[i], err_msg="query %d k %d" % (i, k))
+            assert ov[0].tobytes() == bv[i].tobytes()
+        ms, n, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.call("hipts_query_profile_read", bm._h, 5, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+        assert n.value == len(qs) and ms.value > 0 and by.value > D * 300 * 4 * len(qs)      # the one-query path really ran
+        _lib.call("hipts_query_profile_enable", bm._h, 0)
+    # and against the oracle directly (not only against the other device path)
+    corpus, idf, avgdl, _, dl = _oracle_index(ptr, terms, V)
+    optr, oterm, otf = obm25.to_csr(corpus)
+    idf_arr = np.zeros(V)
+    for t, v in idf.items():
+        idf_arr[t] = v
+    for i in (0, 3, 17, 40, 41):
+        q = qs[i]
+        b = obm25.bm25_score_csr(optr, oterm, otf, idf_arr, avgdl, dl, list(q.keys()), list(q.values()))
+        f = osearch.combine(b, osearch.similarity(rows, qv[i]))
+        wi, wv = osearch.topk(f, 100)
+        gi, gv = eng.score_topk([q], qv[i:i + 1], 100)
+        np.testing.assert_array_equal(gi[0], wi)
+        assert gv[0].tobytes() == wv.tobytes()
+
+
 # --------------------------------------------------------------------------------- full query function
 def test_find_similar_documents_matches_oracle():
     """find_similar_documents (webui.py:345-390, normal mode incl. the 10-document rerank and the gap
