@@ -13,6 +13,7 @@
 // This file is compiled with -ffp-contract=off: every float64 expression below evaluates in
 // numpy's operation order with one rounding per operation.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -20,6 +21,7 @@
 #include <vector>
 
 #include "common.h"
+#include "../../include/hip_tagsearch_debug.h"
 
 using namespace hipts;
 
@@ -38,7 +40,8 @@ struct hipts_bm25 {
     DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
     DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out;
     PinBuf pin_in, pin_out;                    // hipts_search: one H2D of the packed queries, one D2H of the packed results
-    DevBuf s1_state, s1_cand;                  // one-query path: Search1State; candidate keys u64[CAP] then ids u32[CAP]
+    DevBuf s1_state;                           // one-query path: Search1State + group maxima + per-workgroup candidate slots
+    uint32_t s1_seq = 0;                       // sequence number of the last one-query call (completion flag in pinned memory)
     bool s1_dirty = true;                      // s1_state may hold leftovers (first use, or a call that failed half way)
     // per-kernel HIP-event timing (hipts_query_profile_*): events on the stream each kernel is launched on
     bool prof = false;
@@ -388,12 +391,15 @@ constexpr int TOPK_SORT_TARGET = 256;
 
 struct Search1State;
 __device__ void search1_state_clear(Search1State* st);
-__device__ uint32_t search1_state_count(const Search1State* st);
+__device__ void search1_state_debug(Search1State* st, uint32_t cnt, uint32_t fast);
+constexpr int S1_BLOCK_CAP = 64;     // candidates one search1_collect_kernel workgroup (1024 documents) may hand on
 
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
                                                     int32_t* __restrict__ ids_out, double* __restrict__ vals_out,
-                                                    Search1State* __restrict__ pre = nullptr, const unsigned long long* __restrict__ pre_key = nullptr,
-                                                    const uint32_t* __restrict__ pre_id = nullptr) {
+                                                    Search1State* __restrict__ pre = nullptr, const uint32_t* __restrict__ pre_cnt = nullptr,
+                                                    const uint32_t* __restrict__ pre_flag = nullptr, const unsigned long long* __restrict__ pre_key = nullptr,
+                                                    const uint32_t* __restrict__ pre_id = nullptr, int pre_blocks = 0,
+                                                    uint32_t* __restrict__ done_flag = nullptr, uint32_t done_seq = 0) {
     __shared__ uint32_t hist[4096];
     __shared__ uint64_t ckey[TOPK_CAP];
     __shared__ uint32_t cid[TOPK_CAP];
@@ -410,20 +416,39 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     // the score, so the collected set is exactly "all scores >= a pivot": if it has at least k and at most CAP
     // members it contains the top k and the sort below finishes the job; otherwise the exact path runs.
     bool done_fast = false;
+    int fill_need = 0;        // results still missing after the candidates: the lowest-index -inf scores (candidate path only)
     if (pre) {
-        // candidates collected by search1_collect_kernel: every score whose digit is at or above a threshold digit, i.e. all
-        // scores >= a pivot; with at least k and at most CAP of them the top k are among them
-        const int c = (int)search1_state_count(pre);
-        done_fast = c >= k && c <= TOPK_CAP;
+        // Candidates handed on by search1_collect_kernel (per-workgroup slots): every score whose digit is at or above a threshold
+        // digit, i.e. all scores >= a pivot.  With at least k and at most CAP of them the top k are among them.  With fewer than
+        // k, and nothing but -inf below the pivot, they are ALL results and the rest are -inf ties in index order.
+        int mine = 0, bad = 0, other = 0;
+        for (int b = tid; b < pre_blocks; b += 1024) {
+            const int cb = (int)pre_cnt[b];
+            bad |= cb > S1_BLOCK_CAP;
+            mine += cb > S1_BLOCK_CAP ? S1_BLOCK_CAP : cb;
+            other |= (int)pre_flag[b];
+        }
+        int c;
+        const int excl = block_excl_scan(mine, scratch, &c);
+        bad = __syncthreads_or(bad);
+        const bool only_inf_below = __syncthreads_or(other) == 0;
+        done_fast = !bad && c <= TOPK_CAP && (c >= k || only_inf_below);
         if (done_fast) {
-            for (int i = tid; i < c; i += 1024) {
-                ckey[i] = pre_key[i];
-                cid[i] = pre_id[i];
+            int off = excl;
+            for (int b = tid; b < pre_blocks; b += 1024) {
+                const int cb = (int)pre_cnt[b];
+                for (int i = 0; i < cb; ++i) {
+                    ckey[off + i] = pre_key[(int64_t)b * S1_BLOCK_CAP + i];
+                    cid[off + i] = pre_id[(int64_t)b * S1_BLOCK_CAP + i];
+                }
+                off += cb;
             }
             if (tid == 0) sh_cnt = c;
+            if (c < k) fill_need = k - c;
         }
         __syncthreads();
-        search1_state_clear(pre);               // all zero again for the next query (every read of it is behind the barrier above)
+        search1_state_clear(pre);               // the maxima slots are zero again for the next query (search1_combine_kernel has read them)
+        search1_state_debug(pre, (uint32_t)c, done_fast ? 1u : 0u);
     }
     if (!done_fast && n >= 8192) {
         for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
@@ -623,6 +648,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     }
     }
     const int cnt = sh_cnt;
+    const int kout = cnt < k ? cnt : k;
     if (cnt <= 640) {
         // few candidates: rank by counting -- rank(i) = #{j : j before i in (key desc, id asc)} -- no barriers, LDS broadcasts
         __syncthreads();
@@ -635,41 +661,65 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
                 const uint32_t ij = cid[j];
                 rank += (kj > ki || (kj == ki && ij < ii)) ? 1 : 0;
             }
-            if (rank < k) {
+            if (rank < kout) {
                 ids_out[(int64_t)blockIdx.x * k + rank] = (int32_t)ii;
                 vals_out[(int64_t)blockIdx.x * k + rank] = key_value(ki);
             }
         }
-        return;
-    }
-    int np2 = 64;
-    while (np2 < cnt) np2 <<= 1;
-    for (int i = cnt + tid; i < np2; i += 1024) {
-        ckey[i] = 0;
-        cid[i] = 0xffffffffu;
-    }
-    __syncthreads();
-    // bitonic sort, "greater first": (key desc, id asc)
-    for (int size = 2; size <= np2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (np2 >> 1); t += 1024) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride);
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const uint64_t ka = ckey[lo], kb = ckey[hi];
-                const uint32_t ia = cid[lo], ib = cid[hi];
-                const bool a_first = (ka > kb) || (ka == kb && ia < ib);
-                if (a_first != desc) {
-                    ckey[lo] = kb; ckey[hi] = ka;
-                    cid[lo] = ib; cid[hi] = ia;
+    } else {
+        int np2 = 64;
+        while (np2 < cnt) np2 <<= 1;
+        for (int i = cnt + tid; i < np2; i += 1024) {
+            ckey[i] = 0;
+            cid[i] = 0xffffffffu;
+        }
+        __syncthreads();
+        // bitonic sort, "greater first": (key desc, id asc)
+        for (int size = 2; size <= np2; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (np2 >> 1); t += 1024) {
+                    const int lo = ((t / stride) * stride * 2) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const uint64_t ka = ckey[lo], kb = ckey[hi];
+                    const uint32_t ia = cid[lo], ib = cid[hi];
+                    const bool a_first = (ka > kb) || (ka == kb && ia < ib);
+                    if (a_first != desc) {
+                        ckey[lo] = kb; ckey[hi] = ka;
+                        cid[lo] = ib; cid[hi] = ia;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
+        }
+        for (int i = tid; i < kout; i += 1024) {
+            ids_out[(int64_t)blockIdx.x * k + i] = (int32_t)cid[i];
+            vals_out[(int64_t)blockIdx.x * k + i] = key_value(ckey[i]);
         }
     }
-    for (int i = tid; i < k; i += 1024) {
-        ids_out[(int64_t)blockIdx.x * k + i] = (int32_t)cid[i];
-        vals_out[(int64_t)blockIdx.x * k + i] = key_value(ckey[i]);
+    if (fill_need > 0) {
+        // the remaining results are -inf scores in ascending index order (ordered compaction; stops as soon as enough are found)
+        const uint64_t ninf = order_key(-INFINITY);
+        int taken = 0;
+        for (int64_t i0 = 0; i0 < n && taken < fill_need; i0 += 1024) {
+            const int64_t i = i0 + tid;
+            const int flag = (i < n && order_key(v[i]) == ninf) ? 1 : 0;
+            int total;
+            const int excl = block_excl_scan(flag, scratch, &total);
+            if (flag && taken + excl < fill_need) {
+                ids_out[(int64_t)blockIdx.x * k + cnt + taken + excl] = (int32_t)i;
+                vals_out[(int64_t)blockIdx.x * k + cnt + taken + excl] = -INFINITY;
+            }
+            taken += total;
+        }
+    }
+    if (done_flag) {
+        // The results above went to pinned host memory.  Publish them to the HOST without waiting for the runtime's completion
+        // signal (a hipStreamSynchronize wake-up costs ~10 us): every storing thread fences at system scope, the workgroup meets,
+        // one lane releases the sequence number the host is spinning on.
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -681,18 +731,24 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 //   search1_score    BM25 in the reference's own shape (webui.py:139-170: for each query term a pass over the documents,
 //                    here the document's own (term, tf) list, document-major CSR) + the index product as the k-ordered
 //                    fmaf chain (bit-equal to the exact-f32 MFMA chain of sim_mfma_kernel and to the oracle) from the
-//                    tile-major copy; per-workgroup maxima into 64 slots
-//   search1_combine  webui.py:377-383 with the global maxima; histogram of a 1/8 sample over the value-uniform digit
-//   search1_collect  threshold digit from the sample, candidates (score digit >= threshold) into one buffer
-//   topk_kernel      takes the candidates (sort, or rank by counting when few); if the sample misjudged (fewer than k or
-//                    more than the buffer) the exact radix select runs instead -- same kernel, same results
+//                    tile-major copy; per-workgroup maxima into 256 slots
+//   search1_combine  webui.py:377-383 with the global maxima; the maximum of every group of 64 * gw documents
+//   search1_collect  threshold digit = digit of the k-th largest group maximum; candidates (score digit >= threshold) into
+//                    the workgroup's own slots
+//   topk_kernel      gathers the candidates and ranks them (by counting when few, bitonic sort otherwise); fills up with -inf
+//                    ties when a required / excluded term left fewer than k finite scores; if the candidates overflow their
+//                    buffers the exact radix select runs instead -- same kernel, same results
+// No global atomics on shared addresses after the score kernel: same-address atomics serialise at ~50-60 ns each on this part
+// (measured: 1563 histogram adds over ~100 bins cost 5 us, ~100 adds on one counter 6 us).
 // Algorithmic bytes per query: D * dim * 4 (index) + nnz * 8 + D * 12 (CSR) + D * (8 + 4) * 2 + D * 8 * 2 (scores, final).
 // =============================================================================================
 constexpr int S1_MAX_TERMS = 16;
 constexpr int S1_MAX_DIM = 768;
 constexpr int S1_THREADS = 128;
-constexpr int S1_SLOTS = 64;
+constexpr int S1_SLOTS = 256;
 constexpr int S1_MIN_DOCS = 8192;
+constexpr int S1_LDS_TERMS = 5120;   // (term, tf) entries of one workgroup's 128 documents staged in LDS (40 per document)
+constexpr int S1_GROUPS = 4096;      // at most this many document groups (a group = 64 * gw consecutive documents, one wave of search1_combine_kernel)
 
 struct Search1Query {            // passed by value: 3.3 KB of the 4 KB kernel-argument segment
     int32_t nt, n_required, masking, dim;
@@ -701,19 +757,22 @@ struct Search1Query {            // passed by value: 3.3 KB of the 4 KB kernel-a
     float q[S1_MAX_DIM];
 };
 
-struct Search1State {            // device resident, all zero between queries (the last kernel of a query clears it)
-    uint32_t hist[4096];
+struct Search1State {            // device resident; the maxima slots are all zero between queries (the last kernel clears them)
     unsigned long long max_a[S1_SLOTS];      // order_key images of the per-workgroup BM25 maxima
     uint32_t max_b[S1_SLOTS];                // float_order_key images of the index-product maxima
-    uint32_t cnt;                            // candidates collected
-    uint32_t pad[3];
+    uint32_t dbg[4];                         // NOT cleared: {candidates, took the candidate path, 0, 0} of the last query (hiptsdbg_search1_last)
 };
 
 __device__ void search1_state_clear(Search1State* st) {
     uint32_t* w = reinterpret_cast<uint32_t*>(st);
-    for (int i = threadIdx.x; i < (int)(sizeof(Search1State) / 4); i += blockDim.x) w[i] = 0;
+    for (int i = threadIdx.x; i < (int)(offsetof(Search1State, dbg) / 4); i += blockDim.x) w[i] = 0;
 }
-__device__ uint32_t search1_state_count(const Search1State* st) { return st->cnt; }
+__device__ void search1_state_debug(Search1State* st, uint32_t cnt, uint32_t fast) {
+    if (threadIdx.x == 0) {
+        st->dbg[0] = cnt;
+        st->dbg[1] = fast;
+    }
+}
 
 __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1Query Q, const float4* __restrict__ tiled, int64_t D,
                                                                    const int64_t* __restrict__ ptr, const int32_t* __restrict__ term,
@@ -721,49 +780,101 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
                                                                    const double* __restrict__ idf, int32_t V, double avgdl,
                                                                    double* __restrict__ bm_out, float* __restrict__ sim_out,
                                                                    Search1State* __restrict__ st) {
+    __shared__ int32_t sterm[S1_LDS_TERMS];
+    __shared__ uint16_t stfe[S1_LDS_TERMS], sdoc[S1_LDS_TERMS];
+    __shared__ int32_t stf[S1_MAX_TERMS][S1_THREADS];          // tf of query term j in this thread's document (0 = absent)
     const int tid = threadIdx.x;
     const int64_t d = (int64_t)blockIdx.x * S1_THREADS + tid;
     const bool valid = d < D;
     const int64_t dd = valid ? d : D - 1;
-    // ---- index product: acc = fmaf(row[k], q[k], acc), k ascending (the order of sim_mfma_kernel's chain and of the oracle)
+    // ---- index product: acc = fmaf(row[k], q[k], acc), k ascending (the order of sim_mfma_kernel's chain and of the oracle).
+    // The kernel is a stream of D * dim * 4 bytes: two register buffers of U float4 per lane, the loads of round r + 1 are issued
+    // before round r is consumed, and the first round is requested before the BM25 part below so that it flies meanwhile.
+    // Rounds past the last k re-read the last float4 (a cache hit) against Q.q's zero padding: fmaf(x, +0, acc) = acc exactly.
+    // (Measured: U = 8 or 16 and 128- or 256-thread workgroups make no difference; 64-thread workgroups are 40 % slower.)
     const int KQ = Q.dim >> 2;
     const float4* __restrict__ p = tiled + ((dd >> 5) * KQ) * 32 + (dd & 31);
-    float acc = 0.0f;
-    int kq = 0;
-    constexpr int U = 15;        // 15 x 16 B per lane in flight (dim 300 = 5 x 15 float4)
-    for (; kq + U <= KQ; kq += U) {
-        float4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = p[(int64_t)(kq + u) * 32];
+    constexpr int U = 8;
+    static_assert(S1_MAX_DIM % (4 * U) == 0, "Q.q must cover whole rounds");
+    float4 va[U], vb[U];
+    auto request = [&](float4(&v)[U], int kq0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float* qq = Q.q + 4 * (kq + u);
+            const int kq = kq0 + u < KQ ? kq0 + u : KQ - 1;
+            v[u] = p[(int64_t)kq * 32];
+        }
+    };
+    float acc = 0.0f;
+    auto consume = [&](const float4(&v)[U], int kq0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* qq = Q.q + 4 * (kq0 + u);
             acc = fmaf(v[u].x, qq[0], acc);
             acc = fmaf(v[u].y, qq[1], acc);
             acc = fmaf(v[u].z, qq[2], acc);
             acc = fmaf(v[u].w, qq[3], acc);
         }
+    };
+    request(va, 0);
+    // ---- BM25 (webui.py:139-170), the arithmetic of bm25_score_kernel.  The (term, tf) lists of a workgroup's documents are one
+    // contiguous span of the document-major CSR: it is staged in LDS with coalesced loads together with an entry -> document map,
+    // then walked ONCE, coalesced: a lane compares its entry with the (scalar) query terms; a match -- at most nt per document --
+    // records the entry's tf in the slot of (query term, entry's document).
+    const int64_t d_first = (int64_t)blockIdx.x * S1_THREADS;
+    const int64_t d_last = d_first + S1_THREADS < D ? d_first + S1_THREADS : D;
+    const int64_t b0 = ptr[d_first], e0 = ptr[d_last];
+    const bool staged = e0 - b0 <= S1_LDS_TERMS;
+    const int nspan = staged ? (int)(e0 - b0) : 0;
+    for (int i0 = 0; i0 < nspan; i0 += 4 * S1_THREADS) {
+        int32_t t4[4], f4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * S1_THREADS + tid;
+            t4[u] = i < nspan ? term[b0 + i] : 0;
+            f4[u] = i < nspan ? tf[b0 + i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * S1_THREADS + tid;
+            if (i < nspan) {
+                sterm[i] = t4[u];
+                stfe[i] = (uint16_t)(f4[u] < 65535 ? f4[u] : 65535);       // 65535 = "read the exact tf from memory"
+            }
+        }
     }
-    for (; kq < KQ; ++kq) {
-        const float4 v = p[(int64_t)kq * 32];
-        const float* qq = Q.q + 4 * kq;
-        acc = fmaf(v.x, qq[0], acc);
-        acc = fmaf(v.y, qq[1], acc);
-        acc = fmaf(v.z, qq[2], acc);
-        acc = fmaf(v.w, qq[3], acc);
-    }
-    // ---- BM25 (webui.py:139-170), the arithmetic of bm25_score_kernel
+    for (int j = 0; j < Q.nt; ++j) stf[j][tid] = 0;
     const int64_t b = ptr[dd], e = ptr[dd + 1];
+    if (staged && valid) {
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int i = (int)(b - b0); i < (int)(e - b0); ++i) sdoc[i] = (uint16_t)tid;
+    }
     const double dlv = (double)dl[dd];
+    __syncthreads();
+    if (staged) {
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (int i = tid; i < nspan; i += S1_THREADS) {
+            const int32_t ti = sterm[i];
+            for (int j = 0; j < Q.nt; ++j)
+                if (ti == Q.terms[j]) {
+                    const int f = stfe[i];
+                    stf[j][sdoc[i]] = f < 65535 ? f : tf[b0 + i];
+                }
+        }
+        __syncthreads();
+    } else {        // a span too long for LDS (documents with hundreds of tags): every thread walks its own list in memory
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t ti = term[i];
+            for (int j = 0; j < Q.nt; ++j)
+                if (ti == Q.terms[j]) stf[j][tid] = tf[i];
+        }
+    }
     const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv / avgdl));
     double s = 0.0;
     bool masked = false;
     for (int j = 0; j < Q.nt; ++j) {
         const int32_t t = Q.terms[j];
         const double w = Q.weights[j];
-        int32_t tfv = 0;
-        for (int64_t i = b; i < e; ++i)
-            if (term[i] == t) tfv = tf[i];
+        const int32_t tfv = stf[j][tid];
         const double idf_t = (t >= 0 && t < V) ? idf[t] : 0.0;
         const double tfd = (double)tfv;
         const double sc = idf_t * ((tfd * (BM25_K1 + 1.0)) / (tfd + nrm));
@@ -777,11 +888,21 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
         }
     }
     if (masked) s = -INFINITY;
+    // ---- the index stream
+    const int rounds = (KQ + U - 1) / U;
+    int r = 0;
+    for (; r + 2 <= rounds; r += 2) {
+        request(vb, (r + 1) * U);
+        consume(va, r * U);
+        request(va, (r + 2) * U);               // past the end: a clamped re-read that nobody consumes
+        consume(vb, (r + 1) * U);
+    }
+    if (r < rounds) consume(va, r * U);
     if (valid) {
         bm_out[d] = s;
         sim_out[d] = acc;
     }
-    // ---- per-workgroup maxima -> one of 64 slots (atomicMax on order-preserving images; 0 is below every value)
+    // ---- per-workgroup maxima -> one of 256 slots (atomicMax on order-preserving images; 0 is below every value): ~3 adds per slot
     double ma = valid ? s : -INFINITY;
     float mb = valid ? acc : -INFINITY;
     for (int o = 32; o >= 1; o >>= 1) {
@@ -806,10 +927,17 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
 }
 
 __device__ __forceinline__ void search1_maxima(const Search1State* __restrict__ st, double* ma, float* mb) {
-    // every workgroup folds the 64 slots itself (1 KB from L2)
+    // every wave folds the slots itself (3 KB from L2)
     const int lane = threadIdx.x & 63;
-    unsigned long long ka = st->max_a[lane];
-    uint32_t kb = st->max_b[lane];
+    unsigned long long ka = 0;
+    uint32_t kb = 0;
+#pragma unroll
+    for (int i = 0; i < S1_SLOTS / 64; ++i) {
+        const unsigned long long a = st->max_a[i * 64 + lane];
+        const uint32_t b = st->max_b[i * 64 + lane];
+        ka = a > ka ? a : ka;
+        kb = b > kb ? b : kb;
+    }
     for (int o = 32; o >= 1; o >>= 1) {
         const unsigned long long oa = __shfl_xor(ka, o);
         const uint32_t ob = __shfl_xor(kb, o);
@@ -820,72 +948,105 @@ __device__ __forceinline__ void search1_maxima(const Search1State* __restrict__ 
     *mb = kb ? float_from_key(kb) : -INFINITY;
 }
 
+// Threshold without sampling: the documents are cut into G <= 4096 groups of 64 * gw consecutive documents (one wave of this
+// kernel each); the k-th largest of the G group maxima is a LOWER bound of the k-th largest score (k groups hold a score at
+// least that large), so "every score whose digit is >= the digit of that bound" always contains the top k -- about
+// G * -ln(1 - k/G) of them, a few percent more than k (measured, 100k documents: 100-110 candidates for k = 100, 1630-1710 for
+// k = 1024).  Each wave stores its maximum in its own slot: no atomics.
 __global__ __launch_bounds__(256) void search1_combine_kernel(const double* __restrict__ bm, const float* __restrict__ sim, int64_t D, double wa,
-                                                              float wb, double* __restrict__ final_out, Search1State* __restrict__ st) {
+                                                              float wb, double* __restrict__ final_out, const Search1State* __restrict__ st,
+                                                              unsigned long long* __restrict__ wmax, int gw) {
     double ma;
     float mb;
     search1_maxima(st, &ma, &mb);
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
-    double A = bm[d];
-    float B = sim[d];
-    if (ma > 0.0) A = A / ma;                    // webui.py:379-380
-    if (mb > 0.0f) B = B / mb;                   // webui.py:377-378
-    const float wB = wb * B;
-    const double f = wa * A + (double)wB;        // webui.py:383
-    final_out[d] = f;
-    if ((d & 7) == 0) atomicAdd(&st->hist[value_digit(f)], 1u);       // the 1/8 sample
+    const int lane = threadIdx.x & 63;
+    const int64_t group = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double m = -INFINITY;
+    for (int c = 0; c < gw; ++c) {
+        const int64_t d = (group * gw + c) * 64 + lane;
+        if (d < D) {
+            double A = bm[d];
+            float B = sim[d];
+            if (ma > 0.0) A = A / ma;                    // webui.py:379-380
+            if (mb > 0.0f) B = B / mb;                   // webui.py:377-378
+            const float wB = wb * B;
+            const double f = wa * A + (double)wB;        // webui.py:383
+            final_out[d] = f;
+            m = fmax(m, f);
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if (lane == 0) wmax[group] = (unsigned long long)order_key(m);          // a group past the last document stores the image of -inf
 }
 
-__global__ __launch_bounds__(256) void search1_collect_kernel(const double* __restrict__ final_in, int64_t D, int k, Search1State* __restrict__ st,
-                                                              unsigned long long* __restrict__ cand_key, uint32_t* __restrict__ cand_id) {
-    __shared__ int scan[5];
+constexpr int S1_COLLECT_THREADS = 1024;
+__global__ __launch_bounds__(S1_COLLECT_THREADS) void search1_collect_kernel(const double* __restrict__ final_in, int64_t D, int k,
+                                                                             const unsigned long long* __restrict__ wmax, int groups,
+                                                                             uint32_t* __restrict__ bcnt, uint32_t* __restrict__ bflag,
+                                                                             unsigned long long* __restrict__ bkey, uint32_t* __restrict__ bid) {
+    __shared__ uint32_t hist[4096];
+    __shared__ int scan[17];
     __shared__ int sh_dmin;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // threshold digit: walking down from the top bin, the first digit at which the sample holds `want` entries
-    const int want = k / 8 + 3 * (int)ceilf(sqrtf((float)k / 8.0f)) + 4;
-    int own[16], ssum = 0;
+    __shared__ uint32_t sh_n, sh_other;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // threshold digit: the digit of the k-th largest group maximum (every workgroup finds it itself: 8 B x G from L2)
+    for (int i = tid; i < 4096; i += S1_COLLECT_THREADS) hist[i] = 0;
+    if (tid == 0) {
+        sh_n = 0;
+        sh_other = 0;
+    }
+    __syncthreads();
+    for (int g0 = 0; g0 < groups; g0 += S1_COLLECT_THREADS) {
+        const int g = g0 + tid;
+        const uint32_t dg = g < groups ? value_digit(key_value(wmax[g])) : 0u;
+        hist_add(hist, dg, dg != 0u);
+    }
+    __syncthreads();
+    // Digit 0 is everything below -2: combined scores are >= -1 unless a required / excluded term made them -inf, so with fewer
+    // than k groups above it the threshold is digit 1 -- every finite score is a candidate and the ranking fills up with -inf ties.
+    int own[4], ssum = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        own[j] = (int)st->hist[4095 - (16 * tid + j)];
+    for (int j = 0; j < 4; ++j) {
+        const int bin = 4095 - (4 * tid + j);
+        own[j] = bin >= 1 ? (int)hist[bin] : 0;
         ssum += own[j];
     }
-    int incl = ssum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-    }
-    if (lane == 63) scan[wave] = incl;
-    if (tid == 0) sh_dmin = 0;                   // fewer sampled entries than `want`: everything is a candidate (-> exact path)
+    int total;
+    const int excl = block_excl_scan(ssum, scan, &total);
+    if (tid == 0) sh_dmin = 1;
     __syncthreads();
-    int excl = incl - ssum;
-    for (int w = 0; w < wave; ++w) excl += scan[w];
-    if (excl < want && want <= excl + ssum) {
+    if (excl < k && k <= excl + ssum) {
         int run = excl;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (run < want && want <= run + own[j]) sh_dmin = 4095 - (16 * tid + j);
+        for (int j = 0; j < 4; ++j) {
+            if (run < k && k <= run + own[j]) sh_dmin = 4095 - (4 * tid + j);
             run += own[j];
         }
     }
     __syncthreads();
     const uint32_t dmin = (uint32_t)sh_dmin;
-    const int64_t d = (int64_t)blockIdx.x * 256 + tid;
-    const double f = d < D ? final_in[d] : 0.0;
+    const int64_t d = (int64_t)blockIdx.x * S1_COLLECT_THREADS + tid;
+    const double f = d < D ? final_in[d] : -INFINITY;
     const bool take = d < D && value_digit(f) >= dmin;
+    if (d < D && !take && f != -INFINITY) sh_other = 1u;
     const uint64_t m = __ballot(take);
-    if (m == 0) return;
-    uint32_t base = 0;
-    const int leader = __ffsll((unsigned long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&st->cnt, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    if (take) {
-        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (slot < (uint32_t)TOPK_CAP) {
-            cand_key[slot] = order_key(f);
-            cand_id[slot] = (uint32_t)d;
+    if (m != 0) {                                   // candidates go to this workgroup's own slots (LDS counter, one add per wave)
+        uint32_t base = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) base = atomicAdd(&sh_n, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (take) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (slot < (uint32_t)S1_BLOCK_CAP) {
+                bkey[(int64_t)blockIdx.x * S1_BLOCK_CAP + slot] = order_key(f);
+                bid[(int64_t)blockIdx.x * S1_BLOCK_CAP + slot] = (uint32_t)d;
+            }
         }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bcnt[blockIdx.x] = sh_n;                    // may exceed the cap: the ranking kernel then takes the exact path
+        bflag[blockIdx.x] = sh_other;
     }
 }
 
@@ -1033,7 +1194,7 @@ int stage_queries(hipts_bm25* h, const int32_t* q_terms, const double* q_weights
 }
 
 // hipts_search for ONE query (webui.py:345-383 + the ranking of :191-192): four launches, no staging copy, results written by the
-// last kernel straight into pinned host memory, one synchronisation.
+// last kernel straight into pinned host memory and published by a sequence number the host spins on.
 int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, const double* q_weights, int nt, const float* q_vector,
                double w_bm25, double w_sim, int k, int32_t* ids_out, double* vals_out, double* final_out_device, hipStream_t s) {
     const int64_t D = bm25->D;
@@ -1053,21 +1214,50 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
         HIPTS_TRY(bm25->ws_final.reserve((size_t)D * 8));
         final_dev = bm25->ws_final.as<double>();
     }
-    if (!bm25->s1_state.p) {
-        HIPTS_TRY(bm25->s1_state.alloc(sizeof(Search1State)));
-        HIPTS_TRY(bm25->s1_cand.alloc((size_t)TOPK_CAP * 12));
+    const int64_t waves = (D + 63) / 64;
+    const int gw = (int)((waves + S1_GROUPS - 1) / S1_GROUPS);                   // 64 * gw documents per group
+    const int blocks2 = (int)((waves + (int64_t)gw * 4 - 1) / ((int64_t)gw * 4));
+    const int groups = blocks2 * 4;
+    const int blocks3 = ceil_div(D, S1_COLLECT_THREADS);
+    // workspace: state | group maxima u64[groups] | per-workgroup counts u32[blocks3] | flags u32[blocks3] | keys u64[blocks3][CAP] | ids u32[blocks3][CAP]
+    const size_t off_wmax = (sizeof(Search1State) + 15) / 16 * 16;
+    const size_t off_bcnt = off_wmax + (size_t)groups * 8;
+    const size_t off_bflag = off_bcnt + (size_t)blocks3 * 4;
+    const size_t off_bkey = (off_bflag + (size_t)blocks3 * 4 + 15) / 16 * 16;
+    const size_t off_bid = off_bkey + (size_t)blocks3 * S1_BLOCK_CAP * 8;
+    const size_t ws_bytes = off_bid + (size_t)blocks3 * S1_BLOCK_CAP * 4;
+    if (bm25->s1_state.bytes < ws_bytes) {
+        HIPTS_TRY(bm25->s1_state.alloc(ws_bytes));
         bm25->s1_dirty = true;
     }
-    Search1State* st = bm25->s1_state.as<Search1State>();
+    char* ws = bm25->s1_state.as<char>();
+    Search1State* st = reinterpret_cast<Search1State*>(ws);
     if (bm25->s1_dirty) HIPTS_HIP(hipMemsetAsync(st, 0, sizeof(Search1State), s));
-    bm25->s1_dirty = true;                    // until the last kernel (which clears the state) has been enqueued
-    unsigned long long* ckey = bm25->s1_cand.as<unsigned long long>();
-    uint32_t* cid = reinterpret_cast<uint32_t*>(ckey + TOPK_CAP);
+    bm25->s1_dirty = true;                    // until the last kernel (which clears the maxima slots) has been enqueued
+    unsigned long long* wmax = reinterpret_cast<unsigned long long*>(ws + off_wmax);
+    uint32_t* bcnt = reinterpret_cast<uint32_t*>(ws + off_bcnt);
+    uint32_t* bflag = reinterpret_cast<uint32_t*>(ws + off_bflag);
+    unsigned long long* bkey = reinterpret_cast<unsigned long long*>(ws + off_bkey);
+    uint32_t* bid = reinterpret_cast<uint32_t*>(ws + off_bid);
     const int kk = (int)std::min<int64_t>(k, D);
     const size_t out_bytes = (size_t)kk * 12;
-    HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 64));
+    HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 192));
     double* hv = bm25->pin_out.as<double>();                  // pinned + mapped: the last kernel stores the results here
     int32_t* hi = reinterpret_cast<int32_t*>(hv + kk);
+    static const bool via_copy = getenv("HIPTS_SEARCH1_D2H") && strcmp(getenv("HIPTS_SEARCH1_D2H"), "1") == 0;     // A/B: device buffer + copy
+    static const bool allow_flag = !(getenv("HIPTS_SEARCH1_FLAG") && strcmp(getenv("HIPTS_SEARCH1_FLAG"), "0") == 0);   // A/B: completion by stream synchronise
+    const bool use_flag = allow_flag && !via_copy && !bm25->prof;
+    uint32_t* flag = reinterpret_cast<uint32_t*>(bm25->pin_out.as<char>() + ((out_bytes + 63) / 64 * 64));       // its own cache line behind the results
+    if (++bm25->s1_seq == 0) bm25->s1_seq = 1;
+    const uint32_t seq = bm25->s1_seq;
+    if (use_flag) __atomic_store_n(flag, 0u, __ATOMIC_RELAXED);          // (fresh pinned memory is not zeroed)
+    double* ov = hv;
+    int32_t* oi = hi;
+    if (via_copy) {
+        HIPTS_TRY(bm25->ws_out.reserve(out_bytes + 64));
+        ov = bm25->ws_out.as<double>();
+        oi = reinterpret_cast<int32_t*>(ov + kk);
+    }
     {
         QueryProfScope ps(bm25, s, QP_S1_SCORE, (double)D * index->dim * 4.0 + (double)bm25->nnz * 8.0 + (double)D * (8 + 4 + 8 + 4));
         search1_score_kernel<<<ceil_div(D, S1_THREADS), S1_THREADS, 0, s>>>(Q, index->tiled.as<float4>(), D, bm25->d_ptr.as<int64_t>(),
@@ -1078,22 +1268,35 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_COMBINE, (double)D * 20.0);
-        search1_combine_kernel<<<ceil_div(D, 256), 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim,
-                                                                final_dev, st);
+        search1_combine_kernel<<<blocks2, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, final_dev,
+                                                       st, wmax, gw);
         HIPTS_LAUNCH_CHECK();
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_COLLECT, (double)D * 8.0);
-        search1_collect_kernel<<<ceil_div(D, 256), 256, 0, s>>>(final_dev, D, kk, st, ckey, cid);
+        search1_collect_kernel<<<blocks3, S1_COLLECT_THREADS, 0, s>>>(final_dev, D, kk, wmax, groups, bcnt, bflag, bkey, bid);
         HIPTS_LAUNCH_CHECK();
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_TOPK, (double)kk * 24.0);
-        topk_kernel<<<1, 1024, 0, s>>>(final_dev, D, kk, hi, hv, st, ckey, cid);
+        topk_kernel<<<1, 1024, 0, s>>>(final_dev, D, kk, oi, ov, st, bcnt, bflag, bkey, bid, blocks3, use_flag ? flag : nullptr, seq);
         HIPTS_LAUNCH_CHECK();
     }
     bm25->s1_dirty = false;
-    HIPTS_HIP(hipStreamSynchronize(s));
+    if (via_copy) HIPTS_HIP(hipMemcpyAsync(hv, ov, out_bytes, hipMemcpyDeviceToHost, s));
+    bool seen = false;
+    if (use_flag) {
+        // spin on the sequence number the last kernel releases after its result stores (bounded: then the ordinary synchronise)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+                seen = true;
+                break;
+            }
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    if (!seen) HIPTS_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < k; ++i) {
         ids_out[i] = i < kk ? hi[i] : -1;
         vals_out[i] = i < kk ? hv[i] : -INFINITY;
@@ -1137,6 +1340,16 @@ int hipts_query_profile_read(hipts_bm25_t* h, int category, double* total_ms, in
     if (total_ms) *total_ms = h->prof_ms[category];
     if (launches) *launches = h->prof_n[category];
     if (total_bytes) *total_bytes = h->prof_bytes[category];
+    return HIPTS_OK;
+}
+
+int hiptsdbg_search1_last(hipts_bm25_t* h, uint32_t* candidates, uint32_t* took_candidate_path) {
+    HIPTS_REQUIRE(h && h->s1_state.p && candidates && took_candidate_path, "hiptsdbg_search1_last: no one-query search has run on this handle");
+    HIPTS_TRY(use_device(h->device));
+    uint32_t dbg[4];
+    HIPTS_HIP(hipMemcpy(dbg, reinterpret_cast<const char*>(h->s1_state.p) + offsetof(Search1State, dbg), sizeof(dbg), hipMemcpyDeviceToHost));
+    *candidates = dbg[0];
+    *took_candidate_path = dbg[1];
     return HIPTS_OK;
 }
 

@@ -63,6 +63,8 @@ class SearchEngine:
         self.search_mode = search_mode
         self.compat_rerank = compat_rerank
         self.cindex = None                     # cfeatures.CharacterFeatureIndex for 'character oriented' mode
+        self._search_fn = _lib.load().hipts_search
+        self._w_bm25, self._w_sim = c_double(BM25_WEIGHT), c_double(DOC2VEC_WEIGHT)
         # webui.py:623-646: path -> {tag: True} and path -> doc id, built from the same index file
         self.file_tag_index_dict = {l.split(",")[0]: {t: True for t in l.split(",")[1:]} for l in self.image_files_name_tags_arr}
         self.filepath_docid_dict = {l.split(",")[0]: i for i, l in enumerate(self.image_files_name_tags_arr)}
@@ -114,6 +116,18 @@ class SearchEngine:
         """Fused webui.py:352-383 for a batch: returns (ids int32 [nq,k], scores float64 [nq,k]) in
         rank order; `final_out` (device float64 tensor [nq, D]) receives all combined scores."""
         nq = len(query_weights)
+        if nq == 1 and final_out is None:                       # the reference's usage (webui.py:586): keep the host side short
+            q = query_weights[0]
+            n = len(q)
+            qt_a = np.fromiter(q.keys(), dtype=np.int32, count=n) if n else np.zeros(1, np.int32)
+            qw_a = np.fromiter(q.values(), dtype=np.float64, count=n) if n else np.zeros(1, np.float64)
+            qp = np.array((0, n), dtype=np.int32)
+            qv = np.ascontiguousarray(query_vectors, dtype=np.float32).reshape(1, -1)
+            ids = np.empty((1, k), dtype=np.int32)
+            vals = np.empty((1, k), dtype=np.float64)
+            _lib.check(self._search_fn(self.bm25._h, self.index._h, qt_a.ctypes.data, qw_a.ctypes.data, qp.ctypes.data, qv.ctypes.data, 1,
+                                       self._w_bm25, self._w_sim, k, ids.ctypes.data, vals.ctypes.data, None, _lib.current_stream_ptr()))
+            return ids, vals
         qp = np.zeros(nq + 1, dtype=np.int32)
         qt: List[int] = []
         qw: List[float] = []

@@ -113,11 +113,14 @@ def query_section(device):
         ids, vals = eng.score_topk(qs[s:s + chunk], qv[s:s + chunk], TOPK)
     torch.cuda.synchronize()
     batched = NQ / (time.perf_counter() - t0)
+    for i in range(8):
+        eng.score_topk(qs[i:i + 1], qv[i:i + 1], TOPK)                # warm-up of the one-query path (first launch loads its kernels)
+    n_single = 256
     t0 = time.perf_counter()
-    for i in range(64):
+    for i in range(n_single):
         eng.score_topk(qs[i:i + 1], qv[i:i + 1], TOPK)
     torch.cuda.synchronize()
-    single = 64 / (time.perf_counter() - t0)
+    single = n_single / (time.perf_counter() - t0)
     # CPU port on a bounded sample (vectorised numpy BM25 + fma-chain similarity + stable sort)
     e = bm.export()
     nq_cpu = 4
