@@ -747,7 +747,7 @@ constexpr int S1_MAX_DIM = 768;
 constexpr int S1_THREADS = 128;
 constexpr int S1_SLOTS = 256;
 constexpr int S1_MIN_DOCS = 8192;
-constexpr int S1_LDS_TERMS = 5120;   // (term, tf) entries of one workgroup's 128 documents staged in LDS (40 per document)
+constexpr int S1_LDS_TERMS = 6144;   // term ids of one workgroup's 128 documents staged in LDS (48 per document)
 constexpr int S1_GROUPS = 4096;      // at most this many document groups (a group = 64 * gw consecutive documents, one wave of search1_combine_kernel)
 
 struct Search1Query {            // passed by value: 3.3 KB of the 4 KB kernel-argument segment
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
                                                                    double* __restrict__ bm_out, float* __restrict__ sim_out,
                                                                    Search1State* __restrict__ st) {
     __shared__ int32_t sterm[S1_LDS_TERMS];
-    __shared__ uint16_t stfe[S1_LDS_TERMS], sdoc[S1_LDS_TERMS];
+    __shared__ int sptr[S1_THREADS + 1];
     __shared__ int32_t stf[S1_MAX_TERMS][S1_THREADS];          // tf of query term j in this thread's document (0 = absent)
     const int tid = threadIdx.x;
     const int64_t d = (int64_t)blockIdx.x * S1_THREADS + tid;
@@ -817,47 +817,47 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
     };
     request(va, 0);
     // ---- BM25 (webui.py:139-170), the arithmetic of bm25_score_kernel.  The (term, tf) lists of a workgroup's documents are one
-    // contiguous span of the document-major CSR: it is staged in LDS with coalesced loads together with an entry -> document map,
-    // then walked ONCE, coalesced: a lane compares its entry with the (scalar) query terms; a match -- at most nt per document --
-    // records the entry's tf in the slot of (query term, entry's document).
+    // contiguous span of the document-major CSR: its term ids are staged in LDS with coalesced loads, then walked ONCE, coalesced:
+    // a lane compares its entry with the (scalar) query terms; on a match -- at most nt per document -- it finds the entry's
+    // document by bisection of the 128 start offsets and records the entry's tf in the slot of (query term, document).
+    // (Measured alternatives, all within 2 us of each other at ~33 us for the kernel: every thread walking its own list from memory
+    // or from LDS; a staged entry -> document map with 16-bit LDS stores was slower, 50 us.)
     const int64_t d_first = (int64_t)blockIdx.x * S1_THREADS;
     const int64_t d_last = d_first + S1_THREADS < D ? d_first + S1_THREADS : D;
     const int64_t b0 = ptr[d_first], e0 = ptr[d_last];
     const bool staged = e0 - b0 <= S1_LDS_TERMS;
     const int nspan = staged ? (int)(e0 - b0) : 0;
     for (int i0 = 0; i0 < nspan; i0 += 4 * S1_THREADS) {
-        int32_t t4[4], f4[4];
+        int32_t t4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * S1_THREADS + tid;
             t4[u] = i < nspan ? term[b0 + i] : 0;
-            f4[u] = i < nspan ? tf[b0 + i] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * S1_THREADS + tid;
-            if (i < nspan) {
-                sterm[i] = t4[u];
-                stfe[i] = (uint16_t)(f4[u] < 65535 ? f4[u] : 65535);       // 65535 = "read the exact tf from memory"
-            }
+            if (i < nspan) sterm[i] = t4[u];
         }
     }
     for (int j = 0; j < Q.nt; ++j) stf[j][tid] = 0;
     const int64_t b = ptr[dd], e = ptr[dd + 1];
-    if (staged && valid) {
-#pragma clang loop vectorize(disable) unroll(disable)
-        for (int i = (int)(b - b0); i < (int)(e - b0); ++i) sdoc[i] = (uint16_t)tid;
-    }
+    sptr[tid] = valid ? (int)(b - b0) : (int)(e0 - b0);         // where this thread's document starts inside the staged span (threads past D: nowhere)
+    if (tid == 0) sptr[S1_THREADS] = (int)(e0 - b0);
     const double dlv = (double)dl[dd];
     __syncthreads();
     if (staged) {
-#pragma clang loop vectorize(disable) unroll(disable)
         for (int i = tid; i < nspan; i += S1_THREADS) {
             const int32_t ti = sterm[i];
             for (int j = 0; j < Q.nt; ++j)
                 if (ti == Q.terms[j]) {
-                    const int f = stfe[i];
-                    stf[j][sdoc[i]] = f < 65535 ? f : tf[b0 + i];
+                    int lo = 0, hi = S1_THREADS;            // largest lo with sptr[lo] <= i (an empty document shares its start with the next)
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (sptr[mid] <= i) lo = mid;
+                        else hi = mid;
+                    }
+                    stf[j][lo] = tf[b0 + i];
                 }
         }
         __syncthreads();
