@@ -93,8 +93,10 @@ def test_gen_cfeatures_cli_builds_and_extends_the_feature_index(tmp_path, monkey
     # the same image encodes to the same row whatever batch it was in
     r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "2000-01-01", "--batch", "8"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    idx2 = Similarity.load("charactor-featues-idx")
-    assert len(idx2) == 14 and os.path.exists("charactor-featues-idx.bak")
+    # --after writes a NEW revision (gen_cfeatures.py:354-370): charactor-featues-idx stays, charactor-featues-idx1 = old rows + new rows
+    assert len(Similarity.load("charactor-featues-idx")) == 7
+    idx2 = Similarity.load("charactor-featues-idx1")
+    assert len(idx2) == 14
     m2 = idx2.matrix()
     p2 = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
     assert p2[:7] == paths
@@ -104,7 +106,7 @@ def test_gen_cfeatures_cli_builds_and_extends_the_feature_index(tmp_path, monkey
     # --workers: multi-process decode to uint8, normalisation on the device -- the same features again
     r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "2000-01-01", "--batch", "4", "--workers", "2"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    m3 = Similarity.load("charactor-featues-idx").matrix()
+    m3 = Similarity.load("charactor-featues-idx2").matrix()
     p3 = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
     assert len(p3) == 21
     for i, p in enumerate(paths):
