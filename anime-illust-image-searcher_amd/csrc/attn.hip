@@ -119,17 +119,40 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
     }
 }
 
+// Softmax WITHOUT a running maximum (the default path).  softmax(S) V = (sum_j 2^S_j V_j) / (sum_j 2^S_j) whatever the scale, and
+// P = 2^S is kept in bf16 / fp32, whose exponent range is the same 8 bits: as long as the row's unnormalised sum l stays inside
+// [2^-100, 2^126] nothing overflows, and everything that underflows (S < -126) weighs less than 2^-16 of the row -- below the
+// 2^-9 rounding of P itself.  So a tile is 32 v_exp + 32 v_add + 16 v_cvt_pk per wave and nothing else: no maximum (17 v_max3),
+// no subtraction (32 v_sub), no rescale of O (32 v_mul + an exp) -- ~460 VALU issue cycles per 64-key tile against 512 of MFMA,
+// where the classic step above costs ~880.  Scores are log2-domain dot products of LayerNormed activations (|S| of a few tens);
+// a row whose sum does leave the window is detected at the end (attn_kernel) and the workgroup repeats the block with the
+// classic per-tile maximum, which cannot overflow.
 template <bool F16, int HD>
-__global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                   const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
-                                                   int tokens, int tokens_pad, int qblocks, int out_stride) {
+__device__ __forceinline__ void softmax_nomax(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& l_run) {
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sacc[g][i]);
+            if (i & 1) lsum1 += p; else lsum0 += p;
+            pf[g][i >> 3][i & 7] = to_op<F16>(p);
+        }
+    l_run += lsum0 + lsum1;
+}
+
+// CLASSIC: online softmax with the per-tile running maximum (softmax_tile); otherwise softmax_nomax.  Returns true when the
+// fast path's row sum left its safe window (nothing is stored then).
+template <bool F16, int HD, bool CLASSIC>
+__device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                          const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
+                                          int qblocks, int out_stride) {
     using G = Geo<HD>;
     constexpr int KS = G::KS, K_BYTES = G::K_BYTES, V_BYTES = G::V_BYTES, V_BASE = G::V_BASE;
     // iteration t multiplies K(t) (slot t & 1) and V(t-1) (slot (t-1) % 3) while tile t+1 is written: K(t+1)
     // over K(t-1), V(t+1) over V(t-2), both last read before the previous barrier.  Two K and three V^T
     // slots = 44.5 KB, so three workgroups (three waves per SIMD at 148 VGPRs) share a CU and one wave's
     // softmax (VALU) runs under the others' MFMAs.
-    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware work id: workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
@@ -207,7 +230,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     }
     if (nkv == 1 && masked_tail) s_tile<true, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
     else s_tile<false, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
-    softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+    if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+    else softmax_nomax<F16, HD>(sacc, pf, l_run);
     if (nkv > 1) {
         attn_write(1, 1);
     }
@@ -222,7 +246,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
         if (t + 1 == nkv && masked_tail) s_tile<true, F16, HD>(kt, t * KV, tokens, r, h, qf, sacc);
         else s_tile<false, F16, HD>(kt, t * KV, tokens, r, h, qf, sacc);
         pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
-        softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+        if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+        else softmax_nomax<F16, HD>(sacc, pf, l_run);
         if (t + 1 < nkv) {
             attn_write((t + 1) & 1, vnxt);
         }
@@ -236,6 +261,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + r;
+    if constexpr (!CLASSIC) {
+        // 2^-100 < l < 2^126 (a NaN fails both comparisons): inside it the fast path is exact to bf16 rounding, see softmax_nomax
+        if (!(l_tot > 7.888609052210118e-31f && l_tot < 8.507059173023462e37f)) return true;
+    }
     if (qi < tokens) {
         bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
 #pragma unroll
@@ -246,6 +275,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q,
                     pack4<F16>(o[blk][4 * g4] * inv, o[blk][4 * g4 + 1] * inv, o[blk][4 * g4 + 2] * inv, o[blk][4 * g4 + 3] * inv);
             }
     }
+    return false;
+}
+
+template <bool F16, int HD>
+__global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                   const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
+                                                   int tokens, int tokens_pad, int qblocks, int out_stride, int classic) {
+    __shared__ __attribute__((aligned(16))) char smem[Geo<HD>::LDS_BYTES];
+    if (classic) {              // HIPTS_ATTN_CLASSIC=1: the per-tile maximum everywhere (A/B runs; the fallback's own test)
+        attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+        return;
+    }
+    const bool bad = attn_body<F16, HD, false>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+    // a wave whose row sum left the window stored nothing; the workgroup (its waves stage K / V^T together) repeats the block classically
+    if (__syncthreads_or(bad ? 1 : 0)) attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
 }
 
 }  // namespace
@@ -258,12 +302,13 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     const int qtiles = (tokens + 31) / 32;
     const int qblocks = (qtiles + 3) / 4;
     const int grid = batch * heads * qblocks;
+    static const int classic = (getenv("HIPTS_ATTN_CLASSIC") && atoi(getenv("HIPTS_ATTN_CLASSIC"))) ? 1 : 0;
     if (head_dim == 64) {
-        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
-        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
+        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
     } else {
-        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
-        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost);
+        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
     }
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;

@@ -1149,6 +1149,30 @@ extern "C" int hiptsdbg_gemm8_run(int M, int N, int K, const float* a_f32, const
     return HIPTS_OK;
 }
 
+// Test entry (tests/test_gpu_attention.py): the attention kernel alone on caller-supplied operands.  q, k: 16-bit patterns
+// [batch * heads][tokens_pad][head_dim] (q already scaled by head_dim^-0.5 * log2 e, padding rows zero), vT: [batch * heads][head_dim][tokens_pad];
+// out: 16-bit patterns [batch][tokens][heads * head_dim].
+extern "C" int hiptsdbg_attention_run(const uint16_t* q, const uint16_t* k, const uint16_t* vT, uint16_t* out_host, int batch, int heads, int tokens,
+                                      int tokens_pad, int head_dim, int f16) {
+    HIPTS_REQUIRE(q && k && vT && out_host && batch >= 1 && heads >= 1 && tokens >= 1, "hiptsdbg_attention_run: bad arguments");
+    HIPTS_TRY(use_device(0));
+    const size_t nqk = (size_t)batch * heads * tokens_pad * head_dim, nout = (size_t)batch * tokens * heads * head_dim;
+    DevBuf dq, dk, dv, dout;
+    HIPTS_TRY(dq.alloc(nqk * 2));
+    HIPTS_TRY(dk.alloc(nqk * 2));
+    HIPTS_TRY(dv.alloc(nqk * 2));
+    HIPTS_TRY(dout.alloc(nout * 2));
+    HIPTS_TRY(upload(dq.p, q, nqk * 2));
+    HIPTS_TRY(upload(dk.p, k, nqk * 2));
+    HIPTS_TRY(upload(dv.p, vT, nqk * 2));
+    HIPTS_HIP(hipMemset(dout.p, 0, nout * 2));
+    HIPTS_TRY(launch_attention(dq.as<bf16_t>(), dk.as<bf16_t>(), dv.as<bf16_t>(), dout.as<bf16_t>(), batch, heads, tokens, tokens_pad, f16 != 0, nullptr,
+                               head_dim, 0));
+    HIPTS_HIP(hipDeviceSynchronize());
+    HIPTS_HIP(hipMemcpy(out_host, dout.p, nout * 2, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}
+
 // Development aid: copy one workspace buffer of the last forward to the host (tools/determinism.py).
 extern "C" int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes) {
     HIPTS_REQUIRE(h && name && out_host && bytes, "null argument");

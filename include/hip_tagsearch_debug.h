@@ -30,6 +30,11 @@ int hiptsdbg_gemm8_run(int M, int N, int K, const float* a_f32, const float* w_f
 /* Copies a named workspace tensor of the last forward ("x", "xn", "q", "k", "vT", "att", "hmid") to the host. */
 int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes);
 
+/* The attention kernel alone: q, k 16-bit patterns [batch * heads][tokens_pad][head_dim] (q pre-scaled by head_dim^-0.5 * log2 e, rows past
+ * `tokens` zero), vT [batch * heads][head_dim][tokens_pad]; out 16-bit patterns [batch][tokens][heads * head_dim].  f16: IEEE half operands. */
+int hiptsdbg_attention_run(const uint16_t* q, const uint16_t* k, const uint16_t* vT, uint16_t* out_host, int batch, int heads, int tokens,
+                           int tokens_pad, int head_dim, int f16);
+
 /* One-query search path (hipts_search with nq == 1): how many candidates its threshold step collected for the last query and
  * whether the ranking used them (1) or fell through to the exact radix select (0). */
 int hiptsdbg_search1_last(hipts_bm25_t* h, uint32_t* candidates, uint32_t* took_candidate_path);
