@@ -14,6 +14,8 @@
 // i%64), dot products are 5 fused multiply-adds + a 6-step xor butterfly, control flow is
 // wave-uniform.  Bound by dependent-load latency (syn1neg row gather, cum_table search), not by
 // HBM or MFMA.
+#include <vector>
+
 #include "common.h"
 
 using namespace hipts;
@@ -143,6 +145,121 @@ __global__ __launch_bounds__(256) void d2v_infer_kernel(const float* __restrict_
         if (lane + 64 * c < dim) out[doc * dim + lane + 64 * c] = v[c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training (genmodel.py:159-162: Doc2Vec(vector_size=300, window=50, min_count=1, workers=1, dm=0), build_vocab, train(epochs=100)).
+// One document's pass = the inference step above PLUS the hidden-layer update syn1neg[target] += g * doc_vector
+// (doc2vec_inner.pyx::fast_document_dbow_neg with learn_hidden = 1), the document vector updated in place in the table.
+// A job's alpha (word2vec.py::_get_next_alpha): alpha0 - (alpha0 - min_alpha) * (epoch + first_doc_of_job / ndocs) / epochs.
+//   SEQUENTIAL (mode 0)  one wavefront walks every document of every epoch in corpus order -- the reference's workers=1
+//                        semantics; bit-identical to oracle/csrc/oracle.c::orc_d2v_train.  For small corpora and parity.
+//   PARALLEL (mode 1)    a wavefront per document, the corpus in chunks of HIPTS_D2V_CHUNK (default 2048) documents per launch:
+//                        documents of a chunk train concurrently against the hidden layer as the chunks before left it, their
+//                        own updates of it are float atomic adds (gensim's worker threads race with plain stores, which works
+//                        while collisions are rare; with thousands of concurrent documents on a 10 k-word vocabulary plain
+//                        stores lose nearly every update -- measured: neighbour purity at chance).  Not reproducible run to
+//                        run; its quality is judged downstream (tests/test_gpu_d2v_train.py).
+// ---------------------------------------------------------------------------------------------
+template <int EPL, bool ATOMIC>
+__device__ __forceinline__ void train_document(float* __restrict__ syn1neg, const uint32_t* __restrict__ cum_table,
+                                               const uint32_t* __restrict__ sample_int, int64_t V, int dim, const int32_t* __restrict__ words,
+                                               int64_t wb, int64_t we, float* __restrict__ vrow, uint64_t lcg0, float a, int negative,
+                                               double exp_scale, const float* exp_table, uint32_t cum_last, int lane) {
+    float v[EPL], work[EPL], rw[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) v[c] = (lane + 64 * c < dim) ? vrow[lane + 64 * c] : 0.0f;
+    uint64_t next_random = uniform64(lcg0);
+    for (int64_t i = wb; i < we; ++i) {
+        const int32_t w = __builtin_amdgcn_readfirstlane(words[i]);
+        if (w < 0 || w >= V) continue;
+        if (sample_int) {
+            const uint64_t r = next_random >> 16;
+            next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+            if ((uint64_t)sample_int[w] < r) continue;
+        }
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) work[c] = 0.0f;
+        for (int d = 0; d < negative + 1; ++d) {
+            uint32_t target;
+            float label;
+            if (d == 0) {
+                target = (uint32_t)w;
+                label = 1.0f;
+            } else {
+                const uint32_t x = (uint32_t)(next_random >> 16) % cum_last;
+                target = __builtin_amdgcn_readfirstlane(bisect_left_wave(cum_table, x, (uint32_t)V, lane));
+                next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                if (target == (uint32_t)w) continue;
+                label = 0.0f;
+            }
+            float* __restrict__ row = syn1neg + (int64_t)target * dim;
+            float p = 0.0f;
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) {
+                rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
+                p = fmaf(v[c], rw[c], p);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) p = p + __shfl_xor(p, m);
+            float f = p;
+            if (f <= -(float)MAX_EXP || f >= (float)MAX_EXP) continue;
+            f = exp_table[(int)((double)(f + (float)MAX_EXP) * exp_scale)];
+            const float g = (label - f) * a;
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) {
+                work[c] = fmaf(g, rw[c], work[c]);                                   // work += g * syn1neg[target]
+                if (lane + 64 * c < dim) {                                           // syn1neg[target] += g * doc   (learn_hidden)
+                    if (ATOMIC) unsafeAtomicAdd(&row[lane + 64 * c], g * v[c]);      // concurrent documents: no update is lost
+                    else row[lane + 64 * c] = fmaf(g, v[c], rw[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) v[c] = v[c] + work[c];
+    }
+#pragma unroll
+    for (int c = 0; c < EPL; ++c)
+        if (lane + 64 * c < dim) vrow[lane + 64 * c] = v[c];
+}
+
+__device__ __forceinline__ float job_alpha(int epoch, int64_t job_first, int64_t ndocs, int epochs, float alpha0, float min_alpha) {
+    const double progress = ((double)epoch + (double)job_first / (double)ndocs) / (double)epochs;
+    double al = (double)alpha0 - ((double)alpha0 - (double)min_alpha) * progress;
+    if (al < (double)min_alpha) al = (double)min_alpha;
+    return (float)al;
+}
+
+// mode 1: grid over documents [doc0, doc1) of ONE epoch.  mode 0: one wavefront (grid 1, 64 threads), epochs [epoch0, epoch1).
+template <int EPL, bool SEQUENTIAL>
+__global__ __launch_bounds__(256) void d2v_train_kernel(float* __restrict__ syn1neg, float* __restrict__ doc_vectors,
+                                                        const uint32_t* __restrict__ cum_table, const uint32_t* __restrict__ sample_int,
+                                                        int64_t V, int dim, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ words,
+                                                        const int64_t* __restrict__ job_first, int64_t ndocs, int epoch0, int epoch1, int epochs,
+                                                        float alpha0, float min_alpha, int negative, double exp_scale, uint64_t seed,
+                                                        const float* __restrict__ exp_table_g, int64_t doc0, int64_t doc1) {
+    __shared__ float exp_table[EXP_TABLE_SIZE];
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += blockDim.x) exp_table[i] = exp_table_g[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t cum_last = cum_table[V - 1];
+    if (SEQUENTIAL) {
+        if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+        for (int e = epoch0; e < epoch1; ++e)
+            for (int64_t doc = 0; doc < ndocs; ++doc) {
+                const float a = job_alpha(e, job_first[doc], ndocs, epochs, alpha0, min_alpha);
+                const uint64_t lcg0 = splitmix64(seed + (uint64_t)e * (uint64_t)ndocs + (uint64_t)doc) & LCG_MOD;
+                train_document<EPL, false>(syn1neg, cum_table, sample_int, V, dim, words, doc_ptr[doc], doc_ptr[doc + 1], doc_vectors + doc * dim, lcg0,
+                                           a, negative, exp_scale, exp_table, cum_last, lane);
+            }
+    } else {
+        const int64_t doc = doc0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (doc >= doc1) return;
+        const float a = job_alpha(epoch0, job_first[doc], ndocs, epochs, alpha0, min_alpha);
+        const uint64_t lcg0 = splitmix64(seed + (uint64_t)epoch0 * (uint64_t)ndocs + (uint64_t)doc) & LCG_MOD;
+        train_document<EPL, true>(syn1neg, cum_table, sample_int, V, dim, words, doc_ptr[doc], doc_ptr[doc + 1], doc_vectors + doc * dim, lcg0, a,
+                                  negative, exp_scale, exp_table, cum_last, lane);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,6 +349,96 @@ int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words
         HIPTS_HIP(hipMemcpyAsync(out, out_dev, (size_t)ndocs * h->dim * 4, hipMemcpyDeviceToHost, s));
     }
     HIPTS_HIP(hipStreamSynchronize(s));   // staging buffers are reused by the next call
+    return HIPTS_OK;
+}
+
+int hipts_d2v_train(const uint32_t* cum_table, const uint32_t* sample_int, int64_t vocab, int dim, int negative, double exp_scale,
+                    const int64_t* doc_ptr, const int32_t* words, int64_t ndocs, float* doc_vectors, float* syn1neg, int epochs,
+                    float alpha, float min_alpha, uint64_t seed, int batch_words, int mode, int device, void* stream) {
+    HIPTS_REQUIRE(cum_table && doc_ptr && doc_vectors && syn1neg && vocab >= 1 && vocab < (1ll << 31) && ndocs >= 1 && epochs >= 1,
+                  "hipts_d2v_train: bad arguments");
+    HIPTS_REQUIRE(dim >= 1 && dim <= 512 && negative >= 0 && negative <= 64 && batch_words >= 1 && (mode == 0 || mode == 1),
+                  "hipts_d2v_train: dim in [1, 512], negative in [0, 64], batch_words >= 1, mode 0 (sequential) or 1 (parallel)");
+    HIPTS_REQUIRE(cum_table[vocab - 1] > 0, "hipts_d2v_train: cum_table[-1] must be positive");
+    const int64_t nw = doc_ptr[ndocs];
+    HIPTS_REQUIRE(doc_ptr[0] == 0 && nw >= 0 && (words || nw == 0), "hipts_d2v_train: bad CSR");
+    HIPTS_TRY(use_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    // jobs (word2vec.py::_job_producer): consecutive documents while their raw word counts fit batch_words
+    std::vector<int64_t> job_first((size_t)ndocs);
+    {
+        int64_t first = 0, jw = 0;
+        for (int64_t d = 0; d < ndocs; ++d) {
+            const int64_t n = doc_ptr[d + 1] - doc_ptr[d];
+            if (d == 0 || jw + n > batch_words) {
+                first = d;
+                jw = 0;
+            }
+            jw += n;
+            job_first[(size_t)d] = first;
+        }
+    }
+    float table[EXP_TABLE_SIZE];
+    for (int i = 0; i < EXP_TABLE_SIZE; ++i) {
+        const float e = (float)exp((i / (float)EXP_TABLE_SIZE * 2 - 1) * MAX_EXP);
+        table[i] = (float)(e / (e + 1));
+    }
+    DevBuf d_syn, d_dv, d_cum, d_si, d_ptr, d_words, d_job, d_exp;
+    HIPTS_TRY(d_syn.alloc((size_t)vocab * dim * 4));
+    HIPTS_TRY(d_dv.alloc((size_t)ndocs * dim * 4));
+    HIPTS_TRY(d_cum.alloc((size_t)vocab * 4));
+    HIPTS_TRY(d_ptr.alloc((size_t)(ndocs + 1) * 8));
+    HIPTS_TRY(d_words.alloc((size_t)(nw > 0 ? nw : 1) * 4));
+    HIPTS_TRY(d_job.alloc((size_t)ndocs * 8));
+    HIPTS_TRY(d_exp.alloc(sizeof(table)));
+    HIPTS_TRY(upload(d_syn.p, syn1neg, (size_t)vocab * dim * 4, s));
+    HIPTS_TRY(upload(d_dv.p, doc_vectors, (size_t)ndocs * dim * 4, s));
+    HIPTS_TRY(upload(d_cum.p, cum_table, (size_t)vocab * 4, s));
+    HIPTS_TRY(upload(d_ptr.p, doc_ptr, (size_t)(ndocs + 1) * 8, s));
+    if (nw) HIPTS_TRY(upload(d_words.p, words, (size_t)nw * 4, s));
+    HIPTS_TRY(upload(d_job.p, job_first.data(), (size_t)ndocs * 8, s));
+    HIPTS_TRY(upload(d_exp.p, table, sizeof(table), s));
+    if (sample_int) {
+        HIPTS_TRY(d_si.alloc((size_t)vocab * 4));
+        HIPTS_TRY(upload(d_si.p, sample_int, (size_t)vocab * 4, s));
+    }
+    const int epl = (dim + 63) / 64;
+#define D2V_TRAIN(E, SEQ, GRID, THREADS, E0, E1, D0, D1)                                                                                              \
+    d2v_train_kernel<E, SEQ><<<GRID, THREADS, 0, s>>>(d_syn.as<float>(), d_dv.as<float>(), d_cum.as<uint32_t>(),                               \
+                                                      sample_int ? d_si.as<uint32_t>() : nullptr, vocab, dim, d_ptr.as<int64_t>(),              \
+                                                      d_words.as<int32_t>(), d_job.as<int64_t>(), ndocs, E0, E1, epochs, alpha, min_alpha,      \
+                                                      negative, exp_scale, seed, d_exp.as<float>(), D0, D1)
+#define D2V_TRAIN_EPL(SEQ, GRID, THREADS, E0, E1, D0, D1)                 \
+    switch (epl) {                                                \
+        case 1: D2V_TRAIN(1, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        case 2: D2V_TRAIN(2, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        case 3: D2V_TRAIN(3, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        case 4: D2V_TRAIN(4, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        case 5: D2V_TRAIN(5, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        case 6: D2V_TRAIN(6, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        case 7: D2V_TRAIN(7, SEQ, GRID, THREADS, E0, E1, D0, D1); break;  \
+        default: D2V_TRAIN(8, SEQ, GRID, THREADS, E0, E1, D0, D1); break; \
+    }
+    if (mode == 0) {
+        // one wavefront; a launch per epoch keeps each kernel bounded (a watchdog-safe few seconds even for mid-sized corpora)
+        for (int e = 0; e < epochs; ++e) {
+            D2V_TRAIN_EPL(true, 1, 64, e, e + 1, 0, ndocs);
+            HIPTS_LAUNCH_CHECK();
+        }
+    } else {
+        static const int64_t chunk = getenv("HIPTS_D2V_CHUNK") && atoll(getenv("HIPTS_D2V_CHUNK")) > 0 ? atoll(getenv("HIPTS_D2V_CHUNK")) : 2048;
+        for (int e = 0; e < epochs; ++e)
+            for (int64_t d0 = 0; d0 < ndocs; d0 += chunk) {
+                const int64_t d1 = d0 + chunk < ndocs ? d0 + chunk : ndocs;
+                D2V_TRAIN_EPL(false, ceil_div(d1 - d0, 4), 256, e, e + 1, d0, d1);
+                HIPTS_LAUNCH_CHECK();
+            }
+    }
+#undef D2V_TRAIN_EPL
+#undef D2V_TRAIN
+    HIPTS_HIP(hipMemcpyAsync(syn1neg, d_syn.p, (size_t)vocab * dim * 4, hipMemcpyDeviceToHost, s));
+    HIPTS_HIP(hipMemcpyAsync(doc_vectors, d_dv.p, (size_t)ndocs * dim * 4, hipMemcpyDeviceToHost, s));
+    HIPTS_HIP(hipStreamSynchronize(s));
     return HIPTS_OK;
 }
 

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "hipts_query_profile_name": [c_int, c_char_p, c_size_t],
     "hipts_d2v_create": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_int, POINTER(c_void_p)],
     "hipts_d2v_destroy": [c_void_p],
+    "hipts_d2v_train": [c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                        c_float, c_float, ctypes.c_uint64, c_int, c_int, c_int, c_void_p],
     "hipts_d2v_infer": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p,
                         c_int, c_void_p],
 }

@@ -193,6 +193,24 @@ def query_section(device):
             roof[tag].update({"dominant_kernel": d["kernel"], "achieved": d["achieved"], "frac": d["frac"], "avg_launch_us": d["avg_us"],
                               "kernel_time_per_query_us": sum(c["avg_us"] * c["launches"] for c in prof) / (NQ if tag == "batched" else 64)})
     # bytes one query costs on each path (for the batched path the index pass is shared by 32 queries)
+    # Doc2Vec PV-DBOW training (genmodel.py:159-162), parallel schedule: 20k documents x 5 epochs of the bench corpus
+    from hiptagsearch.d2v import Doc2Vec
+    n_tr, ep_tr = 20_000, 5
+    tr_docs = [[str(t) for t in terms[ptr[d]:ptr[d + 1]]] for d in range(n_tr)]
+    tm = Doc2Vec(vector_size=K, window=50, min_count=1, workers=1, dm=0, device=device)
+    tm.build_vocab(tr_docs)
+    tm.train(tr_docs[:256] + [[]] * (n_tr - 256), epochs=1, mode="parallel")               # warm-up (kernel load)
+    t0 = time.perf_counter()
+    tm.train(tr_docs, total_examples=n_tr, epochs=ep_tr, mode="parallel")
+    d2v_train = n_tr * ep_tr / (time.perf_counter() - t0)
+    n_trc, ep_trc = 200, 2
+    k2i, _, cum_c, si_c = od2v.build_vocab(tr_docs[:n_trc])
+    p_c = np.cumsum([0] + [len(d) for d in tr_docs[:n_trc]]).astype(np.int64)
+    i_c = np.array([k2i[t] for d in tr_docs[:n_trc] for t in d], dtype=np.int32)
+    syn_c, dv_c = np.zeros((len(k2i), K), np.float32), od2v.init_doc_vectors(n_trc, K)
+    t0 = time.perf_counter()
+    od2v.train(syn_c, dv_c, cum_c, si_c, p_c, i_c, epochs=ep_trc)
+    d2v_train_cpu = n_trc * ep_trc / (time.perf_counter() - t0)
     bytes_single = D * K * 4 + bm.nnz * 8 + D * (8 + 4 + 8 + 4) + D * 20 + D * 8
     bytes_batched = D * K * 4 / 32.0 + D * (8 * 3 + 4 + 4 + 20 + 8)
     return {"metric": "top-100 queries/sec over 100k-doc index (BM25 + 300-d index product, fused)",
@@ -202,6 +220,8 @@ def query_section(device):
                                             "note": "batched: one 120 MB index pass per 32 queries + per-query score rows (posting lists counted per launch in roofline)"},
             "cpu_port_qps": cpu_qps, "cpu_port_sample": "%d queries, numpy CSR BM25 + C fma-chain + lexsort, 1 thread" % nq_cpu,
             "d2v_infer_docs_per_s": d2v_gpu, "d2v_sample": "%d docs x 100 epochs, host buffers in/out" % n_gpu,
+            "d2v_train_doc_epochs_per_s": d2v_train, "d2v_train_sample": "%d docs x %d epochs, parallel schedule, host arrays in/out" % (n_tr, ep_tr),
+            "d2v_train_cpu_port_doc_epochs_per_s": d2v_train_cpu, "d2v_train_cpu_sample": "%d docs x %d epochs, C oracle, 1 thread (reference: workers=1)" % (n_trc, ep_trc),
             "d2v_cpu_port_docs_per_s": d2v_cpu, "d2v_cpu_sample": "%d docs, C oracle, 1 thread (reference: workers=1)" % n_cpu}
 
 

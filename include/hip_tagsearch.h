@@ -336,6 +336,22 @@ int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words
                     const float* v0, const uint64_t* seeds, int epochs, float alpha, float min_alpha,
                     float* out, int out_memspace, void* stream);
 
+/* Doc2Vec PV-DBOW TRAINING.   Replaces  Doc2Vec(vector_size=300, window=50, min_count=1, workers=1, dm=0) / build_vocab /
+ * train(epochs=100)                                                                       genmodel.py:159-162.
+ * The vocabulary statistics (build_vocab: cum_table with ns_exponent 0.75, sample_int for sample = 1e-3, both over the
+ * vocabulary sorted by descending count) are prepared by the caller (hiptagsearch/d2v.py::Doc2Vec.build_vocab); documents
+ * arrive in CSR form over vocabulary indices.  syn1neg float32 [vocab][dim] (gensim starts it at zero) and doc_vectors
+ * float32 [ndocs][dim] (gensim: uniform in +-1/dim) are HOST arrays updated in place.  seed replaces the model's hidden
+ * RandomState: the 48-bit LCG state of (epoch, document) is splitmix64(seed + epoch * ndocs + document).
+ * mode 0: sequential -- every document of every epoch in corpus order on one wavefront (the reference's workers=1 semantics;
+ *         reproducible, bit-identical to the CPU oracle); for parity and small corpora.
+ * mode 1: parallel -- a wavefront per document, launches of 2048 documents (HIPTS_D2V_CHUNK): the documents of a launch train
+ *         concurrently, their hidden-layer updates are float atomic adds (no update lost, order free); the throughput mode,
+ *         not reproducible bit for bit. */
+int hipts_d2v_train(const uint32_t* cum_table, const uint32_t* sample_int, int64_t vocab, int dim, int negative, double exp_scale,
+                    const int64_t* doc_ptr, const int32_t* words, int64_t ndocs, float* doc_vectors, float* syn1neg, int epochs,
+                    float alpha, float min_alpha, uint64_t seed, int batch_words, int mode, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,79 @@ void orc_d2v_infer(const float* syn1neg, const uint32_t* cum_table, int64_t V, c
                   v0 + d * dim, seeds[d], epochs, alpha, min_alpha, negative, exp_scale, table, out + d * dim);
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * orc_d2v_train -- gensim Doc2Vec(dm=0).train as genmodel.py:159-162 runs it (vector_size=300, window=50, min_count=1,
+ * workers=1, dm=0, epochs=100; defaults negative=5, hs=0, sample=1e-3, alpha=0.025, min_alpha=1e-4, dbow_words=0).
+ * PARITY UNPINNED (gensim 4.3.3 absent): restated from doc2vec.py / doc2vec_inner.pyx::train_document_dbow ->
+ * fast_document_dbow_neg (learn_doctags = learn_hidden = 1, lockf = 1) and word2vec.py::_train_epoch / _get_next_alpha:
+ *   - ONE worker: documents are visited in corpus order, every epoch;
+ *   - jobs: consecutive documents are batched while their raw word counts fit batch_words (10000); a job's alpha is
+ *     alpha0 - (alpha0 - min_alpha) * (epoch + documents_pushed_before_the_job / total_documents) / epochs, not below min_alpha;
+ *   - per document: the LCG state is drawn afresh (gensim: two draws from the model's RandomState; here the pure function
+ *     splitmix64(seed + epoch * ndocs + doc), the same explicit-seed device as orc_d2v_infer);
+ *   - per kept word (in-vocabulary, surviving sub-sampling): fast_document_dbow_neg as in inference, PLUS the hidden-layer
+ *     update syn1neg[target] += g * doc_vector (with the document vector as it was before this word's own update).
+ * The float32 operation order is the one shared with the HIP kernel: dot = dot_wave64; saxpy element-wise fmaf.
+ * syn1neg [V][dim] and doc_vectors [ndocs][dim] are updated in place.
+ */
+void orc_d2v_train(float* syn1neg, float* doc_vectors, const uint32_t* cum_table, int64_t V, const uint32_t* sample_int, int dim,
+                   const int64_t* doc_ptr, const int32_t* words, int64_t ndocs, int epochs, float alpha0, float min_alpha,
+                   int negative, double exp_scale, uint64_t seed, int batch_words) {
+    const uint64_t MOD = 281474976710655ULL;
+    float table[ORC_EXP_TABLE_SIZE];
+    orc_exp_table(table);
+    float* work = (float*)malloc(sizeof(float) * (size_t)dim);
+    for (int e = 0; e < epochs; ++e) {
+        int64_t job_first = 0;          /* first document of the current job */
+        int64_t job_words = 0;
+        float a = 0.0f;
+        for (int64_t d = 0; d < ndocs; ++d) {
+            const int64_t nw = doc_ptr[d + 1] - doc_ptr[d];
+            if (d == 0 || job_words + nw > batch_words) {      /* a new job starts with this document */
+                job_first = d;
+                job_words = 0;
+                double progress = ((double)e + (double)job_first / (double)ndocs) / (double)epochs;
+                double al = (double)alpha0 - ((double)alpha0 - (double)min_alpha) * progress;
+                if (al < (double)min_alpha) al = (double)min_alpha;
+                a = (float)al;
+            }
+            job_words += nw;
+            float* v = doc_vectors + d * dim;
+            uint64_t next_random = splitmix64(seed + (uint64_t)e * (uint64_t)ndocs + (uint64_t)d) & MOD;
+            for (int64_t i = doc_ptr[d]; i < doc_ptr[d + 1]; ++i) {
+                int32_t w = words[i];
+                if (w < 0 || w >= V) continue;
+                if (sample_int) {
+                    uint64_t r = next_random >> 16;
+                    next_random = (next_random * 25214903917ULL + 11) & MOD;
+                    if ((uint64_t)sample_int[w] < r) continue;
+                }
+                memset(work, 0, sizeof(float) * (size_t)dim);
+                for (int t = 0; t < negative + 1; ++t) {
+                    uint32_t target;
+                    float label;
+                    if (t == 0) {
+                        target = (uint32_t)w;
+                        label = 1.0f;
+                    } else {
+                        target = bisect_left_u32(cum_table, (next_random >> 16) % cum_table[V - 1], 0, (uint64_t)V);
+                        next_random = (next_random * 25214903917ULL + 11) & MOD;
+                        if (target == (uint32_t)w) continue;
+                        label = 0.0f;
+                    }
+                    float* row = syn1neg + (int64_t)target * dim;
+                    float f = dot_wave64(v, row, dim);
+                    if (f <= -ORC_MAX_EXP || f >= ORC_MAX_EXP) continue;
+                    f = table[(int)((double)(f + (float)ORC_MAX_EXP) * exp_scale)];
+                    float g = (label - f) * a;
+                    for (int k = 0; k < dim; ++k) work[k] = fmaf(g, row[k], work[k]);     /* saxpy: work += g * syn1neg[target] */
+                    for (int k = 0; k < dim; ++k) row[k] = fmaf(g, v[k], row[k]);          /* learn_hidden: syn1neg[target] += g * doc */
+                }
+                for (int k = 0; k < dim; ++k) v[k] = v[k] + work[k];                       /* learn_doctags, lockf = 1 */
+            }
+        }
+    }
+    free(work);
+}

@@ -49,10 +49,10 @@ def test_tagging_genmodel_query_pipeline(tmp_path, monkeypatch):
     # index stage
     os.remove("tags-wd-tagger.txt")
     open("tags-wd-tagger.txt", "w").write("\n".join(lines) + "\n")
-    r = subprocess.run([sys.executable, os.path.join(PKG, "genmodel.py"), "--synthetic-d2v", "--epochs", "5"],
+    r = subprocess.run([sys.executable, os.path.join(PKG, "genmodel.py"), "--epochs", "5"],            # trains the Doc2Vec model (genmodel.py:159-162)
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    for f in ("doc2vec_index", "doc2vec_dictionary", "bm25_corpus", "bm25_idf", "bm25_avgdl", "bm25_D", "bm25_doc_lengths",
+    for f in ("doc2vec_model", "doc2vec_index", "doc2vec_dictionary", "bm25_corpus", "bm25_idf", "bm25_avgdl", "bm25_D", "bm25_doc_lengths",
               "tags-wd-tagger_doc2vec_idx.csv"):
         assert os.path.exists(f), f
     # query stage
