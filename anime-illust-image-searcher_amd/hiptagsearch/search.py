@@ -63,6 +63,7 @@ class SearchEngine:
         self.search_mode = search_mode
         self.compat_rerank = compat_rerank
         self.cindex = None                     # cfeatures.CharacterFeatureIndex for 'character oriented' mode
+        self.stats = {"queries": 0, "full_rank_fallbacks": 0}
         self._search_fn = _lib.load().hipts_search
         self._w_bm25, self._w_sim = c_double(BM25_WEIGHT), c_double(DOC2VEC_WEIGHT)
         # webui.py:623-646: path -> {tag: True} and path -> doc id, built from the same index file
@@ -149,6 +150,7 @@ class SearchEngine:
     # ---- webui.py:345-390 -----------------------------------------------------------------------
     def find_similar_documents(self, new_doc: str, topn: int = 50) -> List[Tuple[int, float]]:
         import torch
+        self.stats["queries"] += 1
         vec = self.normalize_and_apply_weight_doc2vec(new_doc)                        # :349
         qw, required, exclude = self.parse_bm25_query(new_doc)                        # :354-371
         D = len(self.index)
@@ -230,7 +232,12 @@ class SearchEngine:
         final += [(int(i), float(v)) for i, v in zip(rids, rvals) if int(i) not in top10_set]   # :217,225-237
         if k < D and not self._two_cut_points(final):
             # The gap filter looks for its *second* cut point anywhere in the ranked list.  It is almost
-            # always inside the first 1024 entries; if not, rank all D scores (host, rare path).
+            # always inside the first 1024 entries; if not, rank all D scores (host, rare path) -- counted in
+            # self.stats and announced once, so that a corpus on which it is NOT rare does not go unnoticed.
+            self.stats["full_rank_fallbacks"] += 1
+            if self.stats["full_rank_fallbacks"] == 1:
+                print("hiptagsearch: the result filter found no second cut point in the first %d ranks; ranking all %d scores on the "
+                      "host for this query (SearchEngine.stats counts these)" % (k, D))
             rf = rf_dev[0].cpu().numpy()
             if mx > 0:
                 rf = rf / mx

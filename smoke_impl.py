@@ -62,5 +62,5 @@ def run():
     elog, _ = EvaTagger(ecfg, ew, max_batch=2).forward_u8(eimgs)
     ewant = oeva.eva_forward(oeva.to_torch(ew), ovit.preprocess_u8_nhwc(eimgs), patch=ecfg["patch"], heads=ecfg["heads"]).numpy()
     eerr = float(np.abs(elog - ewant).max())
-    assert eerr <= 1e-2, "EVA02 logits differ from the oracle by %g" % eerr
+    assert eerr <= 1e-3, "EVA02 logits differ from the oracle by %g" % eerr       # IEEE-half operands (EvaTagger default)
     print("smoke ok: ViT max|dlogit| = %.2e, tag rows and top-50 identical to the oracle, CCIP max|df| = %.2e, EVA02 max|dlogit| = %.2e" % (err, cerr, eerr))

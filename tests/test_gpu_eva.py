@@ -3,12 +3,13 @@ torch-CPU oracle (oracle/eva.py; parity unpinned: timm and the weights are not a
 
 Tolerance: the north_star's 1e-3 on logits is stated for the ViT-B/16 contract model.  For this model the
 synthetic checkpoint (unit-variance LayerNorm outputs after every SwiGLU, 24 blocks of width 1024) makes the
-residual branches O(1), so 16-bit operand rounding reaches the logits at full size -- measured with bf16
-operands max |dlogit| 4.0e-3 (tiny) / 2.6e-2 (EVA02-L, logit rms 0.65), with IEEE-half operands 4.9e-4 /
-3.0e-3: the 8x ratio of the two mantissas, i.e. rounding only.  Bounds: bf16 1e-2 / 5e-2 and cosine(logits,
-oracle) >= 0.9995; half 1e-3 / 5e-3."""
+residual branches O(1), so 16-bit operand rounding reaches the logits at full size.  Measured (round 2, LayerNorms and RoPE
+folded into the GEMM epilogues): IEEE-half operands -- the DEFAULT of EvaTagger -- max |dlogit| 2.9e-4 (tiny) / 2.1e-3
+(EVA02-L, logit rms 0.65); bf16 operands 2.3e-3 / 1.7e-2: the 8x ratio of the two mantissas, i.e. rounding only.
+Bounds = measured + 20 %: half 5e-4 / 2.5e-3, bf16 4e-3 / 2.1e-2, and cosine(logits, oracle) >= 0.9995 (bf16) / 0.99999 (half)."""
 
-TOL = {"tiny": {0: 1e-2, 1: 1e-3}, "large": {0: 5e-2, 1: 5e-3}}
+TOL = {"tiny": {0: 4e-3, 1: 5e-4}, "large": {0: 2.1e-2, 1: 2.5e-3}}
+COS = {0: 0.9995, 1: 0.99999}
 
 
 def _cos(a, b):
@@ -38,7 +39,7 @@ def test_eva_tiny_matches_oracle(f16):
     err = np.abs(logits - want).max()
     print("EVA tiny (operand_f16=%d) max |logit error| = %.3e" % (f16, err))
     assert err <= TOL["tiny"][f16], err
-    assert _cos(logits, want) >= 0.9995
+    assert _cos(logits, want) >= COS[f16]
     np.testing.assert_allclose(probs, 1 / (1 + np.exp(-logits.astype(np.float64))), atol=2e-7)
     logits2, _ = model.forward(x)                                  # float32 NCHW entry point (tagging.py:174's tensor)
     assert np.abs(logits2 - want).max() <= TOL["tiny"][f16]
@@ -62,7 +63,10 @@ def test_eva02_large_448_matches_oracle(f16):
     err = np.abs(logits - want).max()
     print("EVA02-L/14@448 max |logit error| = %.3e (logit rms %.3f), %.1f GFLOP/image" % (err, np.sqrt((want ** 2).mean()), model.flops_per_image() / 1e9))
     assert err <= TOL["large"][f16], err
-    assert _cos(logits, want) >= 0.9995
+    assert _cos(logits, want) >= COS[f16]
+    if f16 == 1:                                                   # half operands are what EvaTagger runs unless told otherwise
+        dflt = EvaTagger(dict(synth.EVA02_L14_448), w, max_batch=2)
+        np.testing.assert_array_equal(dflt.forward_u8(imgs)[0], logits)
 
 
 def test_eva_missing_tensor_is_reported():
