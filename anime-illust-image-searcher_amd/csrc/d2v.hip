@@ -14,6 +14,8 @@
 // i%64), dot products are 5 fused multiply-adds + a 6-step xor butterfly, control flow is
 // wave-uniform.  Bound by dependent-load latency (syn1neg row gather, cum_table search), not by
 // HBM or MFMA.
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -47,6 +49,40 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t x) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
     return ((uint64_t)hi << 32) | lo;
+}
+
+// The dot product's cross-lane sum: p[l] + p[l ^ 32], then ^16, ^8, ^4, ^2, ^1 -- the order oracle/csrc/oracle.c::dot_wave64
+// defines.  Every stage adds each lane's value and its partner's (a + b on one side, b + a on the other: the same float), so any
+// way of fetching the partner gives the same bits; __shfl_xor fetches it through the LDS crossbar (ds_bpermute, ~100 cycles a
+// stage with its wait), these forms stay in the vector ALU: v_permlane32_swap / v_permlane16_swap for the two widest stages
+// (swap with a copy: one register then holds the lower, the other the upper partner of every pair), DPP for the rest
+// (row_ror:8; row_shl:4 | row_shr:4 under bank masks; quad_perm).  ~0.55 -> 0.3 us per step of the serial chain.
+__device__ __forceinline__ float wave_sum_butterfly(float p) {
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+        p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+        p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const int pi = __float_as_int(p);
+    p = p + __int_as_float(__builtin_amdgcn_update_dpp(pi, pi, 0x128, 0xf, 0xf, false));                 // row_ror:8  = lane ^ 8
+    {
+        const int qi = __float_as_int(p);
+        int t = __builtin_amdgcn_update_dpp(qi, qi, 0x104, 0xf, 0x5, false);                               // row_shl:4: lanes 0-3, 8-11 of a row read lane + 4
+        t = __builtin_amdgcn_update_dpp(t, qi, 0x114, 0xf, 0xa, false);                                    // row_shr:4: lanes 4-7, 12-15 read lane - 4
+        p = p + __int_as_float(t);
+    }
+    {
+        const int qi = __float_as_int(p);
+        p = p + __int_as_float(__builtin_amdgcn_update_dpp(qi, qi, 0x4e, 0xf, 0xf, false));              // quad_perm [2,3,0,1] = lane ^ 2
+    }
+    {
+        const int qi = __float_as_int(p);
+        p = p + __int_as_float(__builtin_amdgcn_update_dpp(qi, qi, 0xb1, 0xf, 0xf, false));              // quad_perm [1,0,3,2] = lane ^ 1
+    }
+    return p;
 }
 
 // bisect_left(a, x, 0, n): smallest i with a[i] >= x.  64-ary search: each lane probes the last
@@ -126,8 +162,7 @@ __global__ __launch_bounds__(256) void d2v_infer_kernel(const float* __restrict_
                     rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
                     p = fmaf(v[c], rw[c], p);
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) p = p + __shfl_xor(p, m);
+                p = wave_sum_butterfly(p);
                 float f = p;
                 if (f <= -(float)MAX_EXP || f >= (float)MAX_EXP) continue;
                 f = exp_table[(int)((double)(f + (float)MAX_EXP) * exp_scale)];
@@ -137,6 +172,226 @@ __global__ __launch_bounds__(256) void d2v_infer_kernel(const float* __restrict_
             }
 #pragma unroll
             for (int c = 0; c < EPL; ++c) v[c] = v[c] + work[c];
+        }
+        alpha -= alpha_delta;
+    }
+#pragma unroll
+    for (int c = 0; c < EPL; ++c)
+        if (lane + 64 * c < dim) out[doc * dim + lane + 64 * c] = v[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Planned inference (default).  d2v_infer_kernel above pays, per dot/axpy step, a 64-ary search of cum_table (three dependent
+// rounds of loads) and a dependent gather of the target row: ~2 us per step, ~30 ms for one document of 100 epochs -- the
+// latency of find_similar_documents' rerank (webui.py:198-199: ten documents re-inferred per query).  But the random stream does
+// not depend on the vector being trained: which words survive sub-sampling and which rows the negative samples hit follows
+// from the LCG alone.  So per epoch and chunk of words a wave
+//   1. walks the LCG (uniform, scalar): one entry per positive target, one raw draw per negative sample, into LDS;
+//   2. resolves all draws of the chunk AT ONCE, a lane per draw: modulo, bisect_left over cum_table (its first levels from a
+//      1024-entry coarse table in LDS), drops the samples that hit their own word, compacts;
+//   3. runs the serial chain over the compacted plan a WORD at a time: the (1 + negative) dot products of a word are
+//      independent (the vector changes only after the word), the next word's rows are already requested.
+// The arithmetic of a step and its order are those of d2v_infer_kernel: results are bit-identical (same tests).
+// ---------------------------------------------------------------------------------------------
+constexpr int PLAN_WORDS = 32;            // words per chunk
+constexpr int PLAN_MAX_NEG = 5;             // a word's group: 1 positive + up to 5 negative samples (gensim's default negative = 5)
+constexpr int PLAN_GROUP = 1 + PLAN_MAX_NEG;
+constexpr int PLAN_CAP = PLAN_WORDS * (1 + PLAN_MAX_NEG);     // 512 plan entries per wave
+constexpr int PLAN_COARSE = 1024;
+constexpr uint32_t PLAN_POS = 0x80000000u;
+
+__device__ __forceinline__ uint32_t bisect_left_coarse(const uint32_t* __restrict__ a, const uint32_t* coarse, uint32_t x, uint32_t n, uint32_t stride) {
+    // coarse[c] = a[min((c + 1) * stride, n) - 1]: the last element of block c.  Smallest block whose last element is >= x, then
+    // the smallest element >= x inside it: exactly bisect_left (a is non-decreasing); x above every element returns n.
+    const uint32_t nblk = (n + stride - 1) / stride;
+    uint32_t lo = 0, hi = nblk;
+    while (hi > lo) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (coarse[mid] >= x) hi = mid;
+        else lo = mid + 1;
+    }
+    if (lo == nblk) return n;
+    uint32_t b = lo * stride, e = b + stride < n ? b + stride : n;
+    while (e > b) {
+        const uint32_t mid = (b + e) >> 1;
+        if (a[mid] >= x) e = mid;
+        else b = mid + 1;
+    }
+    return b;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void d2v_infer_plan_kernel(const float* __restrict__ syn1neg, const uint32_t* __restrict__ cum_table,
+                                                             const uint32_t* __restrict__ sample_int, int64_t V, int dim,
+                                                             const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ words,
+                                                             int64_t ndocs, const float* __restrict__ v0, const uint64_t* __restrict__ seeds,
+                                                             int epochs, float alpha0, float min_alpha, int negative, double exp_scale,
+                                                             const float* __restrict__ exp_table_g, float* __restrict__ out) {
+    __shared__ float exp_table[EXP_TABLE_SIZE];
+    __shared__ uint32_t coarse[PLAN_COARSE];
+    __shared__ uint32_t plan_raw[4][PLAN_CAP], plan_own[4][PLAN_CAP], plan[4][PLAN_CAP];
+    __shared__ int32_t cw[4][PLAN_WORDS];
+    __shared__ uint32_t csi[4][PLAN_WORDS];
+    const uint32_t stride = (uint32_t)((V + PLAN_COARSE - 1) / PLAN_COARSE);
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += 256) exp_table[i] = exp_table_g[i];
+    for (uint32_t c = threadIdx.x; c * stride < (uint32_t)V; c += 256) {
+        const uint32_t last = (c + 1) * stride < (uint32_t)V ? (c + 1) * stride : (uint32_t)V;
+        coarse[c] = cum_table[last - 1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t doc = (int64_t)blockIdx.x * 4 + wv;
+    if (doc >= ndocs) return;                       // whole wave exits together (no barrier below)
+    float v[EPL], work[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) v[c] = (lane + 64 * c < dim) ? v0[doc * dim + lane + 64 * c] : 0.0f;
+    const int64_t wb = doc_ptr[doc], we = doc_ptr[doc + 1];
+    const uint64_t seed = seeds[doc];
+    const uint32_t cum_last = cum_table[V - 1];
+    double alpha = (double)alpha0;
+    const double alpha_delta = ((double)alpha0 - (double)min_alpha) / (double)(epochs - 1 > 1 ? epochs - 1 : 1);
+    uint32_t* praw = plan_raw[wv];
+    uint32_t* pown = plan_own[wv];
+    uint32_t* pl = plan[wv];
+    auto load_row = [&](uint32_t e, float (&rw)[EPL]) {
+        const float* __restrict__ row = syn1neg + (int64_t)(e & ~PLAN_POS) * dim;
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
+    };
+    for (int e = 0; e < epochs; ++e) {
+        uint64_t next_random = uniform64(splitmix64(seed + (uint64_t)e) & LCG_MOD);
+        const float a = (float)alpha;
+        for (int64_t c0 = wb; c0 < we; c0 += PLAN_WORDS) {
+            const int nc = (int)(we - c0 < PLAN_WORDS ? we - c0 : PLAN_WORDS);
+            // the chunk's words and their sub-sampling thresholds: one coalesced load, then uniform reads from LDS
+            if (lane < nc) {
+                const int32_t w = words[c0 + lane];
+                cw[wv][lane] = w;
+                csi[wv][lane] = (sample_int && w >= 0 && w < V) ? sample_int[w] : 0xffffffffu;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-level LDS fence: the phases hand data from lane to lane
+            // ---- 1. the random walk (uniform)
+            int n = 0;
+            for (int i = 0; i < nc; ++i) {
+                const int32_t w = __builtin_amdgcn_readfirstlane(cw[wv][i]);
+                if (w < 0 || w >= V) continue;
+                if (sample_int) {
+                    const uint64_t r = next_random >> 16;
+                    next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                    if ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(csi[wv][i]) < r) continue;      // (the builtin returns int: no sign extension)
+                }
+                if (lane == 0) {
+                    praw[n] = (uint32_t)w;
+                    pown[n] = 0xffffffffu;          // marks a positive target (a raw draw may have any of its 32 bits set)
+                }
+                for (int d = 1; d <= negative; ++d) {
+                    if (lane == 0) {
+                        praw[n + d] = (uint32_t)(next_random >> 16);
+                        pown[n + d] = (uint32_t)w;
+                    }
+                    next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                }
+                n += 1 + negative;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-level LDS fence: the phases hand data from lane to lane
+            // ---- 2. resolve every draw of the chunk, a lane per entry; drop samples that hit their own word; compact in order
+            int m = 0;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                uint32_t entry = 0;
+                bool keep = false;
+                if (j < n) {
+                    const uint32_t r = praw[j], own = pown[j];
+                    if (own == 0xffffffffu) {
+                        entry = PLAN_POS | r;
+                        keep = true;
+                    } else {
+                        const uint32_t t = bisect_left_coarse(cum_table, coarse, r % cum_last, (uint32_t)V, stride);
+                        entry = t;
+                        keep = t != own;
+                    }
+                }
+                const uint64_t mask = __ballot(keep);
+                if (keep) pl[m + __popcll(mask & ((1ull << lane) - 1))] = entry;
+                m += __popcll(mask);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-level LDS fence: the phases hand data from lane to lane
+            // ---- 3. the serial chain, a WORD at a time.  The (1 + negative) dot products of a word all use the document vector as it
+            // stood before the word (v changes only after it), so they are independent: their rows are requested together, the dots,
+            // the cross-lane sums and the sigmoid look-ups of the group overlap in the pipeline, and only the accumulation of `work`
+            // keeps the reference's order.  The next word's rows are requested before this word is computed.
+            if (m == 0) continue;
+            constexpr int G = PLAN_GROUP;
+            auto read_group = [&](int j, uint32_t (&ge)[G], int& gs) {
+                const uint32_t x = (lane <= G && j + lane < m) ? pl[j + lane] : PLAN_POS;      // past the end counts as "next word"
+                const uint64_t rest = __ballot((x & PLAN_POS) != 0) >> 1;                       // entry j itself is a positive target
+                const int nxt = rest ? (int)__ffsll((unsigned long long)rest) : G;
+                gs = nxt < G ? nxt : G;
+#pragma unroll
+                for (int g = 0; g < G; ++g) ge[g] = (uint32_t)__builtin_amdgcn_readlane((int)x, g);
+            };
+            auto load_rows = [&](const uint32_t (&ge)[G], int gs, float (&R)[G][EPL]) {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (g < gs) load_row(ge[g], R[g]);
+            };
+            auto process = [&](int gs, const float (&R)[G][EPL]) {
+                float p[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) p[g] = 0.0f;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        if (g < gs) p[g] = fmaf(v[c], R[g][c], p[g]);
+                float tv[G];
+                bool ok[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float f = g < gs ? wave_sum_butterfly(p[g]) : 0.0f;
+                    ok[g] = g < gs && !(f <= -(float)MAX_EXP || f >= (float)MAX_EXP);
+                    const int idx = ok[g] ? (int)((double)(f + (float)MAX_EXP) * exp_scale) : 0;
+                    tv[g] = exp_table[idx];
+                }
+                float wk[EPL];
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) wk[c] = 0.0f;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (ok[g]) {
+                        const float gg = ((g == 0 ? 1.0f : 0.0f) - tv[g]) * a;
+#pragma unroll
+                        for (int c = 0; c < EPL; ++c) wk[c] = fmaf(gg, R[g][c], wk[c]);
+                    }
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) v[c] = v[c] + wk[c];
+            };
+            uint32_t ea[G], eb[G];
+            int ga = 0, gb = 0;
+            float Ra[G][EPL], Rb[G][EPL];
+            int j = 0;
+            read_group(0, ea, ga);
+            load_rows(ea, ga, Ra);
+            for (;;) {
+                int jn = j + ga;
+                bool more = jn < m;
+                if (more) {
+                    read_group(jn, eb, gb);
+                    load_rows(eb, gb, Rb);
+                }
+                process(ga, Ra);
+                if (!more) break;
+                j = jn;
+                jn = j + gb;
+                more = jn < m;
+                if (more) {
+                    read_group(jn, ea, ga);
+                    load_rows(ea, ga, Ra);
+                }
+                process(gb, Rb);
+                if (!more) break;
+                j = jn;
+            }
         }
         alpha -= alpha_delta;
     }
@@ -198,8 +453,7 @@ __device__ __forceinline__ void train_document(float* __restrict__ syn1neg, cons
                 rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
                 p = fmaf(v[c], rw[c], p);
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) p = p + __shfl_xor(p, m);
+            p = wave_sum_butterfly(p);
             float f = p;
             if (f <= -(float)MAX_EXP || f >= (float)MAX_EXP) continue;
             f = exp_table[(int)((double)(f + (float)MAX_EXP) * exp_scale)];
@@ -327,8 +581,17 @@ int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words
     }
     const int grid = ceil_div(ndocs, 4);
     const int epl = (h->dim + 63) / 64;
+    static const bool planned_ok = !(getenv("HIPTS_D2V_PLAN") && strcmp(getenv("HIPTS_D2V_PLAN"), "0") == 0);      // A/B switch
+    const bool planned = planned_ok && h->negative <= PLAN_MAX_NEG;
 #define D2V_LAUNCH(E)                                                                                                   \
-    d2v_infer_kernel<E><<<grid, 256, 0, s>>>(h->syn1neg.as<float>(), h->cum_table.as<uint32_t>(),                       \
+    if (planned)                                                                                                         \
+        d2v_infer_plan_kernel<E><<<grid, 256, 0, s>>>(h->syn1neg.as<float>(), h->cum_table.as<uint32_t>(),                 \
+                                             h->has_sample ? h->sample_int.as<uint32_t>() : nullptr, h->V, h->dim,      \
+                                             h->ws_ptr.as<int64_t>(), h->ws_words.as<int32_t>(), ndocs,                 \
+                                             h->ws_v0.as<float>(), h->ws_seeds.as<uint64_t>(), epochs, alpha, min_alpha, \
+                                             h->negative, h->exp_scale, h->exp_table.as<float>(), out_dev);              \
+    else                                                                                                                 \
+        d2v_infer_kernel<E><<<grid, 256, 0, s>>>(h->syn1neg.as<float>(), h->cum_table.as<uint32_t>(),                   \
                                              h->has_sample ? h->sample_int.as<uint32_t>() : nullptr, h->V, h->dim,      \
                                              h->ws_ptr.as<int64_t>(), h->ws_words.as<int32_t>(), ndocs,                 \
                                              h->ws_v0.as<float>(), h->ws_seeds.as<uint64_t>(), epochs, alpha, min_alpha, \
