@@ -236,8 +236,9 @@ class SearchEngine:
             # self.stats and announced once, so that a corpus on which it is NOT rare does not go unnoticed.
             self.stats["full_rank_fallbacks"] += 1
             if self.stats["full_rank_fallbacks"] == 1:
+                import sys
                 print("hiptagsearch: the result filter found no second cut point in the first %d ranks; ranking all %d scores on the "
-                      "host for this query (SearchEngine.stats counts these)" % (k, D))
+                      "host for this query (SearchEngine.stats counts these)" % (k, D), file=sys.stderr)
             rf = rf_dev[0].cpu().numpy()
             if mx > 0:
                 rf = rf / mx

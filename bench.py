@@ -193,6 +193,20 @@ def query_section(device):
             roof[tag].update({"dominant_kernel": d["kernel"], "achieved": d["achieved"], "frac": d["frac"], "avg_launch_us": d["avg_us"],
                               "kernel_time_per_query_us": sum(c["avg_us"] * c["launches"] for c in prof) / (NQ if tag == "batched" else 64)})
     # bytes one query costs on each path (for the batched path the index pass is shared by 32 queries)
+    # The whole query function as the web UI calls it (webui.py:586: find_similar_documents(query, topn=800)): parse, per-tag Doc2Vec
+    # inference, fused scoring with top-1024, re-inference of the top-10 documents, rerank product, combine, rank, gap filter.
+    toks = synth.vocab_tokens(V)
+    lines = ["img%06d.png," % d_ + ",".join(toks[t] for t in terms[ptr[d_]:ptr[d_ + 1]]) for d_ in range(D)]
+    full = SearchEngine(model, idx, {t: i for i, t in enumerate(toks)}, bm, lines)
+    model.key_to_index = full.token2id
+    qstrings = [synth.query_string(q, toks) for q in synth.queries(24, V, seed=47)]
+    full.find_similar_documents(qstrings[0], topn=800)
+    fs_ms = []
+    for qs_ in qstrings[:20]:
+        t0 = time.perf_counter()
+        full.find_similar_documents(qs_, topn=800)
+        fs_ms.append(1e3 * (time.perf_counter() - t0))
+    fs_ms.sort()
     # Doc2Vec PV-DBOW training (genmodel.py:159-162), parallel schedule: 20k documents x 5 epochs of the bench corpus
     from hiptagsearch.d2v import Doc2Vec
     n_tr, ep_tr = 20_000, 5
@@ -220,6 +234,8 @@ def query_section(device):
                                             "note": "batched: one 120 MB index pass per 32 queries + per-query score rows (posting lists counted per launch in roofline)"},
             "cpu_port_qps": cpu_qps, "cpu_port_sample": "%d queries, numpy CSR BM25 + C fma-chain + lexsort, 1 thread" % nq_cpu,
             "d2v_infer_docs_per_s": d2v_gpu, "d2v_sample": "%d docs x 100 epochs, host buffers in/out" % n_gpu,
+            "find_similar_documents_ms": {"median": fs_ms[len(fs_ms) // 2], "min": fs_ms[0], "max": fs_ms[-1],
+                                          "sample": "20 queries of 1-4 tags, topn=800, 100-epoch inference of the query tags and of the top-10 documents"},
             "d2v_train_doc_epochs_per_s": d2v_train, "d2v_train_sample": "%d docs x %d epochs, parallel schedule, host arrays in/out" % (n_tr, ep_tr),
             "d2v_train_cpu_port_doc_epochs_per_s": d2v_train_cpu, "d2v_train_cpu_sample": "%d docs x %d epochs, C oracle, 1 thread (reference: workers=1)" % (n_trc, ep_trc),
             "d2v_cpu_port_docs_per_s": d2v_cpu, "d2v_cpu_sample": "%d docs, C oracle, 1 thread (reference: workers=1)" % n_cpu}
