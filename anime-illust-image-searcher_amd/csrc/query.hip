@@ -820,6 +820,9 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
     // contiguous span of the document-major CSR: its term ids are staged in LDS with coalesced loads, then walked ONCE, coalesced:
     // a lane compares its entry with the (scalar) query terms; on a match -- at most nt per document -- it finds the entry's
     // document by bisection of the 128 start offsets and records the entry's tf in the slot of (query term, document).
+    // (Also measured without gain: the BM25 part on two waves of its own beside two index-stream waves (32.7 us); the tf staged
+    // with the term id so that a match needs no global load (35.5 us).  The index stream alone runs at 6 TB/s -- sim1_kernel back to
+    // back, 20 us for these 120 MB -- so ~12 us of this kernel are the BM25 part's dependent chain, not bandwidth.)
     // (Measured alternatives, all within 2 us of each other at ~33 us for the kernel: every thread walking its own list from memory
     // or from LDS; a staged entry -> document map with 16-bit LDS stores was slower, 50 us.)
     const int64_t d_first = (int64_t)blockIdx.x * S1_THREADS;
@@ -946,6 +949,54 @@ __device__ __forceinline__ void search1_maxima(const Search1State* __restrict__ 
     }
     *ma = ka ? key_value(ka) : -INFINITY;
     *mb = kb ? float_from_key(kb) : -INFINITY;
+}
+
+
+// index[query] for ONE query (webui.py:205: the rerank product; webui.py:306-309 restated: the character-feature differences):
+// the index-stream half of search1_score_kernel alone -- thread per document, k-ordered fmaf chain from the tile-major copy,
+// the query in the kernel arguments.  Same bits as sim_mfma_kernel's chain; one pass costs the same bytes but no LDS query
+// tile, no 32-wide MFMA for one useful column: 100k x 768 in ~60 us instead of ~270 us per call.
+struct Sim1Query {
+    int32_t dim, pad[3];
+    float q[S1_MAX_DIM];
+};
+
+__global__ __launch_bounds__(128) void sim1_kernel(const Sim1Query Q, const float4* __restrict__ tiled, int64_t D, float* __restrict__ out) {
+    const int64_t d = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const int64_t dd = d < D ? d : D - 1;
+    const int KQ = Q.dim >> 2;
+    const float4* __restrict__ p = tiled + ((dd >> 5) * KQ) * 32 + (dd & 31);
+    constexpr int U = 8;
+    float4 va[U], vb[U];
+    auto request = [&](float4(&v)[U], int kq0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kq = kq0 + u < KQ ? kq0 + u : KQ - 1;
+            v[u] = p[(int64_t)kq * 32];
+        }
+    };
+    float acc = 0.0f;
+    auto consume = [&](const float4(&v)[U], int kq0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* qq = Q.q + 4 * (kq0 + u);
+            acc = fmaf(v[u].x, qq[0], acc);
+            acc = fmaf(v[u].y, qq[1], acc);
+            acc = fmaf(v[u].z, qq[2], acc);
+            acc = fmaf(v[u].w, qq[3], acc);
+        }
+    };
+    request(va, 0);
+    const int rounds = (KQ + U - 1) / U;
+    int r = 0;
+    for (; r + 2 <= rounds; r += 2) {
+        request(vb, (r + 1) * U);
+        consume(va, r * U);
+        request(va, (r + 2) * U);
+        consume(vb, (r + 1) * U);
+    }
+    if (r < rounds) consume(va, r * U);
+    if (d < D) out[d] = acc;
 }
 
 // Threshold without sampling: the documents are cut into G <= 4096 groups of 64 * gw consecutive documents (one wave of this
@@ -1593,16 +1644,26 @@ int hipts_index_query(hipts_index_t* h, const float* queries, int queries_memspa
     HIPTS_REQUIRE(h->len > 0, "hipts_index_query: empty index");
     HIPTS_TRY(use_device(h->device));
     hipStream_t s = (hipStream_t)stream;
+    float* out_dev = scores_out;
+    if (out_memspace != HIPTS_DEVICE) {
+        HIPTS_TRY(h->ws_out.reserve((size_t)nq * h->len * 4));
+        out_dev = h->ws_out.as<float>();
+    }
+    static const bool allow_one = !(getenv("HIPTS_SEARCH1") && strcmp(getenv("HIPTS_SEARCH1"), "0") == 0);
+    if (nq == 1 && allow_one && queries_memspace != HIPTS_DEVICE && h->dim <= S1_MAX_DIM && h->dim % 4 == 0 && h->tiled.p && h->len >= S1_MIN_DOCS) {
+        Sim1Query Q;                      // a host query goes straight into the kernel arguments: no staging copy
+        memset(&Q, 0, sizeof(Q));
+        Q.dim = h->dim;
+        memcpy(Q.q, queries, (size_t)h->dim * 4);
+        sim1_kernel<<<ceil_div(h->len, 128), 128, 0, s>>>(Q, h->tiled.as<float4>(), h->len, out_dev);
+        HIPTS_LAUNCH_CHECK();
+        return copy_out(scores_out, out_dev, (size_t)h->len * 4, out_memspace, s);
+    }
     const float* q_dev = queries;
     if (queries_memspace != HIPTS_DEVICE) {
         HIPTS_TRY(h->ws_q.reserve((size_t)nq * h->dim * 4));
         HIPTS_HIP(hipMemcpyAsync(h->ws_q.p, queries, (size_t)nq * h->dim * 4, hipMemcpyHostToDevice, s));
         q_dev = h->ws_q.as<float>();
-    }
-    float* out_dev = scores_out;
-    if (out_memspace != HIPTS_DEVICE) {
-        HIPTS_TRY(h->ws_out.reserve((size_t)nq * h->len * 4));
-        out_dev = h->ws_out.as<float>();
     }
     HIPTS_TRY(launch_sim(h->rows.as<float>(), h->tiled.as<float>(), h->len, h->dim, q_dev, nq, out_dev, h->len, s));
     return copy_out(scores_out, out_dev, (size_t)nq * h->len * 4, out_memspace, s);
