@@ -1035,6 +1035,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tile
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if (a.raster_gm > 0) {
+            // Wide outputs (fc1: 12 column tiles): row-major order hands the 32 workgroups of an XCD 2.7 row panels x ALL column
+            // tiles per round -- the whole W (4.7 MB) plus 1 MB of A against a 4 MB L2, so W is pulled through the fabric again every
+            // round.  Groups of raster_gm row panels, walked column-major inside the group: a round is raster_gm row panels x
+            // 32 / raster_gm column tiles, and the next rounds keep the same row panels.
+            const int per = a.raster_gm * tiles_n, grp = bid / per, rem = bid - grp * per;
+            const int left = tiles_m - grp * a.raster_gm, gm = left < a.raster_gm ? left : a.raster_gm;
+            m0 = (grp * a.raster_gm + rem % gm) * TBM;
+            n0 = (rem / gm) * BN;
+            return;
+        }
         m0 = (bid / tiles_n) * TBM;
         n0 = (bid % tiles_n) * BN;
     };
@@ -1855,12 +1866,15 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             const int ntile = (use7 ? tiles_m7 : tiles_m) * tiles_n;
             const int slots = cus >= 8 ? cus / 8 * 8 : cus;
             const int grid = (persist && ntile > slots) ? slots : ntile;
+            static const int raster = getenv("HIPTS_GEMM_RASTER") ? atoi(getenv("HIPTS_GEMM_RASTER")) : 8;      // measured: 8 +0.4..0.8 % on the ViT forward, 4 / 16 +-0
+            GemmArgs ar = a;
+            ar.raster_gm = (raster > 0 && tiles_n >= 8) ? raster : 0;
             if (a.f16) {
-                if (use7) gemm_pp_kernel<EPI, 7, true><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
-                else gemm_pp_kernel<EPI, 8, true><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+                if (use7) gemm_pp_kernel<EPI, 7, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m7, tiles_n);
+                else gemm_pp_kernel<EPI, 8, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
             } else {
-                if (use7) gemm_pp_kernel<EPI, 7, false><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m7, tiles_n);
-                else gemm_pp_kernel<EPI, 8, false><<<grid, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
+                if (use7) gemm_pp_kernel<EPI, 7, false><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m7, tiles_n);
+                else gemm_pp_kernel<EPI, 8, false><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
             }
         }
         else

@@ -1173,6 +1173,39 @@ extern "C" int hiptsdbg_attention_run(const uint16_t* q, const uint16_t* k, cons
     return HIPTS_OK;
 }
 
+// Development aid: average device time of `iters` attention launches with the chip to itself (tools/attn_time.py).
+extern "C" int hiptsdbg_attention_time(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int batch, int heads, int tokens, int tokens_pad,
+                                       int head_dim, int f16, int iters, double* avg_us) {
+    HIPTS_REQUIRE(q && k && vT && avg_us && batch >= 1 && heads >= 1 && tokens >= 1 && iters >= 1, "hiptsdbg_attention_time: bad arguments");
+    HIPTS_TRY(use_device(0));
+    const size_t nqk = (size_t)batch * heads * tokens_pad * head_dim, nout = (size_t)batch * tokens * heads * head_dim;
+    DevBuf dq, dk, dv, dout;
+    HIPTS_TRY(dq.alloc(nqk * 2));
+    HIPTS_TRY(dk.alloc(nqk * 2));
+    HIPTS_TRY(dv.alloc(nqk * 2));
+    HIPTS_TRY(dout.alloc(nout * 2));
+    HIPTS_TRY(upload(dq.p, q, nqk * 2));
+    HIPTS_TRY(upload(dk.p, k, nqk * 2));
+    HIPTS_TRY(upload(dv.p, vT, nqk * 2));
+    hipEvent_t e0, e1;
+    HIPTS_HIP(hipEventCreate(&e0));
+    HIPTS_HIP(hipEventCreate(&e1));
+    int rc = HIPTS_OK;
+    for (int i = 0; i < 3 && rc == HIPTS_OK; ++i)
+        rc = launch_attention(dq.as<bf16_t>(), dk.as<bf16_t>(), dv.as<bf16_t>(), dout.as<bf16_t>(), batch, heads, tokens, tokens_pad, f16 != 0, nullptr, head_dim, 0);
+    HIPTS_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && rc == HIPTS_OK; ++i)
+        rc = launch_attention(dq.as<bf16_t>(), dk.as<bf16_t>(), dv.as<bf16_t>(), dout.as<bf16_t>(), batch, heads, tokens, tokens_pad, f16 != 0, nullptr, head_dim, 0);
+    HIPTS_HIP(hipEventRecord(e1, nullptr));
+    HIPTS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = 1e3 * ms / iters;
+    return rc;
+}
+
 // Development aid: copy one workspace buffer of the last forward to the host (tools/determinism.py).
 extern "C" int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes) {
     HIPTS_REQUIRE(h && name && out_host && bytes, "null argument");

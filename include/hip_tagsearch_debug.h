@@ -34,6 +34,9 @@ int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t m
  * `tokens` zero), vT [batch * heads][head_dim][tokens_pad]; out 16-bit patterns [batch][tokens][heads * head_dim].  f16: IEEE half operands. */
 int hiptsdbg_attention_run(const uint16_t* q, const uint16_t* k, const uint16_t* vT, uint16_t* out_host, int batch, int heads, int tokens,
                            int tokens_pad, int head_dim, int f16);
+/* The same launch timed: average device microseconds over `iters` launches (HIP events) with the chip to itself. */
+int hiptsdbg_attention_time(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int batch, int heads, int tokens, int tokens_pad,
+                            int head_dim, int f16, int iters, double* avg_us);
 
 /* One-query search path (hipts_search with nq == 1): how many candidates its threshold step collected for the last query and
  * whether the ranking used them (1) or fell through to the exact radix select (0). */

@@ -253,6 +253,44 @@ def test_search_one_query_path_is_bit_equal_to_the_batched_path(corpus20k):
         assert gv[0].tobytes() == wv.tobytes()
 
 
+def test_search_one_query_many_in_a_row(corpus20k):
+    """The default one-query path (results stored to pinned memory by the last kernel and published by a sequence number the host
+    spins on; per-query state -- maxima slots, group maxima, candidate slots -- reused from call to call): 300 different queries back
+    to back, plain and masked, k = 100 and 1024, against the batched kernels.  State leaking from one query into the next would show
+    here.  (At 20 k documents many of these take the exact select inside the ranking kernel: both ways are covered.)"""
+    import ctypes
+    from hiptagsearch import _lib, synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    ptr, terms, V = corpus20k
+    D = len(ptr) - 1
+    rows = synth.index_vectors(D, 300, seed=47)
+    bm = BM25Index(ptr, terms, V)
+    index = Similarity("idx", None, 300, capacity=D)
+    index.add_matrix(rows)
+    eng = SearchEngine(None, index, {}, bm, [])
+    qs = [dict(q) for q in synth.queries(300, V, seed=45, head=300)]
+    for i in range(0, 300, 7):                                     # every seventh query requires one of its own terms
+        if qs[i]:
+            t = next(iter(qs[i]))
+            qs[i][t] = 1001.0
+    rng = np.random.default_rng(6)
+    qv = rng.standard_normal((len(qs), 300))
+    qv = (qv / np.linalg.norm(qv, axis=1, keepdims=True)).astype(np.float32)
+    for k in (100, 1024):
+        bi, bv = eng.score_topk(qs, qv, k)                         # batched kernels
+        decided = 0
+        for i, q in enumerate(qs):
+            oi, ov = eng.score_topk([q], qv[i:i + 1], k)
+            np.testing.assert_array_equal(oi[0], bi[i], err_msg="query %d k %d" % (i, k))
+            assert ov[0].tobytes() == bv[i].tobytes(), "query %d k %d scores" % (i, k)
+            c, fast = ctypes.c_uint32(), ctypes.c_uint32()
+            _lib.call("hiptsdbg_search1_last", bm._h, ctypes.byref(c), ctypes.byref(fast))
+            decided += fast.value
+        assert 0 <= decided <= len(qs)
+
+
 # --------------------------------------------------------------------------------- full query function
 def test_find_similar_documents_matches_oracle():
     """find_similar_documents (webui.py:345-390, normal mode incl. the 10-document rerank and the gap

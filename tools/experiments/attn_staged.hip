@@ -1,0 +1,447 @@
+// OUT OF BUILD -- round-2 experiment kept for the record ("attention is latency-bound").
+// attn.hip with (a) waves past the last query row staging only, (b) the last key tile peeled and cut to its valid 32-key half,
+// (c) the hot loop staged by hand: every K / V^T fragment of the tile requested up front, P V MFMAs, then S MFMAs, then the softmax,
+// pinned with sched_barrier; staging loads as inline asm (the C++ loads were sunk behind the tile) and one tracked vmcnt(0) after the
+// Q loads (otherwise the waitcnt pass puts vmcnt(3..0) in front of the S MFMAs of every iteration), (d) cycle stamps of one workgroup.
+// Measured (32 images x 12 heads x 784 tokens, kernel alone): shipped kernel 100-105 us; (a)+(b) 102-107; (c) at two waves per SIMD
+// (208 VGPRs) 111-113; (c) at three (168 VGPRs, this file) 96-109.  Stamps of (c): per tile and wave ~850 cycles to issue 4 global loads
+// + 12 LDS reads, 650-930 for the 16 MFMAs, 250 for the softmax, ~800 wait + LDS write, 550-780 barrier, at 1.8-2.0 GHz.
+// attn.hip -- fused softmax(Q K^T) V for the ViT blocks (timm Attention inside tagging.py:174).
+//
+// Non-causal, no mask, head_dim 64, a few hundred tokens (784 for ViT-B/16 @448).
+// One workgroup = 4 waves = 128 query rows of one (image, head); a wave owns 32 query rows.
+// Flash-style: K / V^T tiles of 64 keys are staged through LDS (registers -> ds_write, next
+// tile's global loads issued before the current tile's math), scores never leave registers.
+//
+// (q arrives pre-scaled by head_dim^-0.5 * log2 e, so exp2 of the raw scores is the softmax numerator.)
+//   S^T = K Q^T      v_mfma_f32_32x32x16_bf16, A = K tile rows (keys), B = Q^T held in registers.
+//                    The accumulator then has the QUERY on the lane (column) and 16 of the 32 keys in
+//                    its registers, so the online softmax is lane-local (one cross-half exchange).
+//   O^T = V^T P^T    the S^T accumulator, converted to bf16, is directly the B operand (no lane
+//                    movement); its k order inside a 16-key step is  16s + 8(j>>2) + 4h + (j&3),
+//                    and the V^T A-fragment is read from LDS in that same order (two ds_read_b64).
+//                    O^T keeps the query on the lane too: rescale and final 1/l are lane-local.
+// V arrives already transposed ([head][d][token]) from the QKV GEMM epilogue.
+// LDS rows are padded (K: 144 B, V^T: 136 B) so the b128 / b64 fragment reads are conflict free.
+// Keys beyond `tokens` (padding up to a multiple of 64) are masked to -inf; padded K / V^T entries
+// are zero (buffers are cleared once and the epilogues never write there).
+#include "vit_internal.h"
+
+namespace hipts {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Development aid (hiptsdbg_attention_time): cycle stamps of one workgroup's loop, [wave][tile][8]; null in every other launch.
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#define ATT_STAMP(idx)                                                                          \
+    do {                                                                                        \
+        if (stamps) {                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            const unsigned long long ts_ = __builtin_readcyclecounter();                        \
+            if (lane == 0 && t < 16) stamps[(wave * 16 + t) * 8 + (idx)] = ts_;                 \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+        }                                                                                       \
+    } while (0)
+constexpr int KV = 64;               // keys per tile
+constexpr int VS = 136;              // LDS bytes per V^T row (64 key* 2 B + 8)
+// head_dim HD = 64 (ViT) or 32 (CAFormer): K rows are HD * 2 B + 16 (144 / 80 B: both conflict free for the
+// b128 fragment reads), the V^T tile has HD rows.
+template <int HD> struct Geo {
+    static constexpr int KS = HD * 2 + 16;          // LDS bytes per K row
+    static constexpr int K_BYTES = KV * KS;         // 9216 / 5120
+    static constexpr int V_BYTES = HD * VS;         // 8704 / 4352
+    static constexpr int V_BASE = 2 * K_BYTES;      // LDS: two K slots, then three V^T slots
+    static constexpr int LDS_BYTES = 2 * K_BYTES + 3 * V_BYTES;   // 44.5 KB (HD 64): three workgroups per CU
+};
+
+// Written with plain fmaxf so the compiler sees the MFMA -> VALU dependency and inserts the required
+// wait states itself.  (An inline-asm v_max3_f32 here read accumulator registers before the MFMA had
+// retired them: hipcc pads nothing around asm operands -- results differed run to run by a few bf16
+// ulps.)  This file is compiled with -fno-honor-nans, which drops the canonicalising v_max that fmaxf
+// on MFMA results otherwise costs (45 v_max + 9 v_max3 per tile instead of 17 v_max3); no NaN can
+// occur: every tile has at least one unmasked key, so the running maximum is finite.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+__device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// The per-tile work of one wave (32 queries x 64 keys), split in three so that the loop can be
+// software-pipelined:   S(t) MFMAs | P(t-1) V(t-1) MFMAs | softmax(t) on the VALU.
+// The second MFMA group keeps the matrix pipe busy while the VALU chews on S(t); by the time the
+// softmax wants to rescale O, the P V product it must include has retired.
+// q is pre-scaled by head_dim^-0.5 * log2(e) in the QK GEMM epilogue: scores are in the base-2 domain.
+// MASK (last tile only): keys >= tokens start their accumulator at -inf, which the MFMA carries through.
+// GH: 32-key halves of the tile that hold a valid key (1: the last tile ends inside its first half -- the second half's MFMAs,
+// exponentials and P V steps are skipped altogether).
+template <bool MASK, bool F16, int HD, int GH = 2>
+__device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[HD / 16],
+                                       f32x16 (&sacc)[2]) {
+    constexpr int KS = Geo<HD>::KS;
+#pragma unroll
+    for (int g = 0; g < GH; ++g) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (MASK) sacc[g][i] = (kv0 + g * 32 + crow(i, h) >= tokens) ? -INFINITY : 0.f;
+            else sacc[g][i] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (g * 32 + r) * KS + (16 * s + 8 * h) * 2);
+            sacc[g] = mfma_32x32x16<F16>(kf, qf[s], sacc[g]);
+        }
+    }
+}
+
+template <bool F16, int HD, int GH = 2>
+__device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int h, const bf16x8 (&pf)[2][2], f32x16 (&o)[HD / 32]) {
+#pragma unroll
+    for (int blk = 0; blk < HD / 32; ++blk) {
+        const char* vrow = vt + (blk * 32 + r) * VS;
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int key = g * 32 + 16 * s2 + 4 * h;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + key * 2);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (key + 8) * 2);
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[blk] = mfma_32x32x16<F16>(vf, pf[g][s2], o[blk]);
+            }
+    }
+}
+
+// (Moving the row sums onto the matrix pipe -- a fifth 32 x 32 block with the constant A operand "row 0 = ones",
+// 4 more MFMAs per tile for 34 fewer v_add_f32 -- was measured slightly SLOWER, 209-212 vs 205 us, and costs
+// 20 VGPRs: the loop is not simply VALU-throughput bound.)
+// (A lazy reference -- rescale O and l only when some row's tile maximum exceeds the reference by 2^8,
+// behind a wave-uniform branch -- was measured SLOWER, 217 vs 196 us: the branch stops the scheduler from
+// running this VALU work under the P V MFMAs.)
+template <bool F16, int HD>
+__device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[HD / 32], float& m_run,
+                                             float& l_run) {
+    float mx = max3f(sacc[0][0], sacc[1][0], m_run);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = max3f(mx, sacc[0][i], sacc[1][i]);
+    const float m_new = fmaxf(mx, __shfl_xor(mx, 32));
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
+            if (i & 1) lsum1 += p; else lsum0 += p;
+            pf[g][i >> 3][i & 7] = to_op<F16>(p);
+        }
+    l_run = l_run * alpha + (lsum0 + lsum1);
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {       // O already holds every tile before this one (incl. the P V just issued)
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; ++blk) o[blk][i] *= alpha;
+    }
+}
+
+// Softmax WITHOUT a running maximum (the default path).  softmax(S) V = (sum_j 2^S_j V_j) / (sum_j 2^S_j) whatever the scale, and
+// P = 2^S is kept in bf16 / fp32, whose exponent range is the same 8 bits: as long as the row's unnormalised sum l stays inside
+// [2^-100, 2^126] nothing overflows, and everything that underflows (S < -126) weighs less than 2^-16 of the row -- below the
+// 2^-9 rounding of P itself.  So a tile is 32 v_exp + 32 v_add + 16 v_cvt_pk per wave and nothing else: no maximum (17 v_max3),
+// no subtraction (32 v_sub), no rescale of O (32 v_mul + an exp) -- ~460 VALU issue cycles per 64-key tile against 512 of MFMA,
+// where the classic step above costs ~880.  Scores are log2-domain dot products of LayerNormed activations (|S| of a few tens);
+// a row whose sum does leave the window is detected at the end (attn_kernel) and the workgroup repeats the block with the
+// classic per-tile maximum, which cannot overflow.
+template <bool F16, int HD, int GH = 2>
+__device__ __forceinline__ void softmax_nomax(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& l_run) {
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < GH; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sacc[g][i]);
+            if (i & 1) lsum1 += p; else lsum0 += p;
+            pf[g][i >> 3][i & 7] = to_op<F16>(p);
+        }
+    l_run += lsum0 + lsum1;
+}
+
+// CLASSIC: online softmax with the per-tile running maximum (softmax_tile); otherwise softmax_nomax.  Returns true when the
+// fast path's row sum left its safe window (nothing is stored then).
+template <bool F16, int HD, bool CLASSIC>
+__device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                          const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
+                                          int qblocks, int out_stride) {
+    using G = Geo<HD>;
+    constexpr int KS = G::KS, K_BYTES = G::K_BYTES, V_BYTES = G::V_BYTES, V_BASE = G::V_BASE;
+    // iteration t multiplies K(t) (slot t & 1) and V(t-1) (slot (t-1) % 3) while tile t+1 is written: K(t+1)
+    // over K(t-1), V(t+1) over V(t-2), both last read before the previous barrier.  Two K and three V^T
+    // slots = 44.5 KB, so three workgroups (three waves per SIMD at 148 VGPRs) share a CU and one wave's
+    // softmax (VALU) runs under the others' MFMAs.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware work id: workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
+    // L2).  Remap so that consecutive work items -- the query blocks of one (image, head), which all
+    // stream the same K / V^T -- run on ONE XCD and hit its L2 instead of each pulling its own copy
+    // through the fabric (measured: 1.23 GB fetched per launch vs 0.23 GB algorithmic before this).
+    int wid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qd = nwg >> 3, rm = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    unsigned long long* const stamps = (g_attn_stamps && blockIdx.x == gridDim.x / 2 + 8) ? g_attn_stamps : nullptr;
+    const int bh = wid / qblocks, qb = wid - bh * qblocks;
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = (qb * 4 + wave) * 32;
+    // A wave whose 32 query rows all lie past the last token (ViT @448: 784 rows = 24.5 blocks of 32, so three of the 28 waves of an
+    // (image, head)) takes its share of the K / V^T staging and every barrier, and nothing else.
+    const bool active = q0 < tokens;
+    int qrow = q0 + r;
+    qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
+
+    // Q^T fragments (B operand): lane (q = r, half h), k-step s: d = 16 s + 8 h .. + 7
+    bf16x8 qf[HD / 16];
+    {
+        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < HD / 16; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    // The Q loads stay AHEAD of the first K / V^T loads in program order, so that the counted waits of that tile's LDS writes cover
+    // them.  (Scheduled behind them, as the compiler does on its own, they make the waitcnt pass put vmcnt(3..0) in front of the S
+    // MFMAs of every loop iteration, i.e. wait there for the next tile's loads issued a few instructions earlier.)
+    __builtin_amdgcn_sched_barrier(0);
+
+    // staging: K tile = 64 rows x HD/8 chunks of 16 B, V^T tile = HD rows x 8 chunks; one (HD 32) or two (HD 64)
+    // chunks of each per thread.  Plain scalars, no arrays: a per-thread array here is "promoted" to LDS by
+    // the compiler (8 KB) and costs the third workgroup per CU.
+    constexpr int KCH = HD / 8;
+    constexpr bool TWO = HD == 64;
+    const int kc0 = tid, kc1 = tid + 256;
+    const bf16_t* kp0 = k + (size_t)bh * tokens_pad * HD + (size_t)(kc0 / KCH) * HD + (kc0 % KCH) * 8;
+    const bf16_t* kp1 = k + (size_t)bh * tokens_pad * HD + (size_t)(kc1 / KCH) * HD + (kc1 % KCH) * 8;
+    const bf16_t* vp0 = vT + (size_t)bh * HD * tokens_pad + (size_t)(kc0 >> 3) * tokens_pad + (kc0 & 7) * 8;
+    const bf16_t* vp1 = vT + (size_t)bh * HD * tokens_pad + (size_t)(kc1 >> 3) * tokens_pad + (kc1 & 7) * 8;
+    const int kdst0 = (kc0 / KCH) * KS + (kc0 % KCH) * 16, kdst1 = (kc1 / KCH) * KS + (kc1 % KCH) * 16;
+    const int vdst0 = V_BASE + (kc0 >> 3) * VS + (kc0 & 7) * 16, vdst1 = V_BASE + (kc1 >> 3) * VS + (kc1 & 7) * 16;
+    // The loads are inline asm: written as C++ loads, two of the four are sunk past the whole tile to just before the LDS writes that
+    // consume them (their registers are then shared with the score accumulators), and their latency is exposed once per tile.  The
+    // compiler's waitcnt pass does not see them, so attn_write waits for vmcnt(0) itself; a wait it inserts for a load of its own (Q,
+    // issued before these) can only over-wait, the counter being in order.
+    u32x4 kreg0 = {}, kreg1 = {}, vreg0 = {}, vreg1 = {};
+    auto attn_load = [&](int kv0) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg0) : "v"(kp0 + (size_t)kv0 * HD) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg0) : "v"(vp0 + kv0) : "memory");
+        if constexpr (TWO) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg1) : "v"(kp1 + (size_t)kv0 * HD) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg1) : "v"(vp1 + kv0) : "memory");
+        }
+    };
+    auto attn_write = [&](int ks, int vs) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg0), "+v"(kreg1), "+v"(vreg0), "+v"(vreg1)::"memory");
+        *reinterpret_cast<u32x4*>(smem + ks * K_BYTES + kdst0) = kreg0;
+        *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst0) = make_uint2(vreg0.x, vreg0.y);
+        *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst0 + 8) = make_uint2(vreg0.z, vreg0.w);
+        if constexpr (TWO) {
+            *reinterpret_cast<u32x4*>(smem + ks * K_BYTES + kdst1) = kreg1;
+            *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst1) = make_uint2(vreg1.x, vreg1.y);
+            *reinterpret_cast<uint2*>(smem + vs * V_BYTES + vdst1 + 8) = make_uint2(vreg1.z, vreg1.w);
+        }
+    };
+
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; ++blk) o[blk][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sacc[2];
+    bf16x8 pf[2][2];
+
+    const int nkv = tokens_pad / KV;
+    const int tail_keys = tokens - (nkv - 1) * KV;                 // valid keys of the last tile, 1 .. 64
+    const bool masked_tail = tail_keys < KV;
+    const bool half_tail = !CLASSIC && tail_keys <= 32;             // (the classic fallback keeps one code path: -inf scores weigh 0)
+    // the last tile: unmasked, masked, or masked with only its first 32 keys computed
+    auto s_last = [&](const char* kt, int kv0) {
+        if (half_tail) s_tile<true, F16, HD, 1>(kt, kv0, tokens, r, h, qf, sacc);
+        else if (masked_tail) s_tile<true, F16, HD>(kt, kv0, tokens, r, h, qf, sacc);
+        else s_tile<false, F16, HD>(kt, kv0, tokens, r, h, qf, sacc);
+    };
+    auto softmax_last = [&]() {
+        if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+        else if (half_tail) softmax_nomax<F16, HD, 1>(sacc, pf, l_run);
+        else softmax_nomax<F16, HD>(sacc, pf, l_run);
+    };
+    attn_load(0);
+    // vmcnt(0) as an instruction the waitcnt pass itself tracks: from here on it knows the Q fragments have landed.  (Left to find
+    // that out at their first use, it carries "Q may be pending" around the loop's back edge and puts vmcnt(3..0) in front of the S
+    // MFMAs of every iteration -- where that waits for the NEXT tile's loads, issued a few instructions earlier.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    attn_write(0, 0);
+    __syncthreads();
+    // tile 0: scores and softmax only (its P V is issued with the next tile's scores)
+    if (nkv > 1) attn_load(KV);
+    if (active) {
+        if (nkv == 1) {
+            s_last(smem, 0);
+            softmax_last();
+        } else {
+            s_tile<false, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
+            if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+            else softmax_nomax<F16, HD>(sacc, pf, l_run);
+        }
+    }
+    if (nkv > 1) attn_write(1, 1);
+    __syncthreads();
+    int vprev = 0, vcur = 1;                  // V^T slot of tile t-1 / of tile t
+    if (active) {
+        // full tiles 1 .. nkv-2: every one of them stages its successor
+        for (int t = 1; t + 1 < nkv; ++t) {
+            const int vnxt = vcur == 2 ? 0 : vcur + 1;
+            ATT_STAMP(0);
+            attn_load((t + 1) * KV);
+            if constexpr (CLASSIC) {
+                s_tile<false, F16, HD>(smem + (t & 1) * K_BYTES, t * KV, tokens, r, h, qf, sacc);
+                pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+                softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+            } else {
+                // The hot loop, staged by hand.  Left to itself the compiler reads one or two fragments, waits for them, issues their
+                // MFMAs and only then reads the next ones -- sixteen exposed LDS round trips per tile, a wave-iteration of ~3 500 cycles
+                // for ~650 cycles of issue, which three waves per SIMD do not cover (measured: removing the exponentials or a tenth of
+                // the MFMAs changed nothing).  Here every fragment of the tile is requested first (counted lgkmcnt waits follow from the
+                // in-order returns), then the 8 S MFMAs as two interleaved chains, the 8 P V MFMAs likewise, and the softmax of the new
+                // scores runs on the VALU while those are still in the matrix pipe.
+                const char* kt = smem + (t & 1) * K_BYTES;
+                const char* vt = smem + V_BASE + vprev * V_BYTES;
+                bf16x8 kf[2][HD / 16], vf[HD / 32][2][2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int blk = 0; blk < HD / 32; ++blk) {
+                            const char* vrow = vt + (blk * 32 + r) * VS + (g * 32 + 16 * s2 + 4 * h) * 2;
+                            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+                            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+                            vf[blk][g][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+#pragma unroll
+                for (int s = 0; s < HD / 16; ++s) kf[0][s] = *reinterpret_cast<const bf16x8*>(kt + r * KS + (16 * s + 8 * h) * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                ATT_STAMP(1);
+                // P(t-1) V(t-1) first: its fragments are dead before the score accumulators come alive (168 registers = three waves per SIMD)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int blk = 0; blk < HD / 32; ++blk) o[blk] = mfma_32x32x16<F16>(vf[blk][g][s2], pf[g][s2], o[blk]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < HD / 16; ++s) kf[1][s] = *reinterpret_cast<const bf16x8*>(kt + (32 + r) * KS + (16 * s + 8 * h) * 2);
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int s = 0; s < HD / 16; ++s) {
+                        if (s == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) sacc[g][i] = 0.f;
+                        }
+                        sacc[g] = mfma_32x32x16<F16>(kf[g][s], qf[s], sacc[g]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                ATT_STAMP(2);
+                softmax_nomax<F16, HD>(sacc, pf, l_run);
+                __builtin_amdgcn_sched_barrier(0);
+                ATT_STAMP(3);
+            }
+            attn_write((t + 1) & 1, vnxt);
+            ATT_STAMP(4);
+            __syncthreads();
+            ATT_STAMP(5);
+            if (stamps && lane == 0 && t < 16) stamps[(wave * 16 + t) * 8 + 6] = wall_clock64();
+            vprev = vcur;
+            vcur = vnxt;
+        }
+    } else {
+        for (int t = 1; t + 1 < nkv; ++t) {
+            const int vnxt = vcur == 2 ? 0 : vcur + 1;
+            attn_load((t + 1) * KV);
+            attn_write((t + 1) & 1, vnxt);
+            __syncthreads();
+            vprev = vcur;
+            vcur = vnxt;
+        }
+        return false;
+    }
+    if (nkv > 1) {
+        // the last tile (nothing left to stage, no barrier: its K and V^T slots are not written again)
+        const int t = nkv - 1;
+        s_last(smem + (t & 1) * K_BYTES, t * KV);
+        pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+        softmax_last();
+        vprev = vcur;
+    }
+    if (half_tail) pv_tile<F16, HD, 1>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+    else pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+
+    // ---- normalise and store: out[(b*tokens + q)][head*HD + d], 4 consecutive d per register group
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + r;
+    if constexpr (!CLASSIC) {
+        // 2^-100 < l < 2^126 (a NaN fails both comparisons): inside it the fast path is exact to bf16 rounding, see softmax_nomax
+        if (!(l_tot > 7.888609052210118e-31f && l_tot < 8.507059173023462e37f)) return true;
+    }
+    if (qi < tokens) {
+        bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+#pragma unroll
+        for (int blk = 0; blk < HD / 32; ++blk)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) =
+                    pack4<F16>(o[blk][4 * g4] * inv, o[blk][4 * g4 + 1] * inv, o[blk][4 * g4 + 2] * inv, o[blk][4 * g4 + 3] * inv);
+            }
+    }
+    return false;
+}
+
+template <bool F16, int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                   const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
+                                                   int tokens, int tokens_pad, int qblocks, int out_stride, int classic) {
+    __shared__ __attribute__((aligned(16))) char smem[Geo<HD>::LDS_BYTES];
+    if (classic) {              // HIPTS_ATTN_CLASSIC=1: the per-tile maximum everywhere (A/B runs; the fallback's own test)
+        attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+        return;
+    }
+    const bool bad = attn_body<F16, HD, false>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+    // a wave whose row sum left the window stored nothing; the workgroup (its waves stage K / V^T together) repeats the block classically
+    if (__syncthreads_or(bad ? 1 : 0)) attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+}
+
+}  // namespace
+
+int set_attention_stamps(unsigned long long* device_buffer) {
+    HIPTS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &device_buffer, sizeof(device_buffer)));
+    return HIPTS_OK;
+}
+
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
+                     int tokens_pad, bool f16, hipStream_t s, int head_dim, int out_tokens_stride) {
+    const int ost = out_tokens_stride > 0 ? out_tokens_stride : tokens;
+    HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens, "attention: tokens_pad must be a multiple of %d", KV);
+    HIPTS_REQUIRE(head_dim == 64 || head_dim == 32, "attention: head_dim must be 64 or 32");
+    const int qtiles = (tokens + 31) / 32;
+    const int qblocks = (qtiles + 3) / 4;
+    const int grid = batch * heads * qblocks;
+    static const int classic = (getenv("HIPTS_ATTN_CLASSIC") && atoi(getenv("HIPTS_ATTN_CLASSIC"))) ? 1 : 0;
+    if (head_dim == 64) {
+        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+    } else {
+        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+    }
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+}  // namespace hipts

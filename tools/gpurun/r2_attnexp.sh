@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
+timeout -k 10 200 python tools/attn_time.py 2>&1 | grep -v Warning | tee gpurun_out/attnexp.txt
+timeout -k 10 500 python -m pytest tests/test_gpu_attention.py -x -q -m gpu 2>&1 | tail -5
