@@ -50,12 +50,14 @@ __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (re
 // softmax wants to rescale O, the P V product it must include has retired.
 // q is pre-scaled by head_dim^-0.5 * log2(e) in the QK GEMM epilogue: scores are in the base-2 domain.
 // MASK (last tile only): keys >= tokens start their accumulator at -inf, which the MFMA carries through.
-template <bool MASK, bool F16, int HD>
+// GH: 32-key halves of the tile that hold a valid key (1: the last tile ends inside its first half -- the second half's MFMAs,
+// exponentials and P V steps are skipped altogether).
+template <bool MASK, bool F16, int HD, int GH = 2>
 __device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int tokens, int r, int h, const bf16x8 (&qf)[HD / 16],
                                        f32x16 (&sacc)[2]) {
     constexpr int KS = Geo<HD>::KS;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < GH; ++g) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if constexpr (MASK) sacc[g][i] = (kv0 + g * 32 + crow(i, h) >= tokens) ? -INFINITY : 0.f;
@@ -69,13 +71,13 @@ __device__ __forceinline__ void s_tile(const char* __restrict__ kt, int kv0, int
     }
 }
 
-template <bool F16, int HD>
+template <bool F16, int HD, int GH = 2>
 __device__ __forceinline__ void pv_tile(const char* __restrict__ vt, int r, int h, const bf16x8 (&pf)[2][2], f32x16 (&o)[HD / 32]) {
 #pragma unroll
     for (int blk = 0; blk < HD / 32; ++blk) {
         const char* vrow = vt + (blk * 32 + r) * VS;
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < GH; ++g)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int key = g * 32 + 16 * s2 + 4 * h;
@@ -127,11 +129,11 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
 // where the classic step above costs ~880.  Scores are log2-domain dot products of LayerNormed activations (|S| of a few tens);
 // a row whose sum does leave the window is detected at the end (attn_kernel) and the workgroup repeats the block with the
 // classic per-tile maximum, which cannot overflow.
-template <bool F16, int HD>
+template <bool F16, int HD, int GH = 2>
 __device__ __forceinline__ void softmax_nomax(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& l_run) {
     float lsum0 = 0.f, lsum1 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < GH; ++g)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float p = __builtin_amdgcn_exp2f(sacc[g][i]);
@@ -146,7 +148,7 @@ __device__ __forceinline__ void softmax_nomax(const f32x16 (&sacc)[2], bf16x8 (&
 template <bool F16, int HD, bool CLASSIC>
 __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                           const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
-                                          int qblocks, int out_stride) {
+                                          int qblocks, int out_stride, int trim) {
     using G = Geo<HD>;
     constexpr int KS = G::KS, K_BYTES = G::K_BYTES, V_BYTES = G::V_BYTES, V_BASE = G::V_BASE;
     // iteration t multiplies K(t) (slot t & 1) and V(t-1) (slot (t-1) % 3) while tile t+1 is written: K(t+1)
@@ -167,6 +169,10 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
     const int bh = wid / qblocks, qb = wid - bh * qblocks;
     const int b = bh / heads, head = bh - b * heads;
     const int q0 = (qb * 4 + wave) * 32;
+    // A wave whose 32 query rows all lie past the last token (ViT @448: 784 rows = 24.5 blocks of 32, so three of the 28 waves of an
+    // (image, head)) takes its share of the K / V^T staging and every barrier, and nothing else.  (trim = 0: the A/B switch
+    // HIPTS_ATTN_TRIM=0 -- every wave and every key half computes, as before.)
+    const bool active = !trim || q0 < tokens;
     int qrow = q0 + r;
     qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
 
@@ -220,42 +226,73 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
     bf16x8 pf[2][2];
 
     const int nkv = tokens_pad / KV;
-    const bool masked_tail = tokens_pad > tokens;
+    const int tail_keys = tokens - (nkv - 1) * KV;                 // valid keys of the last tile, 1 .. 64
+    const bool masked_tail = tail_keys < KV;
+    const bool half_tail = !CLASSIC && trim && tail_keys <= 32;     // (the classic fallback keeps one code path: -inf scores weigh 0)
+    // the last tile: unmasked, masked, or masked with only its first 32 keys computed
+    auto s_last = [&](const char* kt, int kv0) {
+        if (half_tail) s_tile<true, F16, HD, 1>(kt, kv0, tokens, r, h, qf, sacc);
+        else if (masked_tail) s_tile<true, F16, HD>(kt, kv0, tokens, r, h, qf, sacc);
+        else s_tile<false, F16, HD>(kt, kv0, tokens, r, h, qf, sacc);
+    };
+    auto softmax_last = [&]() {
+        if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+        else if (half_tail) softmax_nomax<F16, HD, 1>(sacc, pf, l_run);
+        else softmax_nomax<F16, HD>(sacc, pf, l_run);
+    };
     attn_load(0);
     attn_write(0, 0);
     __syncthreads();
-    // tile 0: scores and softmax only (its P V is issued in the next iteration)
-    if (nkv > 1) {
-        attn_load(KV);
+    // tile 0: scores and softmax only (its P V is issued with the next tile's scores)
+    if (nkv > 1) attn_load(KV);
+    if (active) {
+        if (nkv == 1) {
+            s_last(smem, 0);
+            softmax_last();
+        } else {
+            s_tile<false, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
+            if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+            else softmax_nomax<F16, HD>(sacc, pf, l_run);
+        }
     }
-    if (nkv == 1 && masked_tail) s_tile<true, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
-    else s_tile<false, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
-    if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
-    else softmax_nomax<F16, HD>(sacc, pf, l_run);
-    if (nkv > 1) {
-        attn_write(1, 1);
-    }
+    if (nkv > 1) attn_write(1, 1);
     __syncthreads();
     int vprev = 0, vcur = 1;                  // V^T slot of tile t-1 / of tile t
-    for (int t = 1; t < nkv; ++t) {
-        const int vnxt = vcur == 2 ? 0 : vcur + 1;
-        if (t + 1 < nkv) {
+    if (active) {
+        // full tiles 1 .. nkv-2: every one of them stages its successor
+        for (int t = 1; t + 1 < nkv; ++t) {
+            const int vnxt = vcur == 2 ? 0 : vcur + 1;
             attn_load((t + 1) * KV);
-        }
-        const char* kt = smem + (t & 1) * K_BYTES;
-        if (t + 1 == nkv && masked_tail) s_tile<true, F16, HD>(kt, t * KV, tokens, r, h, qf, sacc);
-        else s_tile<false, F16, HD>(kt, t * KV, tokens, r, h, qf, sacc);
-        pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
-        if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
-        else softmax_nomax<F16, HD>(sacc, pf, l_run);
-        if (t + 1 < nkv) {
+            s_tile<false, F16, HD>(smem + (t & 1) * K_BYTES, t * KV, tokens, r, h, qf, sacc);
+            pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+            if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
+            else softmax_nomax<F16, HD>(sacc, pf, l_run);
             attn_write((t + 1) & 1, vnxt);
+            __syncthreads();
+            vprev = vcur;
+            vcur = vnxt;
         }
-        __syncthreads();
-        vprev = vcur;
-        vcur = vnxt;
+    } else {
+        for (int t = 1; t + 1 < nkv; ++t) {
+            const int vnxt = vcur == 2 ? 0 : vcur + 1;
+            attn_load((t + 1) * KV);
+            attn_write((t + 1) & 1, vnxt);
+            __syncthreads();
+            vprev = vcur;
+            vcur = vnxt;
+        }
+        return false;
     }
-    pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+    if (nkv > 1) {
+        // the last tile (nothing left to stage, no barrier: its K and V^T slots are not written again)
+        const int t = nkv - 1;
+        s_last(smem + (t & 1) * K_BYTES, t * KV);
+        pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+        softmax_last();
+        vprev = vcur;
+    }
+    if (half_tail) pv_tile<F16, HD, 1>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
+    else pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
 
     // ---- normalise and store: out[(b*tokens + q)][head*HD + d], 4 consecutive d per register group
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -281,15 +318,15 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
 template <bool F16, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                    const bf16_t* __restrict__ vT, bf16_t* __restrict__ out, int heads,
-                                                   int tokens, int tokens_pad, int qblocks, int out_stride, int classic) {
+                                                   int tokens, int tokens_pad, int qblocks, int out_stride, int classic, int trim) {
     __shared__ __attribute__((aligned(16))) char smem[Geo<HD>::LDS_BYTES];
     if (classic) {              // HIPTS_ATTN_CLASSIC=1: the per-tile maximum everywhere (A/B runs; the fallback's own test)
-        attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+        attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride, trim);
         return;
     }
-    const bool bad = attn_body<F16, HD, false>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+    const bool bad = attn_body<F16, HD, false>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride, trim);
     // a wave whose row sum left the window stored nothing; the workgroup (its waves stage K / V^T together) repeats the block classically
-    if (__syncthreads_or(bad ? 1 : 0)) attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride);
+    if (__syncthreads_or(bad ? 1 : 0)) attn_body<F16, HD, true>(smem, q, k, vT, out, heads, tokens, tokens_pad, qblocks, out_stride, trim);
 }
 
 }  // namespace
@@ -303,12 +340,13 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     const int qblocks = (qtiles + 3) / 4;
     const int grid = batch * heads * qblocks;
     static const int classic = (getenv("HIPTS_ATTN_CLASSIC") && atoi(getenv("HIPTS_ATTN_CLASSIC"))) ? 1 : 0;
+    static const int trim = (getenv("HIPTS_ATTN_TRIM") && atoi(getenv("HIPTS_ATTN_TRIM")) == 0) ? 0 : 1;
     if (head_dim == 64) {
-        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
-        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+        if (f16) attn_kernel<true, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic, trim);
+        else attn_kernel<false, 64><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic, trim);
     } else {
-        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
-        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic);
+        if (f16) attn_kernel<true, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic, trim);
+        else attn_kernel<false, 32><<<grid, 256, 0, s>>>(q, k, vT, out, heads, tokens, tokens_pad, qblocks, ost, classic, trim);
     }
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
