@@ -392,19 +392,21 @@ constexpr int TOPK_SORT_TARGET = 256;
 struct Search1State;
 __device__ void search1_state_clear(Search1State* st);
 __device__ void search1_state_debug(Search1State* st, uint32_t cnt, uint32_t fast);
-constexpr int S1_BLOCK_CAP = 64;     // candidates one search1_collect_kernel workgroup (1024 documents) may hand on
+constexpr int S1_BLOCK_CAP = 64;     // candidates one search1_collect_kernel workgroup (1024 documents) may hand on: at least this many (search_one sizes it)
+constexpr int S1_GATHER_BLOCKS = 1024;  // up to this many workgroups' slots are gathered through an offset table in LDS
 
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
                                                     int32_t* __restrict__ ids_out, double* __restrict__ vals_out,
                                                     Search1State* __restrict__ pre = nullptr, const uint32_t* __restrict__ pre_cnt = nullptr,
                                                     const uint32_t* __restrict__ pre_flag = nullptr, const unsigned long long* __restrict__ pre_key = nullptr,
                                                     const uint32_t* __restrict__ pre_id = nullptr, int pre_blocks = 0,
-                                                    uint32_t* __restrict__ done_flag = nullptr, uint32_t done_seq = 0) {
+                                                    uint32_t* __restrict__ done_flag = nullptr, uint32_t done_seq = 0, int pre_cap = S1_BLOCK_CAP) {
     __shared__ uint32_t hist[4096];
     __shared__ uint64_t ckey[TOPK_CAP];
     __shared__ uint32_t cid[TOPK_CAP];
     __shared__ int scratch[17];
     __shared__ int sh_digit, sh_need, sh_bin, sh_cnt;
+    __shared__ int soff[S1_GATHER_BLOCKS];
     const int tid = threadIdx.x;
     const double* __restrict__ v = vals + (int64_t)blockIdx.x * n;
     if ((int64_t)k > n) k = (int)n;
@@ -424,8 +426,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         int mine = 0, bad = 0, other = 0;
         for (int b = tid; b < pre_blocks; b += 1024) {
             const int cb = (int)pre_cnt[b];
-            bad |= cb > S1_BLOCK_CAP;
-            mine += cb > S1_BLOCK_CAP ? S1_BLOCK_CAP : cb;
+            bad |= cb > pre_cap;
+            mine += cb > pre_cap ? pre_cap : cb;
             other |= (int)pre_flag[b];
         }
         int c;
@@ -433,13 +435,30 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         bad = __syncthreads_or(bad);
         const bool only_inf_below = __syncthreads_or(other) == 0;
         done_fast = !bad && c <= TOPK_CAP && (c >= k || only_inf_below);
-        if (done_fast) {
+        if (done_fast && pre_blocks <= S1_GATHER_BLOCKS) {
+            // one thread per CANDIDATE: its workgroup by bisection of the offsets (a workgroup may hand on hundreds when k is a large
+            // part of a small index; a thread per workgroup copying them one by one took a round trip each)
+            if (tid < pre_blocks) soff[tid] = excl;
+            __syncthreads();
+            for (int j = tid; j < c; j += 1024) {
+                int lo = 0, hi = pre_blocks - 1;                   // last block whose offset is <= j
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (soff[mid] <= j) lo = mid; else hi = mid - 1;
+                }
+                const int64_t src = (int64_t)lo * pre_cap + (j - soff[lo]);
+                ckey[j] = pre_key[src];
+                cid[j] = pre_id[src];
+            }
+            if (tid == 0) sh_cnt = c;
+            if (c < k) fill_need = k - c;
+        } else if (done_fast) {
             int off = excl;
             for (int b = tid; b < pre_blocks; b += 1024) {
                 const int cb = (int)pre_cnt[b];
                 for (int i = 0; i < cb; ++i) {
-                    ckey[off + i] = pre_key[(int64_t)b * S1_BLOCK_CAP + i];
-                    cid[off + i] = pre_id[(int64_t)b * S1_BLOCK_CAP + i];
+                    ckey[off + i] = pre_key[(int64_t)b * pre_cap + i];
+                    cid[off + i] = pre_id[(int64_t)b * pre_cap + i];
                 }
                 off += cb;
             }
@@ -1006,7 +1025,7 @@ __global__ __launch_bounds__(128) void sim1_kernel(const Sim1Query Q, const floa
 // k = 1024).  Each wave stores its maximum in its own slot: no atomics.
 __global__ __launch_bounds__(256) void search1_combine_kernel(const double* __restrict__ bm, const float* __restrict__ sim, int64_t D, double wa,
                                                               float wb, double* __restrict__ final_out, const Search1State* __restrict__ st,
-                                                              unsigned long long* __restrict__ wmax, int gw) {
+                                                              unsigned long long* __restrict__ wmax, int gw, int gl) {
     double ma;
     float mb;
     search1_maxima(st, &ma, &mb);
@@ -1026,15 +1045,17 @@ __global__ __launch_bounds__(256) void search1_combine_kernel(const double* __re
             m = fmax(m, f);
         }
     }
-    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-    if (lane == 0) wmax[group] = (unsigned long long)order_key(m);          // a group past the last document stores the image of -inf
+    // gl < 64 (only with gw == 1): the wave's 64 documents form 64 / gl groups of gl consecutive ones -- when k is a large part of a
+    // small index there must be several times k groups for the k-th largest group maximum to be a useful bound
+    for (int o = (gl >> 1); o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((lane & (gl - 1)) == 0) wmax[group * (64 / gl) + lane / gl] = (unsigned long long)order_key(m);      // a group past the last document stores the image of -inf
 }
 
 constexpr int S1_COLLECT_THREADS = 1024;
 __global__ __launch_bounds__(S1_COLLECT_THREADS) void search1_collect_kernel(const double* __restrict__ final_in, int64_t D, int k,
                                                                              const unsigned long long* __restrict__ wmax, int groups,
                                                                              uint32_t* __restrict__ bcnt, uint32_t* __restrict__ bflag,
-                                                                             unsigned long long* __restrict__ bkey, uint32_t* __restrict__ bid) {
+                                                                             unsigned long long* __restrict__ bkey, uint32_t* __restrict__ bid, int bcap) {
     __shared__ uint32_t hist[4096];
     __shared__ int scan[17];
     __shared__ int sh_dmin;
@@ -1088,9 +1109,9 @@ __global__ __launch_bounds__(S1_COLLECT_THREADS) void search1_collect_kernel(con
         base = __shfl(base, leader);
         if (take) {
             const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (slot < (uint32_t)S1_BLOCK_CAP) {
-                bkey[(int64_t)blockIdx.x * S1_BLOCK_CAP + slot] = order_key(f);
-                bid[(int64_t)blockIdx.x * S1_BLOCK_CAP + slot] = (uint32_t)d;
+            if (slot < (uint32_t)bcap) {
+                bkey[(int64_t)blockIdx.x * bcap + slot] = order_key(f);
+                bid[(int64_t)blockIdx.x * bcap + slot] = (uint32_t)d;
             }
         }
     }
@@ -1268,15 +1289,23 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     const int64_t waves = (D + 63) / 64;
     const int gw = (int)((waves + S1_GROUPS - 1) / S1_GROUPS);                   // 64 * gw documents per group
     const int blocks2 = (int)((waves + (int64_t)gw * 4 - 1) / ((int64_t)gw * 4));
-    const int groups = blocks2 * 4;
     const int blocks3 = ceil_div(D, S1_COLLECT_THREADS);
+    const int kk = (int)std::min<int64_t>(k, D);
+    // lanes per group: 64 unless that leaves fewer than 2.5 k groups (then the k-th largest group maximum bounds little: with fewer
+    // groups than k every finite score is a candidate); down to 4.  G groups give about G * -ln(1 - k / G) candidates.
+    int gl = 64;
+    while (gw == 1 && gl > 4 && D / gl < (int64_t)kk * 5 / 2) gl >>= 1;
+    const int groups = blocks2 * 4 * (64 / gl);
+    // candidate slots per collect workgroup (1024 documents): four times the expected share of ~1.7 k candidates, 64 .. 1024
+    int bcap = S1_BLOCK_CAP;
+    while (bcap < 1024 && (int64_t)bcap * D < (int64_t)4 * 1024 * 17 * kk / 10) bcap <<= 1;
     // workspace: state | group maxima u64[groups] | per-workgroup counts u32[blocks3] | flags u32[blocks3] | keys u64[blocks3][CAP] | ids u32[blocks3][CAP]
     const size_t off_wmax = (sizeof(Search1State) + 15) / 16 * 16;
     const size_t off_bcnt = off_wmax + (size_t)groups * 8;
     const size_t off_bflag = off_bcnt + (size_t)blocks3 * 4;
     const size_t off_bkey = (off_bflag + (size_t)blocks3 * 4 + 15) / 16 * 16;
-    const size_t off_bid = off_bkey + (size_t)blocks3 * S1_BLOCK_CAP * 8;
-    const size_t ws_bytes = off_bid + (size_t)blocks3 * S1_BLOCK_CAP * 4;
+    const size_t off_bid = off_bkey + (size_t)blocks3 * bcap * 8;
+    const size_t ws_bytes = off_bid + (size_t)blocks3 * bcap * 4;
     if (bm25->s1_state.bytes < ws_bytes) {
         HIPTS_TRY(bm25->s1_state.alloc(ws_bytes));
         bm25->s1_dirty = true;
@@ -1290,7 +1319,6 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     uint32_t* bflag = reinterpret_cast<uint32_t*>(ws + off_bflag);
     unsigned long long* bkey = reinterpret_cast<unsigned long long*>(ws + off_bkey);
     uint32_t* bid = reinterpret_cast<uint32_t*>(ws + off_bid);
-    const int kk = (int)std::min<int64_t>(k, D);
     const size_t out_bytes = (size_t)kk * 12;
     HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 192));
     double* hv = bm25->pin_out.as<double>();                  // pinned + mapped: the last kernel stores the results here
@@ -1320,17 +1348,17 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     {
         QueryProfScope ps(bm25, s, QP_S1_COMBINE, (double)D * 20.0);
         search1_combine_kernel<<<blocks2, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, final_dev,
-                                                       st, wmax, gw);
+                                                       st, wmax, gw, gl);
         HIPTS_LAUNCH_CHECK();
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_COLLECT, (double)D * 8.0);
-        search1_collect_kernel<<<blocks3, S1_COLLECT_THREADS, 0, s>>>(final_dev, D, kk, wmax, groups, bcnt, bflag, bkey, bid);
+        search1_collect_kernel<<<blocks3, S1_COLLECT_THREADS, 0, s>>>(final_dev, D, kk, wmax, groups, bcnt, bflag, bkey, bid, bcap);
         HIPTS_LAUNCH_CHECK();
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_TOPK, (double)kk * 24.0);
-        topk_kernel<<<1, 1024, 0, s>>>(final_dev, D, kk, oi, ov, st, bcnt, bflag, bkey, bid, blocks3, use_flag ? flag : nullptr, seq);
+        topk_kernel<<<1, 1024, 0, s>>>(final_dev, D, kk, oi, ov, st, bcnt, bflag, bkey, bid, blocks3, use_flag ? flag : nullptr, seq, bcap);
         HIPTS_LAUNCH_CHECK();
     }
     bm25->s1_dirty = false;
