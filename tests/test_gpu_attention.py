@@ -51,7 +51,9 @@ def _reference(q, k, v):
     return np.einsum("bqk,bkd->bqd", p / p.sum(axis=2, keepdims=True), v.astype(np.float64))
 
 
-@pytest.mark.parametrize("tokens,hd", [(784, 64), (1025, 64), (144, 32), (50, 64)])
+# 16: one tile cut to its first half; 64 / 128: no masked tail; 96: the last tile holds exactly 32 keys (half); 97: 33 (masked, both halves);
+# 784 / 1025: waves past the last query row (three of 28 / of 36) that only stage
+@pytest.mark.parametrize("tokens,hd", [(784, 64), (1025, 64), (144, 32), (50, 64), (16, 64), (64, 64), (96, 64), (97, 64), (128, 32)])
 def test_attention_matches_float64_softmax(tokens, hd):
     rng = np.random.default_rng(tokens + hd)
     BH = 6
