@@ -28,7 +28,7 @@ struct hipts_d2v {
     int dim = 0, negative = 5;
     double exp_scale = 83.0;
     bool has_sample = false;
-    DevBuf syn1neg, cum_table, sample_int, exp_table;
+    DevBuf syn1neg, syn_lane, cum_table, sample_int, exp_table;      // syn_lane: the lane-major copy the planned kernel gathers (below)
     DevBuf ws_ptr, ws_words, ws_v0, ws_seeds, ws_out;
 };
 
@@ -220,6 +220,33 @@ __device__ __forceinline__ uint32_t bisect_left_coarse(const uint32_t* __restric
     return b;
 }
 
+// Lane-major copy of syn1neg for the planned kernel.  A lane owns elements lane, lane + 64, ... of a row (that is what fixes the bits
+// of the dot product), so in the row-major matrix its EPL values are 256 B apart: EPL global_load_dword per row and lane, 30 vector-
+// memory instructions per word at negative = 5 -- and the wave's time went into ISSUING them (~50-75 cycles each).  Here a row is
+// stored as [64 lanes][4] blocks for c = 0..3, 4..7, ... followed by one [64][tw] block for the remaining EPL % 4 values (tw = 1, 2,
+// or 4 with padding for 3): the same values in the same registers from EPL / 4 dwordx4 loads plus at most one more (300-d: 2 loads
+// per row instead of 5, 1 280 B per row).
+__host__ __device__ inline int lane_tail_width(int epl) { return (epl & 3) == 3 ? 4 : (epl & 3); }
+__host__ __device__ inline int lane_row_floats(int epl) { return 64 * (4 * (epl >> 2) + lane_tail_width(epl)); }
+
+__global__ __launch_bounds__(256) void d2v_lane_major_kernel(const float* __restrict__ syn1neg, float* __restrict__ out, int64_t V, int dim, int epl) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= V) return;
+    const int n4 = epl >> 2, tw = lane_tail_width(epl);
+    float* __restrict__ row = out + w * lane_row_floats(epl);
+    const float* __restrict__ src = syn1neg + w * dim;
+    for (int q = 0; q < n4; ++q)
+        for (int i = 0; i < 4; ++i) {
+            const int e = lane + 64 * (4 * q + i);
+            row[(q * 64 + lane) * 4 + i] = e < dim ? src[e] : 0.0f;
+        }
+    for (int i = 0; i < tw; ++i) {
+        const int e = lane + 64 * (4 * n4 + i);
+        row[n4 * 256 + lane * tw + i] = (4 * n4 + i < epl && e < dim) ? src[e] : 0.0f;
+    }
+}
+
 template <int EPL>
 __global__ __launch_bounds__(256) void d2v_infer_plan_kernel(const float* __restrict__ syn1neg, const uint32_t* __restrict__ cum_table,
                                                              const uint32_t* __restrict__ sample_int, int64_t V, int dim,
@@ -253,10 +280,24 @@ __global__ __launch_bounds__(256) void d2v_infer_plan_kernel(const float* __rest
     uint32_t* praw = plan_raw[wv];
     uint32_t* pown = plan_own[wv];
     uint32_t* pl = plan[wv];
+    // (syn1neg here is the LANE-MAJOR copy, d2v_lane_major_kernel: dwordx4 blocks, then the tail block)
+    constexpr int N4 = EPL >> 2, TW = (EPL & 3) == 3 ? 4 : (EPL & 3), ROWF = 64 * (4 * N4 + TW);
     auto load_row = [&](uint32_t e, float (&rw)[EPL]) {
-        const float* __restrict__ row = syn1neg + (int64_t)(e & ~PLAN_POS) * dim;
+        const float* __restrict__ row = syn1neg + (int64_t)(e & ~PLAN_POS) * ROWF;
 #pragma unroll
-        for (int c = 0; c < EPL; ++c) rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
+        for (int q = 0; q < N4; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(row + (q * 64 + lane) * 4);
+            rw[4 * q] = x.x; rw[4 * q + 1] = x.y; rw[4 * q + 2] = x.z; rw[4 * q + 3] = x.w;
+        }
+        if constexpr (TW == 1) {
+            rw[4 * N4] = row[N4 * 256 + lane];
+        } else if constexpr (TW == 2) {
+            const float2 x = *reinterpret_cast<const float2*>(row + N4 * 256 + lane * 2);
+            rw[4 * N4] = x.x; rw[4 * N4 + 1] = x.y;
+        } else if constexpr (TW == 4) {
+            const float4 x = *reinterpret_cast<const float4*>(row + N4 * 256 + lane * 4);
+            rw[4 * N4] = x.x; rw[4 * N4 + 1] = x.y; rw[4 * N4 + 2] = x.z;
+        }
     };
     for (int e = 0; e < epochs; ++e) {
         uint64_t next_random = uniform64(splitmix64(seed + (uint64_t)e) & LCG_MOD);
@@ -546,6 +587,18 @@ int hipts_d2v_create(const float* syn1neg, const uint32_t* cum_table, const uint
         delete h;
         return st;
     }
+    {
+        const int epl = (dim + 63) / 64;
+        if ((st = h->syn_lane.alloc((size_t)vocab * lane_row_floats(epl) * 4))) {
+            delete h;
+            return st;
+        }
+        d2v_lane_major_kernel<<<ceil_div(vocab, 4), 256>>>(h->syn1neg.as<float>(), h->syn_lane.as<float>(), vocab, dim, epl);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            delete h;
+            return set_error(HIPTS_ERR_HIP, "hipts_d2v_create: building the lane-major copy failed");
+        }
+    }
     *out = h;
     return HIPTS_OK;
 }
@@ -585,7 +638,7 @@ int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words
     const bool planned = planned_ok && h->negative <= PLAN_MAX_NEG;
 #define D2V_LAUNCH(E)                                                                                                   \
     if (planned)                                                                                                         \
-        d2v_infer_plan_kernel<E><<<grid, 256, 0, s>>>(h->syn1neg.as<float>(), h->cum_table.as<uint32_t>(),                 \
+        d2v_infer_plan_kernel<E><<<grid, 256, 0, s>>>(h->syn_lane.as<float>(), h->cum_table.as<uint32_t>(),                \
                                              h->has_sample ? h->sample_int.as<uint32_t>() : nullptr, h->V, h->dim,      \
                                              h->ws_ptr.as<int64_t>(), h->ws_words.as<int32_t>(), ndocs,                 \
                                              h->ws_v0.as<float>(), h->ws_seeds.as<uint64_t>(), epochs, alpha, min_alpha, \
