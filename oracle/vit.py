@@ -6,6 +6,8 @@ configuration (vit_base_patch16, img 448, class_token=False, global_pool='avg',
 fc_norm=False, LayerNorm eps 1e-6, qkv_bias=True) and anchored on the reference call
 sites: tagging.py:241-243 (transform + BGR flip), :164 (stack), :174 (forward),
 :176 (sigmoid).
+The transformer blocks are additionally checked against HuggingFace transformers' ViTLayer
+(an independent implementation, present in the image) by tests/test_oracle_vit_vs_transformers.py.
 
 Input convention matches the product boundary: uint8 NHWC RGB images that are already
 448x448 (resize/center-crop are the identity for them), so the timm eval transform is
