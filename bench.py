@@ -121,6 +121,26 @@ def query_section(device):
         eng.score_topk(qs[i:i + 1], qv[i:i + 1], TOPK)
     torch.cuda.synchronize()
     single = n_single / (time.perf_counter() - t0)
+    # the same calls through the C ABI alone (hipts_search, nq = 1; arguments marshalled once per query beforehand, so this is the
+    # library's latency without the Python mirror's per-call work)
+    import ctypes as _ct
+    from hiptagsearch import _lib as _l
+    _fn = _l.load().hipts_search
+    _ids, _vals = np.empty((1, TOPK), np.int32), np.empty((1, TOPK), np.float64)
+    _calls = []
+    for i in range(n_single):
+        q = qs[i]
+        qt = np.asarray(list(q.keys()) or [0], np.int32); qw = np.asarray(list(q.values()) or [0.0], np.float64)
+        qp = np.asarray([0, len(q)], np.int32); v = np.ascontiguousarray(qv[i:i + 1])
+        _calls.append(((qt, qw, qp, v), (bm._h, idx._h, _l.ptr(qt), _l.ptr(qw), _l.ptr(qp), _l.ptr(v), 1, _ct.c_double(0.5), _ct.c_double(0.5), TOPK,
+                                        _l.ptr(_ids), _l.ptr(_vals), None, None)))
+    for _, a in _calls[:8]:
+        _fn(*a)
+    t0 = time.perf_counter()
+    for _, a in _calls:
+        rc = _fn(*a)
+    single_c_abi = n_single / (time.perf_counter() - t0)
+    assert rc == 0
     # CPU port on a bounded sample (vectorised numpy BM25 + fma-chain similarity + stable sort)
     e = bm.export()
     nq_cpu = 4
@@ -228,7 +248,7 @@ def query_section(device):
     bytes_single = D * K * 4 + bm.nnz * 8 + D * (8 + 4 + 8 + 4) + D * 20 + D * 8
     bytes_batched = D * K * 4 / 32.0 + D * (8 * 3 + 4 + 4 + 20 + 8)
     return {"metric": "top-100 queries/sec over 100k-doc index (BM25 + 300-d index product, fused)",
-            "batched_qps": batched, "single_query_qps": single, "batch": chunk,
+            "batched_qps": batched, "single_query_qps": single, "single_query_c_abi_qps": single_c_abi, "batch": chunk,
             "roofline": roof,
             "algorithmic_bytes_per_query": {"single": bytes_single, "batched": bytes_batched,
                                             "note": "batched: one 120 MB index pass per 32 queries + per-query score rows (posting lists counted per launch in roofline)"},
