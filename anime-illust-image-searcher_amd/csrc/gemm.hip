@@ -1019,7 +1019,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // phase = (m-half, j-half): 4 x 2 MFMAs, the same 256 matrix-pipe cycles -- and barriers, staging order and counted
 // waits are unchanged.  W fragments are read in phases 0/1 and kept; A fragments in phases 0 and 2.
 template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
     constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
