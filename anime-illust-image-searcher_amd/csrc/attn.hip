@@ -121,22 +121,53 @@ __device__ __forceinline__ void softmax_tile(const f32x16 (&sacc)[2], bf16x8 (&p
     }
 }
 
-// Softmax WITHOUT a running maximum (the default path).  softmax(S) V = (sum_j 2^S_j V_j) / (sum_j 2^S_j) whatever the scale, and
-// P = 2^S is kept in bf16 / fp32, whose exponent range is the same 8 bits: as long as the row's unnormalised sum l stays inside
-// [2^-100, 2^126] nothing overflows, and everything that underflows (S < -126) weighs less than 2^-16 of the row -- below the
-// 2^-9 rounding of P itself.  So a tile is 32 v_exp + 32 v_add + 16 v_cvt_pk per wave and nothing else: no maximum (17 v_max3),
-// no subtraction (32 v_sub), no rescale of O (32 v_mul + an exp) -- ~460 VALU issue cycles per 64-key tile against 512 of MFMA,
-// where the classic step above costs ~880.  Scores are log2-domain dot products of LayerNormed activations (|S| of a few tens);
-// a row whose sum does leave the window is detected at the end (attn_kernel) and the workgroup repeats the block with the
-// classic per-tile maximum, which cannot overflow.
+// Softmax with a FIXED reference exponent (the default path).  softmax(S) V = (sum_j 2^(S_j - m) V_j) / (sum_j 2^(S_j - m)) for any m,
+// so no running maximum is needed as long as nothing leaves the number format: no maximum (17 v_max3), no rescale of O (32 v_mul + an
+// exp) per tile.
+//  * bf16 operands: m = 0, P = 2^S directly.  bf16 / fp32 carry the same 8 exponent bits; while the row's unnormalised sum l stays
+//    inside [2^-100, 2^100] nothing overflowed (P, l, and O = sum P V for |V| < 2^27), and everything that underflowed (S < -126)
+//    weighs less than 2^-16 of the row -- below the 2^-9 rounding of P.  A tile is 32 v_exp + 32 v_add + 16 v_cvt_pk per wave:
+//    ~460 VALU issue cycles per 64-key tile against 512 of MFMA, where the classic step above costs ~880.
+//  * IEEE-half operands (5 exponent bits: 2^S is +inf from S = 16 on, i.e. natural-log scores of 11): m = m_ref, the row's maximum
+//    over the FIRST key tile, fixed afterwards; P = 2^(S - m_ref) costs one v_sub per score.  The largest P of tile 0 is exactly 1,
+//    so l >= 1 and whatever flushes to zero (below 2^-24 of a row whose sum is >= 1) is under the 2^-11 rounding of P itself.  A
+//    later key may exceed the reference, P > 1: while l < 2^15 every P <= l is finite in half.  (Starting the S accumulator at
+//    -m_ref would give S - m_ref for free, but the 16-register C tuple it needs takes the kernel from 156 to 172+ VGPRs and the
+//    third workgroup off the CU; measured by compiling it.)
+// A row whose sum leaves its window -- for half operands a key more than ~15 binary orders above everything among the first 64 keys
+// -- is detected at the end (attn_kernel, on the BITS of l so that a NaN cannot slip through -fno-honor-nans) and the workgroup
+// repeats the block with the classic per-tile maximum, which cannot overflow.
+// (Round 2 ran P = 2^S for half operands too, and its window check on l could not see a P that had already become +inf.)
 template <bool F16, int HD, int GH = 2>
-__device__ __forceinline__ void softmax_nomax(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& l_run) {
+__device__ __forceinline__ void softmax_first(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& l_run, float& m_ref) {
+    if constexpr (F16) {
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+#pragma unroll
+            for (int i = (g == 0 ? 1 : 0); i < 16; ++i) mx = fmaxf(mx, sacc[g][i]);
+        m_ref = fmaxf(mx, __shfl_xor(mx, 32));          // finite: tile 0 holds at least one unmasked key
+    }
     float lsum0 = 0.f, lsum1 = 0.f;
 #pragma unroll
     for (int g = 0; g < GH; ++g)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = __builtin_amdgcn_exp2f(sacc[g][i]);
+            const float p = __builtin_amdgcn_exp2f(F16 ? sacc[g][i] - m_ref : sacc[g][i]);
+            if (i & 1) lsum1 += p; else lsum0 += p;
+            pf[g][i >> 3][i & 7] = to_op<F16>(p);
+        }
+    l_run += lsum0 + lsum1;
+}
+
+template <bool F16, int HD, int GH = 2>
+__device__ __forceinline__ void softmax_nomax(const f32x16 (&sacc)[2], bf16x8 (&pf)[2][2], float& l_run, float m_ref) {
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < GH; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(F16 ? sacc[g][i] - m_ref : sacc[g][i]);
             if (i & 1) lsum1 += p; else lsum0 += p;
             pf[g][i >> 3][i & 7] = to_op<F16>(p);
         }
@@ -222,6 +253,7 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
 #pragma unroll
         for (int blk = 0; blk < HD / 32; ++blk) o[blk][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = 0.f;                  // fast path: the row's reference exponent, fixed by tile 0 (softmax_first)
     f32x16 sacc[2];
     bf16x8 pf[2][2];
 
@@ -235,10 +267,13 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
         else if (masked_tail) s_tile<true, F16, HD>(kt, kv0, tokens, r, h, qf, sacc);
         else s_tile<false, F16, HD>(kt, kv0, tokens, r, h, qf, sacc);
     };
-    auto softmax_last = [&]() {
+    auto softmax_last = [&](bool first) {
         if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
-        else if (half_tail) softmax_nomax<F16, HD, 1>(sacc, pf, l_run);
-        else softmax_nomax<F16, HD>(sacc, pf, l_run);
+        else if (first) {
+            if (half_tail) softmax_first<F16, HD, 1>(sacc, pf, l_run, m_ref);
+            else softmax_first<F16, HD>(sacc, pf, l_run, m_ref);
+        } else if (half_tail) softmax_nomax<F16, HD, 1>(sacc, pf, l_run, m_ref);
+        else softmax_nomax<F16, HD>(sacc, pf, l_run, m_ref);
     };
     attn_load(0);
     attn_write(0, 0);
@@ -248,11 +283,11 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
     if (active) {
         if (nkv == 1) {
             s_last(smem, 0);
-            softmax_last();
+            softmax_last(true);
         } else {
             s_tile<false, F16, HD>(smem, 0, tokens, r, h, qf, sacc);
             if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
-            else softmax_nomax<F16, HD>(sacc, pf, l_run);
+            else softmax_first<F16, HD>(sacc, pf, l_run, m_ref);
         }
     }
     if (nkv > 1) attn_write(1, 1);
@@ -266,7 +301,7 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
             s_tile<false, F16, HD>(smem + (t & 1) * K_BYTES, t * KV, tokens, r, h, qf, sacc);
             pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
             if constexpr (CLASSIC) softmax_tile<F16, HD>(sacc, pf, o, m_run, l_run);
-            else softmax_nomax<F16, HD>(sacc, pf, l_run);
+            else softmax_nomax<F16, HD>(sacc, pf, l_run, m_ref);
             attn_write((t + 1) & 1, vnxt);
             __syncthreads();
             vprev = vcur;
@@ -288,7 +323,7 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
         const int t = nkv - 1;
         s_last(smem + (t & 1) * K_BYTES, t * KV);
         pv_tile<F16, HD>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
-        softmax_last();
+        softmax_last(false);
         vprev = vcur;
     }
     if (half_tail) pv_tile<F16, HD, 1>(smem + V_BASE + vprev * V_BYTES, r, h, pf, o);
@@ -299,8 +334,11 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
     const float inv = 1.0f / l_tot;
     const int qi = q0 + r;
     if constexpr (!CLASSIC) {
-        // 2^-100 < l < 2^126 (a NaN fails both comparisons): inside it the fast path is exact to bf16 rounding, see softmax_nomax
-        if (!(l_tot > 7.888609052210118e-31f && l_tot < 8.507059173023462e37f)) return true;
+        // 0.5 <= l < 2^15 (half) / 2^-100 <= l < 2^100 (bf16), tested on the bit pattern: positive floats order like their bits, a
+        // negative value or a NaN (>= 0x7f800001, or sign bit set) falls outside whatever the compiler assumes about NaNs
+        const uint32_t lb = __float_as_uint(l_tot);
+        constexpr uint32_t LO = F16 ? 0x3f000000u : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
+        if (!(lb >= LO && lb < HI)) return true;
     }
     if (qi < tokens) {
         bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;

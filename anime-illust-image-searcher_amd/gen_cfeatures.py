@@ -69,8 +69,9 @@ def main(arg_str: list) -> None:
     parser.add_argument('--device', type=int, default=0)
     parser.add_argument('--workers', type=int, default=0,
                         help='decode / resize in this many processes (hiptagsearch/pipeline.py); the uint8 images go to the device u8 entry point')
-    parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='bf16',
-                        help='MFMA operand type of the encoder GEMMs (e4m3 = the fp8 mode: faster, 3 mantissa bits)')
+    parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='half',
+                        help='MFMA operand type of the encoder GEMMs (half: same matrix rate as bf16, 8x smaller activation rounding; '
+                             'e4m3 = the fp8 mode: 3 mantissa bits)')
     parser.add_argument('--arch', choices=['b36', 'tiny'], default='b36', help='b36: CAFormer-B36 widths @384 (the CCIP encoder); tiny: test geometry')
     args = parser.parse_args(arg_str)
     after_date = None

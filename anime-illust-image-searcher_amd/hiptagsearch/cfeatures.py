@@ -110,7 +110,7 @@ class CCIPEncoder:
         self.out_dim = int(cfg["dims"][3])
         c = _lib.CcipConfig(cfg["image_size"], (ctypes.c_int32 * 4)(*cfg["dims"]), (ctypes.c_int32 * 4)(*cfg["depths"]),
                             cfg.get("head_dim", 32), cfg.get("attn_from_stage", 2), cfg.get("ln_eps", 1e-6), max_batch,
-                            cfg.get("operand_f16", 0))
+                            cfg.get("operand_f16", 1))     # IEEE-half operands by default, as ViTTagger / EvaTagger
         self._h = ctypes.c_void_p()
         _lib.call("hipts_ccip_create", ctypes.byref(c), device, ctypes.byref(self._h))
         for key, val in weights.items():

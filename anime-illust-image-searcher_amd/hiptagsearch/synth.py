@@ -38,11 +38,51 @@ def _trunc_normal(rng, shape, std):
     return x
 
 
-def vit_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[str, np.ndarray]:
+def _trained_like_qk(rng, w: Dict[str, np.ndarray], key_q: str, key_k: str, row0_q: int, row0_k: int, li: int, heads: int, hd: int,
+                      bias_q: str = None, bias_k: str = None) -> None:
+    """Scale the q and k projection rows of every head by powers of two (exact in bf16) so that attention scores look like a
+    trained model's instead of a random init's (score std 0.33: a near-uniform softmax): ordinary heads x4 / x2 (natural-log score
+    std ~2.6, row maxima ~9), and in every fourth layer head 0 x8 / x4 (std ~10, maxima 30-40: a heavy tail that exceeds an
+    IEEE-half 2^S outright and, for a good part of its rows, the fixed-reference window of attn.hip, so the classic fallback runs)."""
+    for h in range(heads):
+        sq, sk = (8.0, 4.0) if (h == 0 and li % 4 == 1) else (4.0, 2.0)
+        w[key_q][row0_q + h * hd:row0_q + (h + 1) * hd] *= np.float32(sq)
+        w[key_k][row0_k + h * hd:row0_k + (h + 1) * hd] *= np.float32(sk)
+        if bias_q is not None:
+            w[bias_q][row0_q + h * hd:row0_q + (h + 1) * hd] *= np.float32(sq)
+        if bias_k is not None:
+            w[bias_k][row0_k + h * hd:row0_k + (h + 1) * hd] *= np.float32(sk)
+
+
+def _trained_like_head(rng, w: Dict[str, np.ndarray], num_classes: int) -> None:
+    """A tagger head whose outputs look like a trained one's: weights x4 (exact), biases bimodal -- about 28 general and 3
+    character labels (a fixed random set per checkpoint) sit at +5, everything else at -10, one rating at +3.  Probabilities are
+    then sparse: the MCut gap falls between the two clusters and 10-40 labels are selected per image, logit rms ~10."""
+    _, cat = label_table(num_classes)
+    w["head.weight"] *= np.float32(4.0)
+    b = (-10.0 + rng.standard_normal(num_classes)).astype(np.float32)
+    gen = np.flatnonzero(cat == 0)
+    ch = np.flatnonzero(cat == 4)
+    n_gen = min(28, max(1, len(gen) // 8))
+    n_ch = min(3, max(1, len(ch) // 8)) if len(ch) else 0
+    hi = list(rng.choice(gen, size=n_gen, replace=False)) + (list(rng.choice(ch, size=n_ch, replace=False)) if n_ch else [])
+    b[hi] = (5.0 + 0.5 * rng.standard_normal(len(hi))).astype(np.float32)
+    rating = np.flatnonzero(cat == 9)
+    if len(rating):
+        b[rating] = -3.0
+        b[rating[0]] = 3.0
+    w["head.bias"] = b
+
+
+def vit_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True, trained_like: bool = False) -> Dict[str, np.ndarray]:
     """Random-init checkpoint with timm state_dict keys.  W ~ N(0,0.02^2) truncated at 2 sigma,
     biases ~ N(0,0.02^2), LN gamma ~ U(0.5,1.5), LN beta ~ N(0,0.02^2), pos_embed ~ N(0,0.02^2).
     With bf16_matrices the GEMM weight matrices are bf16-representable (a bf16 checkpoint, as
-    config[1] names), so the float32 oracle and the bf16 MFMA path see identical weights."""
+    config[1] names), so the float32 oracle and the bf16 MFMA path see identical weights.
+    trained_like: the same tensors with the q / k projections and the head rescaled (by powers of two) and the head bias made
+    bimodal, see _trained_like_qk / _trained_like_head: peaked attention with a heavy tail, logit rms ~10, sparse probabilities,
+    tens of labels selected per image -- the regime a trained wd-tagger runs in, which a plain random init (logit rms 0.35, every
+    probability near 0.5, ~3000 labels "selected") never visits."""
     rng = np.random.default_rng(seed)
     D, P, M, C = cfg["dim"], cfg["patch"], cfg["mlp_dim"], cfg["num_classes"]
     N = (cfg["image_size"] // P) ** 2
@@ -68,12 +108,19 @@ def vit_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[st
     w["norm.bias"] = _trunc_normal(rng, (D,), 0.02)
     w["head.weight"] = rb(_trunc_normal(rng, (C, D), 0.02))
     w["head.bias"] = _trunc_normal(rng, (C,), 0.02)
+    if trained_like:
+        rng2 = np.random.default_rng(seed + 7919)
+        H = cfg["heads"]
+        for i in range(cfg["depth"]):
+            p = "blocks.%d." % i
+            _trained_like_qk(rng2, w, p + "attn.qkv.weight", p + "attn.qkv.weight", 0, D, i, H, D // H, p + "attn.qkv.bias", p + "attn.qkv.bias")
+        _trained_like_head(rng2, w, C)
     return w
 
 
-def eva_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[str, np.ndarray]:
+def eva_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True, trained_like: bool = False) -> Dict[str, np.ndarray]:
     """Random-init EVA02 checkpoint with timm `Eva` state_dict keys (q/k/v separate, SwiGLU with inner norm),
-    same distributions as vit_weights."""
+    same distributions as vit_weights (and the same trained_like variant)."""
     rng = np.random.default_rng(seed)
     D, P, Hd, C = cfg["dim"], cfg["patch"], cfg["mlp_hidden"], cfg["num_classes"]
     N = (cfg["image_size"] // P) ** 2
@@ -106,6 +153,13 @@ def eva_weights(cfg: Dict, seed: int = 0, bf16_matrices: bool = True) -> Dict[st
     w["fc_norm.bias"] = _trunc_normal(rng, (D,), 0.02)
     w["head.weight"] = rb(_trunc_normal(rng, (C, D), 0.02))
     w["head.bias"] = _trunc_normal(rng, (C,), 0.02)
+    if trained_like:
+        rng2 = np.random.default_rng(seed + 7919)
+        H = cfg["heads"]
+        for i in range(cfg["depth"]):
+            p = "blocks.%d." % i
+            _trained_like_qk(rng2, w, p + "attn.q_proj.weight", p + "attn.k_proj.weight", 0, 0, i, H, D // H, p + "attn.q_proj.bias", None)
+        _trained_like_head(rng2, w, C)
     return w
 
 
@@ -160,6 +214,53 @@ def ccip_weights(cfg: Dict, seed: int = 46, bf16_matrices: bool = True) -> Dict[
 
 def images_u8(n: int, size: int = 448, seed: int = 1234) -> np.ndarray:
     return np.random.default_rng(seed).integers(0, 256, (n, size, size, 3), dtype=np.uint8)
+
+
+STRUCTURED_KINDS = ("flat", "posterised", "gradient", "lineart", "halfflat", "blocks")
+
+
+def structured_images_u8(size: int = 448, seed: int = 77, kinds=STRUCTURED_KINDS) -> np.ndarray:
+    """One uint8 [len(kinds), size, size, 3] image per kind -- what illustrations are made of, and what uniform noise never shows a
+    16-bit datapath: large regions in which every patch is IDENTICAL, so that an operand's rounding error is the same on every token
+    and does not average out in the mean pool (the case that takes bf16 operands to ~4e-3 logit error).
+      flat        one colour                         posterised  noise quantised to 4 levels per channel
+      gradient    smooth diagonal colour ramp        lineart     black strokes, 1-3 px wide, on white
+      halfflat    left half one colour, right noise  blocks      64 x 64 px tiles of flat colour (cel shading)"""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((len(kinds), size, size, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size]
+    for i, kind in enumerate(kinds):
+        if kind == "flat":
+            out[i] = rng.integers(0, 256, 3, dtype=np.uint8)
+        elif kind == "posterised":
+            out[i] = (rng.integers(0, 256, (size, size, 3), dtype=np.uint8) // 64) * 64
+        elif kind == "gradient":
+            c0, c1 = rng.integers(0, 256, 3).astype(np.float64), rng.integers(0, 256, 3).astype(np.float64)
+            t = ((xx + yy) / (2.0 * (size - 1)))[..., None]
+            out[i] = np.rint(c0 * (1 - t) + c1 * t).astype(np.uint8)
+        elif kind == "lineart":
+            img = np.full((size, size, 3), 255, dtype=np.uint8)
+            for _ in range(24):
+                x0, y0, x1, y1 = rng.integers(0, size, 4)
+                wd = int(rng.integers(1, 4))
+                n = int(max(abs(x1 - x0), abs(y1 - y0))) + 1
+                xs = np.rint(np.linspace(x0, x1, n)).astype(int)
+                ys = np.rint(np.linspace(y0, y1, n)).astype(int)
+                for d in range(wd):
+                    img[np.clip(ys + d, 0, size - 1), xs] = 0
+                    img[ys, np.clip(xs + d, 0, size - 1)] = 0
+            out[i] = img
+        elif kind == "halfflat":
+            out[i] = rng.integers(0, 256, (size, size, 3), dtype=np.uint8)
+            out[i, :, :size // 2] = rng.integers(0, 256, 3, dtype=np.uint8)
+        elif kind == "blocks":
+            bs = max(8, size // 7)
+            nb = (size + bs - 1) // bs
+            cols = rng.integers(0, 256, (nb, nb, 3), dtype=np.uint8)
+            out[i] = np.repeat(np.repeat(cols, bs, axis=0), bs, axis=1)[:size, :size]
+        else:
+            raise ValueError(kind)
+    return out
 
 
 def label_table(num_classes: int = 10861) -> Tuple[List[str], np.ndarray]:
