@@ -1,0 +1,684 @@
+// attn2.hip -- fused softmax(Q K^T) V, head_dim 64, round 3 (ViT-B/16 and EVA02; timm Attention inside tagging.py:174).
+//
+// What changed against attn.hip (which still serves head_dim 32, the CAFormer):
+//   * K and V tiles of 64 keys reach LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into a ring of three K and
+//     three V slots (K two tiles ahead, V one): no staging registers, no ds_write pass, one counted vmcnt + one raw s_barrier per tile.
+//   * V stays in its natural [token][d] layout (the QKV GEMM needs no transposing epilogue any more); the V^T fragment of
+//     O^T = V^T P^T comes out of the row-major tile by ds_read_b64_tr_b16.
+//   * a wave owns QB = 2 blocks of 32 query rows: one K / V fragment read feeds two MFMAs (half the LDS instructions per flop).
+//   * four waves per workgroup, two workgroups per CU: the two waves that share a SIMD belong to DIFFERENT workgroups, so no
+//     barrier keeps them in phase and one's softmax runs under the other's MFMAs.
+//   * the query blocks of an (image, head) are dealt to its workgroups evenly (784 rows = 13 blocks of 64 -> 4 + 3 + 3 + 3)
+//     instead of leaving a last workgroup with a single busy wave.
+//   * O leaves through v_permlane32_swap pairs as 16 B pieces (cdna_hip_programming.md T21).
+//
+// Arithmetic is attn.hip's: S^T = K Q^T on v_mfma_f32_32x32x16 (query on the lane, so the softmax is lane-local), the S^T accumulator
+// converted to 16 bit is directly the B operand of O^T = V^T P^T, scores in the base-2 domain (q pre-scaled by head_dim^-0.5 log2 e),
+// softmax with a FIXED reference exponent (see attn.hip: bf16 operands P = 2^S, half operands P = 2^(S - m_ref) with m_ref the row's
+// maximum over the first key tile) and the classic per-tile-maximum body as the fallback of a workgroup whose row sum leaves the window.
+//
+// LDS images (both 128 B per key row, filled lane-linear by the DMA with the swizzle on the SOURCE chunk):
+//   K  chunk c of row r at position c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group read 16 different 16 B slots.
+//   V  chunk c of row r at position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B a half-wave of ds_read_b64_tr_b16 covers
+//      lie in the four different 64 B quarters of the 64 banks.
+#include <type_traits>
+
+#include "vit_internal.h"
+
+namespace hipts {
+namespace {
+
+#ifndef HIPTS_ATTN2_SEQ_WAVES
+#define HIPTS_ATTN2_SEQ_WAVES 3          // waves per SIMD the sequential body (MODE 1) is compiled for: 4 -> 128 registers, 3 -> 168
+#endif
+constexpr int KV = 64;                   // keys per tile
+constexpr int HD = 64;
+constexpr int TILE = KV * HD * 2;        // 8 KiB
+constexpr int NSK = 3, NSV = 3;          // ring slots: K two tiles ahead, V one (its tile t - 1 is still being multiplied during step t)
+constexpr int V_BASE = NSK * TILE;
+constexpr int LDS_BYTES = (NSK + NSV) * TILE;      // 48 KiB: three workgroups per CU
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#ifdef HIPTS_X_STAMPS                               // measurement-only build: cycle stamps of one wave (tools/gpurun/r3_attn_x.sh)
+__device__ unsigned long long g_attn2_stamps[4096];
+#define HIPTS_STAMP(slot)                                                                                 \
+    do {                                                                                                  \
+        if (stamp_on) {                                                                                   \
+            const unsigned long long ts_ = __builtin_amdgcn_s_memtime();                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+            if (lane == 0) g_attn2_stamps[(slot)] = ts_;                                                  \
+        }                                                                                                 \
+    } while (0)
+#else
+#define HIPTS_STAMP(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else static_assert(N < 0, "unsupported count");
+}
+
+// One workgroup's pass over its query blocks with the fixed-reference softmax.  Returns true when a row sum left its window
+// (nothing is stored then; the workgroup repeats the blocks with attn2_classic).
+template <bool F16, int QB, int NW>
+__device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                           const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
+                                           int bh, int blk0, int nblk, int out_stride) {
+    constexpr int PCS = 8 / NW;                      // 1 KiB pieces of a K (and of a V) tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bool active = wave < nblk;
+    const int q0 = (blk0 + wave) * (32 * QB);
+    const int b = bh / heads, head = bh - b * heads;
+
+    // ---- LDS-DMA sources: piece = 8 key rows x 128 B; lane l fills position l & 7 of row l >> 3 with the chunk the image wants there
+    const bf16_t* kg[PCS];
+    const bf16_t* vg[PCS];
+    int dst[PCS];
+#pragma unroll
+    for (int pc = 0; pc < PCS; ++pc) {
+        const int piece = wave + NW * pc;
+        const int row = piece * 8 + (lane >> 3);
+        kg[pc] = k + ((size_t)bh * tokens_pad + row) * HD + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+        vg[pc] = v + ((size_t)bh * tokens_pad + row) * HD + (((lane & 7) ^ (((row >> 1) & 1) << 2)) * 8);
+        dst[pc] = piece * 1024;
+    }
+    auto stage_k = [&](int t) __attribute__((always_inline)) {                      // tile t -> K slot t % 3
+#pragma unroll
+        for (int pc = 0; pc < PCS; ++pc) glds16(kg[pc] + (size_t)t * (KV * HD), smem + (t % NSK) * TILE + dst[pc]);
+    };
+    auto stage_v = [&](int t) __attribute__((always_inline)) {                      // tile t -> V slot t % 3
+#pragma unroll
+        for (int pc = 0; pc < PCS; ++pc) glds16(vg[pc] + (size_t)t * (KV * HD), smem + V_BASE + (t % NSV) * TILE + dst[pc]);
+    };
+
+    // ---- Q^T fragments (B operand): lane (query r, half h), k-step s: d = 16 s + 8 h .. + 7
+    bf16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qrow = q0 + 32 * qb + r;
+        qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
+        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    const int nkv = tokens_pad / KV;
+    stage_k(0);                                      // issue order K0 V0 K1 | step 0: V1 K2 | step 1: V2 K3 | ...: at the top of step t the
+    stage_v(0);                                      // youngest requests are K(t + 1)'s, everything older -- K(t), V(t) -- is what vmcnt(PCS) waits for
+    if (nkv > 1) stage_k(1);
+
+    // ---- fragment addresses inside a tile
+    int ka[4];                                       // K row r, logical chunk 2 s + h
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) * 16);
+    int va[2];                                       // V: lane 4 qd + p of a 16-lane group -> row 4 h + qd, columns 16 dgrp + 4 p .. + 3 (+ 32 blk)
+    {
+        const int l16 = lane & 15, qd = l16 >> 2, p = l16 & 3, dgrp = (lane >> 4) & 1;
+        const int x = qd >> 1;                       // ((row >> 1) & 1) for row = 4 h + qd (+ multiples of 8)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) va[blk] = (4 * h + qd) * 128 + (2 * dgrp + (p >> 1) + 4 * (blk ^ x)) * 16 + (p & 1) * 8;
+    }
+
+    f32x16 o[QB][2], sacc[QB][2];
+    bf16x8 pf[QB][2][2];
+    float l_run[QB], m_ref[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        l_run[qb] = 0.f;
+        m_ref[qb] = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qb][blk][i] = 0.f;
+    }
+
+    const int tail_keys = tokens - (nkv - 1) * KV;                 // valid keys of the last tile, 1 .. 64
+    const bool half_tail = tail_keys <= 32;                         // the last tile's second 32-key half holds no valid key: skipped altogether
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // S^T of tile t (K slot t % 3), 32-key half g.  LAST: keys >= tokens start at -inf (the MFMA carries it through)
+    auto s_half = [&](const char* kt, int t, auto g_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        constexpr int g = decltype(g_c)::value;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if constexpr (LAST) sacc[qb][g][i] = (t * KV + g * 32 + crow(i, h) >= tokens) ? -INFINITY : 0.f;
+                else sacc[qb][g][i] = 0.f;
+            }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + g * 4096 + ka[s]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sacc[qb][g] = mfma_32x32x16<F16>(kf, qf[qb][s], sacc[qb][g]);
+        }
+    };
+    // O^T += V^T P^T for the 32-key half g of the V tile
+    auto pv_half = [&](const char* vt, auto g_c) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_c)::value;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* p0 = vt + va[blk] + (32 * g + 16 * s2) * 128;
+                const bf16x4 lo = tr_read(p0);
+                const bf16x4 hi = tr_read(p0 + 8 * 128);
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[qb][blk] = mfma_32x32x16<F16>(vf, pf[qb][g][s2], o[qb][blk]);
+            }
+    };
+    // softmax of the 32-key halves [0, GH) of sacc -> pf
+    auto softmax = [&](auto first_c, auto gh_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int GH = decltype(gh_c)::value;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            {
+                if constexpr (F16 && FIRST) {
+                    float mx = sacc[qb][0][0];
+#pragma unroll
+                    for (int g = 0; g < GH; ++g)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[qb][g][i]);
+                    m_ref[qb] = fmaxf(mx, __shfl_xor(mx, 32));      // finite: tile 0 holds at least one unmasked key
+                }
+                float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+                for (int g = 0; g < GH; ++g) {
+                    bf16x8 w0, w1;                    // whole-vector writes into pf: element-wise writes sent the array to scratch memory (QB = 2)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float p0 = __builtin_amdgcn_exp2f(F16 ? sacc[qb][g][i] - m_ref[qb] : sacc[qb][g][i]);
+                        const float p1 = __builtin_amdgcn_exp2f(F16 ? sacc[qb][g][8 + i] - m_ref[qb] : sacc[qb][g][8 + i]);
+                        if (i & 1) ls1 += p0 + p1; else ls0 += p0 + p1;
+                        w0[i] = to_op<F16>(p0);
+                        w1[i] = to_op<F16>(p1);
+                    }
+                    pf[qb][g][0] = w0;
+                    pf[qb][g][1] = w1;
+                }
+                l_run[qb] += ls0 + ls1;
+            }
+        }
+    };
+    // One tile step.  K(t) and V(t) have landed (every wave waited for its own pieces, then the barrier); V(t + 1) and K(t + 2) are
+    // requested into the slots that V(t - 2) and K(t - 1) were last read from before this barrier; then S(t), P V of tile t - 1, softmax(t).
+    auto step = [&](int t, auto first_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        if constexpr (LAST) wait_vm<0>();
+        else wait_vm<PCS>();                         // leaves K(t + 1) in flight
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nkv) stage_v(t + 1);
+        if (t + 2 < nkv) stage_k(t + 2);
+        if (!active) return;
+        const char* kt = smem + (t % NSK) * TILE;
+        const char* vt = smem + V_BASE + ((t + NSV - 1) % NSV) * TILE;
+        s_half(kt, t, I0{}, last_c);
+        if constexpr (QB > 1) __builtin_amdgcn_sched_barrier(0);
+        if (!(LAST && half_tail)) s_half(kt, t, I1{}, last_c);
+        if constexpr (QB > 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!FIRST) {
+            pv_half(vt, I0{});
+            if constexpr (QB > 1) __builtin_amdgcn_sched_barrier(0);
+            pv_half(vt, I1{});
+            if constexpr (QB > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (LAST && half_tail) softmax(first_c, std::integral_constant<int, 1>{});
+        else softmax(first_c, std::integral_constant<int, 2>{});
+    };
+
+    if (nkv == 1) step(0, T_{}, T_{});
+    else {
+        step(0, T_{}, F_{});
+        for (int t = 1; t + 1 < nkv; ++t) step(t, F_{}, F_{});
+        step(nkv - 1, F_{}, T_{});
+    }
+    if (!active) return false;
+    {
+        const char* vt = smem + V_BASE + ((nkv - 1) % NSV) * TILE;
+        pv_half(vt, I0{});
+        if (!half_tail) pv_half(vt, I1{});
+    }
+
+    // ---- normalise and store: out[(b * out_stride + query)][head * 64 + d]; o[qb][blk][i] = (query q0 + 32 qb + r, d = 32 blk + crow(i, h))
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        {   // 0.5 <= l < 2^15 (half) / 2^-100 <= l < 2^100 (bf16) on the bit pattern: a NaN or a negative value fails whatever -fno-honor-nans assumes
+            const uint32_t lb = __float_as_uint(l_tot);
+            constexpr uint32_t LO = F16 ? 0x3f000000u : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
+            if (!(lb >= LO && lb < HI)) bad = true;
+        }
+        l_run[qb] = 1.0f / l_tot;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) return true;      // wave-uniform: the lane swaps below need every lane
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float inv = l_run[qb];
+        const int qi = q0 + 32 * qb + r;
+        bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+        // quad kq (0 .. 7) of this lane = registers 4 (kq & 3) .. + 3 of blk = kq >> 2 -> d = 32 blk + 8 (kq & 3) + 4 h + (0 .. 3): the two
+        // halves of a query's 16 B chunk sit in lanes r and r + 32.  Swap so that lane h = 0 holds whole chunks of the even quads and
+        // lane h = 1 of the odd ones (cdna_hip_programming.md T21), then 4 stores of 16 B per lane instead of 8 of 8 B.
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {
+            const int ke = 2 * kp, ko = 2 * kp + 1;
+            const f32x16& oe = o[qb][ke >> 2];
+            const f32x16& oo = o[qb][ko >> 2];
+            const int ie = 4 * (ke & 3), io = 4 * (ko & 3);
+            const bf16x4 we = pack4<F16>(oe[ie] * inv, oe[ie + 1] * inv, oe[ie + 2] * inv, oe[ie + 3] * inv);
+            const bf16x4 wo = pack4<F16>(oo[io] * inv, oo[io + 1] * inv, oo[io + 2] * inv, oo[io + 3] * inv);
+            const uint2 ue = __builtin_bit_cast(uint2, we), uo = __builtin_bit_cast(uint2, wo);
+            // v_permlane32_swap a, b: a.lanes[32..63] <-> b.lanes[0..31].  With a = the even quad's word and b = the odd quad's:
+            // afterwards lane h = 0 holds (a = its own even word, b = its partner's even word) = d + 0..3 | d + 4..7 of the even chunk,
+            // lane h = 1 holds (a = its partner's odd word, b = its own odd word) = the odd chunk, in that order as well.
+            uint32_t a0 = ue.x, b0 = uo.x, a1 = ue.y, b1 = uo.y;
+            {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                a0 = r0[0]; b0 = r0[1];
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                a1 = r1[0]; b1 = r1[1];
+            }
+            const int kq = h ? ko : ke;              // the chunk this lane now owns: d = 32 (kq >> 2) + 8 (kq & 3) .. + 7
+            if (qi < tokens) *reinterpret_cast<uint4*>(op + 32 * (kq >> 2) + 8 * (kq & 3)) = make_uint4(a0, a1, b0, b1);
+        }
+    }
+    return false;
+}
+
+// The same pass with the least state per wave (MODE 1): the two 32-key halves of a tile go S -> softmax -> P V one after the other, so a
+// wave holds one 32 x 32 score block instead of two plus a lagging P (about 100 registers instead of 150-160): four waves per SIMD, and
+// the overlap of one wave's softmax with another's MFMAs is left entirely to the hardware.  Ring: two K and two V slots (one tile ahead).
+template <bool F16, int NW>
+__device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                               const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
+                                               int bh, int blk0, int nblk, int out_stride) {
+    constexpr int PCS = 8 / NW;
+    constexpr int VB = 2 * TILE;                     // V slots behind the two K slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: LDS-DMA bases and the active test stay scalar
+    const int r = lane & 31, h = lane >> 5;
+    const bool active = wave < nblk;
+    const int q0 = (blk0 + wave) * 32;
+    const int b = bh / heads, head = bh - b * heads;
+    const int nkv = tokens_pad / KV;
+
+#ifdef HIPTS_X_STAMPS
+    const bool stamp_on = blockIdx.x == HIPTS_X_STAMPS && wave == 0;
+#endif
+    unsigned kgo[PCS], vgo[PCS];                     // element offsets of this lane's DMA sources inside a tile
+#pragma unroll
+    for (int pc = 0; pc < PCS; ++pc) {
+        const int row = (wave + NW * pc) * 8 + (lane >> 3);
+        kgo[pc] = row * HD + (((lane & 7) ^ ((row >> 1) & 7)) * 8);
+        vgo[pc] = row * HD + (((lane & 7) ^ (((row >> 1) & 1) << 2)) * 8);
+    }
+    const bf16_t* kb = k + (size_t)bh * tokens_pad * HD;
+    const bf16_t* vb = v + (size_t)bh * tokens_pad * HD;
+    auto stage = [&](int t) __attribute__((always_inline)) {
+        const int sl = (t & 1) * TILE;
+#pragma unroll
+        for (int pc = 0; pc < PCS; ++pc) glds16(kb + (size_t)t * (KV * HD) + kgo[pc], smem + sl + (wave + NW * pc) * 1024);
+#pragma unroll
+        for (int pc = 0; pc < PCS; ++pc) glds16(vb + (size_t)t * (KV * HD) + vgo[pc], smem + VB + sl + (wave + NW * pc) * 1024);
+    };
+    bf16x8 qf[4];
+    {
+        int qrow = q0 + r;
+        qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
+        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    stage(0);
+    int ka[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) * 16);
+    int va[2];
+    {
+        const int l16 = lane & 15, qd = l16 >> 2, p = l16 & 3, dgrp = (lane >> 4) & 1;
+        const int x = qd >> 1;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) va[blk] = VB + (4 * h + qd) * 128 + (2 * dgrp + (p >> 1) + 4 * (blk ^ x)) * 16 + (p & 1) * 8;
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
+    float l_run = 0.f, m_ref = 0.f;
+    const int tail_keys = tokens - (nkv - 1) * KV;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    // one 32-key half: S, softmax, P V.  The four K fragments are requested together before the first S MFMA and the eight V^T pieces
+    // before the softmax, so that each group's LDS latency is paid once and the V^T pieces land under the exponentials
+    // (left to itself hipcc reads one fragment, waits, multiplies, reads the next: the matrix pipe idles ~100 cycles per MFMA).
+    auto half = [&](int t, int sl, int g, auto first_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        // half operands: the accumulator starts at -m_ref, so S - m_ref comes out of the MFMAs (hipcc keeps the 16-register tuple across the
+        // loop; 32 v_sub per tile otherwise).  The very first half (FIRST) defines m_ref and subtracts explicitly.
+        constexpr bool PRESUB = F16 && !FIRST;
+        const float c0 = PRESUB ? -m_ref : 0.f;
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (LAST) sacc[i] = (t * KV + g * 32 + crow(i, h) >= tokens) ? -INFINITY : c0;
+            else sacc[i] = c0;
+        }
+        bf16x8 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(smem + sl + g * 4096 + ka[s]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc = mfma_32x32x16<F16>(kf[s], qf[s], sacc);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMA
+        HIPTS_STAMP(t * 16 + g * 8 + 2);
+        bf16x8 vf[2][2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const char* p0 = smem + sl + va[blk] + (32 * g) * 128;
+            const bf16x4 a0 = tr_read(p0), a1 = tr_read(p0 + 8 * 128), b0 = tr_read(p0 + 16 * 128), b1 = tr_read(p0 + 24 * 128);
+            vf[blk][0] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            vf[blk][1] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // 8 DS reads (transposed)
+        if constexpr (F16 && FIRST) {                // the reference: this row's maximum over the first 32 keys
+            float mx = sacc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
+            m_ref = fmaxf(mx, __shfl_xor(mx, 32));
+        }
+        bf16x8 w0, w1;
+        float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#ifdef HIPTS_X_NOEXP
+            const float p0 = (F16 && !PRESUB) ? sacc[i] - m_ref : sacc[i], p1 = (F16 && !PRESUB) ? sacc[8 + i] - m_ref : sacc[8 + i];
+#else
+            const float p0 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[i] - m_ref : sacc[i]);
+            const float p1 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[8 + i] - m_ref : sacc[8 + i]);
+#endif
+#ifndef HIPTS_X_NOSUM
+            if (i & 1) ls1 += p0 + p1; else ls0 += p0 + p1;
+#endif
+            w0[i] = to_op<F16>(p0);
+            w1[i] = to_op<F16>(p1);
+        }
+#ifdef HIPTS_X_NOSUM
+        ls0 = sacc[0];
+#endif
+        l_run += ls0 + ls1;
+        HIPTS_STAMP(t * 16 + g * 8 + 3);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            o[blk] = mfma_32x32x16<F16>(vf[blk][0], w0, o[blk]);
+            o[blk] = mfma_32x32x16<F16>(vf[blk][1], w1, o[blk]);
+        }
+        HIPTS_STAMP(t * 16 + g * 8 + 4);
+    };
+    auto step = [&](int t, auto first_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_c)::value;
+        HIPTS_STAMP(t * 16 + 0);
+        wait_vm<0>();                                // tile t (requested one step ago) has landed for this wave ...
+#ifndef HIPTS_X_NOBARRIER                            // (HIPTS_X_*: measurement-only builds, tools/gpurun/r3_attn_x.sh -- results are wrong with them)
+        __builtin_amdgcn_s_barrier();                // ... and for every wave; tile t - 1's slots are free
+#endif
+#ifdef HIPTS_X_NODMA
+        if (t == 0)
+#endif
+        if (t + 1 < nkv) stage(t + 1);
+        if (!active) return;
+        HIPTS_STAMP(t * 16 + 1);
+        const int sl = (t & 1) * TILE;
+        half(t, sl, 0, first_c, last_c);
+        if (!(LAST && tail_keys <= 32)) half(t, sl, 1, F_{}, last_c);
+    };
+    if (nkv == 1) step(0, T_{}, T_{});
+    else {
+        step(0, T_{}, F_{});
+        for (int t = 1; t + 1 < nkv; ++t) step(t, F_{}, F_{});
+        step(nkv - 1, F_{}, T_{});
+    }
+    if (!active) return false;
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    bool bad;
+    {
+        const uint32_t lb = __float_as_uint(l_tot);
+        constexpr uint32_t LO = F16 ? 0x3f000000u : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
+        bad = !(lb >= LO && lb < HI);
+    }
+#ifndef HIPTS_X_NOFALLBACK
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) return true;
+#endif
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + r;
+    bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {                 // see attn2_body
+        const int ke = 2 * kp, ko = 2 * kp + 1;
+        const f32x16& oe = o[ke >> 2];
+        const f32x16& oo = o[ko >> 2];
+        const int ie = 4 * (ke & 3), io = 4 * (ko & 3);
+        const uint2 ue = __builtin_bit_cast(uint2, pack4<F16>(oe[ie] * inv, oe[ie + 1] * inv, oe[ie + 2] * inv, oe[ie + 3] * inv));
+        const uint2 uo = __builtin_bit_cast(uint2, pack4<F16>(oo[io] * inv, oo[io + 1] * inv, oo[io + 2] * inv, oo[io + 3] * inv));
+        const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
+        const int kq = h ? ko : ke;
+        if (qi < tokens) *reinterpret_cast<uint4*>(op + 32 * (kq >> 2) + 8 * (kq & 3)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+    return false;
+}
+
+// The fallback: online softmax with the per-tile running maximum (cannot overflow), for the query blocks of a workgroup whose fast
+// pass reported a row sum outside its window.  Rare, so it is written for few registers, not speed -- the kernel's register
+// allocation is the larger of the two bodies': one block of 32 query rows per wave and pass (QB passes over the keys), one tile
+// in flight, S -> softmax -> P V in order.  Same fragment layouts, LDS images and store path as attn2_body.
+template <bool F16, int QB, int NW>
+__device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                           const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int bh,
+                                           int blk0, int nblk, int out_stride) {
+    constexpr int PCS = 8 / NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bool active = wave < nblk;
+    const int b = bh / heads, head = bh - b * heads;
+    const int nkv = tokens_pad / KV;
+    int ka[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) * 16);
+    int va[2];
+    {
+        const int l16 = lane & 15, qd = l16 >> 2, p = l16 & 3, dgrp = (lane >> 4) & 1;
+        const int x = qd >> 1;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) va[blk] = (4 * h + qd) * 128 + (2 * dgrp + (p >> 1) + 4 * (blk ^ x)) * 16 + (p & 1) * 8;
+    }
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q0 = (blk0 + wave) * (32 * QB) + 32 * qb;
+        int qrow = q0 + r;
+        qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
+        const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        f32x16 o[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int t = 0; t < nkv; ++t) {
+            __syncthreads();                          // every wave is done with the slot (also: with the fast pass's ring)
+#pragma unroll
+            for (int pc = 0; pc < PCS; ++pc) {
+                const int piece = wave + NW * pc;
+                const int row = piece * 8 + (lane >> 3);
+                const size_t g0 = ((size_t)bh * tokens_pad + (size_t)t * KV + row) * HD;
+                glds16(k + g0 + (((lane & 7) ^ ((row >> 1) & 7)) * 8), smem + piece * 1024);
+                glds16(v + g0 + (((lane & 7) ^ (((row >> 1) & 1) << 2)) * 8), smem + V_BASE + piece * 1024);
+            }
+            wait_vm<0>();
+            __syncthreads();
+            if (!active) continue;
+            f32x16 sacc[2];
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc[g][i] = (t * KV + g * 32 + crow(i, h) >= tokens) ? -INFINITY : 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + g * 4096 + ka[s]);
+                    sacc[g] = mfma_32x32x16<F16>(kf, qf[s], sacc[g]);
+                }
+            }
+            float mx = m_run;                         // every tile holds at least one unmasked key: the maximum is finite from tile 0 on
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[g][i]);
+            const float m_new = fmaxf(mx, __shfl_xor(mx, 32));
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[g][i] - m_new);
+                    ls += p;
+                    pf[g][i >> 3][i & 7] = to_op<F16>(p);
+                }
+            l_run = l_run * alpha + ls;
+            m_run = m_new;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[blk][i] *= alpha;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const char* p0 = smem + V_BASE + va[blk] + (32 * g + 16 * s2) * 128;
+                        const bf16x4 lo = tr_read(p0);
+                        const bf16x4 hi = tr_read(p0 + 8 * 128);
+                        const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[blk] = mfma_32x32x16<F16>(vf, pf[g][s2], o[blk]);
+                    }
+            }
+        }
+        if (!active) continue;
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + r;
+        bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+        if (qi < tokens) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) =
+                        pack4<F16>(o[blk][4 * g4] * inv, o[blk][4 * g4 + 1] * inv, o[blk][4 * g4 + 2] * inv, o[blk][4 * g4 + 3] * inv);
+        }
+    }
+}
+
+template <bool F16, int QB, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) void attn2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                        bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int chunks, int out_stride,
+                                                        int classic) {
+    // ALL of the kernel's LDS is this one array (ring + the fallback flag word): with a second LDS object in the kernel -- __syncthreads_or()
+    // brings one -- hipcc puts an s_waitcnt vmcnt(0) in front of the first ds_read of every tile step and the DMA ring never runs ahead
+    // (cdna_hip_programming.md section 5, "three .s-level traps" (a); seen in this kernel's .s).
+    constexpr int RING = MODE == 1 ? 4 * TILE : LDS_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[RING + 16];
+    int* redo = reinterpret_cast<int*>(smem + RING);
+    if (threadIdx.x == 0) *redo = classic;           // ordered before every reader by the barriers of the tile loop
+    // XCD-aware work id (attn.hip): the workgroups of one (image, head) stream the same K / V -- keep them on one XCD's L2
+    int wid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qd = nwg >> 3, rm = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int bh = wid / chunks, c = wid - bh * chunks;
+    const int nb = (tokens + 32 * QB - 1) / (32 * QB);              // query blocks of the (image, head), dealt evenly to its workgroups
+    const int blk0 = (c * nb) / chunks, nblk = ((c + 1) * nb) / chunks - blk0;
+    // classic != 0 (HIPTS_ATTN_CLASSIC=1): the fallback everywhere (A/B runs, its own test)
+    if (!classic) {
+        bool bad;
+        if constexpr (MODE == 1) bad = attn2_seq_body<F16, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride);
+        else bad = attn2_body<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride);
+        if (bad) *redo = 1;
+    }
+    __syncthreads();
+    // a wave whose row sum left the window stored nothing; the workgroup (its waves stage K / V together) repeats its blocks classically
+    if (*redo) attn2_classic<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride);
+}
+
+template <bool F16, int QB, int NW, int MODE>
+int launch_cfg(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, int ost,
+               int classic, hipStream_t s) {
+    const int nb = (tokens + 32 * QB - 1) / (32 * QB);
+    const int chunks = (nb + NW - 1) / NW;
+    attn2_kernel<F16, QB, NW, MODE><<<batch * heads * chunks, NW * 64, 0, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+}  // namespace
+
+// q, k, v: [batch * heads][tokens_pad][64] 16-bit (q pre-scaled by head_dim^-0.5 log2 e; rows past `tokens` zero), out [batch * out_stride][heads * 64].
+// variant: 0 = default; 1: 4 waves x 64 rows, 2: 8 waves x 32 rows, 3: 4 waves x 32 rows (A/B, hiptsdbg_attention2_*).
+int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, bool f16,
+                      hipStream_t s, int out_tokens_stride, int variant) {
+    const int ost = out_tokens_stride > 0 ? out_tokens_stride : tokens;
+    HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens && tokens >= 1, "attention: tokens_pad must be a multiple of %d", KV);
+    static const int classic = (getenv("HIPTS_ATTN_CLASSIC") && atoi(getenv("HIPTS_ATTN_CLASSIC"))) ? 1 : 0;
+    static const int env_variant = getenv("HIPTS_ATTN2") ? atoi(getenv("HIPTS_ATTN2")) : 0;
+    if (variant == 0) variant = env_variant ? env_variant : 5;
+#define HIPTS_ATTN2_CASE(QB_, NW_, MODE_)                                                                                        \
+    return f16 ? launch_cfg<true, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, s)                      \
+               : launch_cfg<false, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, s)
+    switch (variant) {
+        case 1: HIPTS_ATTN2_CASE(2, 4, 0);
+        case 2: HIPTS_ATTN2_CASE(1, 8, 0);
+        case 4: HIPTS_ATTN2_CASE(1, 8, 1);
+        case 5: HIPTS_ATTN2_CASE(1, 4, 1);
+        default: HIPTS_ATTN2_CASE(1, 4, 0);
+    }
+#undef HIPTS_ATTN2_CASE
+}
+
+#ifdef HIPTS_X_STAMPS
+int attention2_read_stamps(unsigned long long* host, int n) {
+    HIPTS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn2_stamps), (size_t)n * 8));
+    return HIPTS_OK;
+}
+#else
+int attention2_read_stamps(unsigned long long*, int) { return set_error(HIPTS_ERR_STATE, "built without HIPTS_X_STAMPS"); }
+#endif
+
+}  // namespace hipts

@@ -1206,6 +1206,48 @@ extern "C" int hiptsdbg_attention_time(const uint16_t* q, const uint16_t* k, con
     return rc;
 }
 
+// The head_dim-64 kernel of attn2.hip alone: q, k, v 16-bit patterns [batch * heads][tokens_pad][64] (v NOT transposed); iters == 0: one launch,
+// result to out_host ([batch][tokens][heads * 64]); iters > 0: timing only (avg_us).  variant: launch_attention2's.
+extern "C" int hiptsdbg_attention2(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out_host, int batch, int heads, int tokens,
+                                   int tokens_pad, int f16, int variant, int iters, double* avg_us) {
+    HIPTS_REQUIRE(q && k && v && batch >= 1 && heads >= 1 && tokens >= 1 && (iters > 0 ? avg_us != nullptr : out_host != nullptr), "hiptsdbg_attention2: bad arguments");
+    HIPTS_TRY(use_device(0));
+    const size_t nqk = (size_t)batch * heads * tokens_pad * 64, nout = (size_t)batch * tokens * heads * 64;
+    DevBuf dq, dk, dv, dout;
+    HIPTS_TRY(dq.alloc(nqk * 2));
+    HIPTS_TRY(dk.alloc(nqk * 2));
+    HIPTS_TRY(dv.alloc(nqk * 2));
+    HIPTS_TRY(dout.alloc(nout * 2));
+    HIPTS_TRY(upload(dq.p, q, nqk * 2));
+    HIPTS_TRY(upload(dk.p, k, nqk * 2));
+    HIPTS_TRY(upload(dv.p, v, nqk * 2));
+    HIPTS_HIP(hipMemset(dout.p, 0, nout * 2));
+    auto run = [&]() { return launch_attention2(dq.as<bf16_t>(), dk.as<bf16_t>(), dv.as<bf16_t>(), dout.as<bf16_t>(), batch, heads, tokens, tokens_pad, f16 != 0, nullptr, 0, variant); };
+    if (iters <= 0) {
+        HIPTS_TRY(run());
+        HIPTS_HIP(hipDeviceSynchronize());
+        HIPTS_HIP(hipMemcpy(out_host, dout.p, nout * 2, hipMemcpyDeviceToHost));
+        return HIPTS_OK;
+    }
+    hipEvent_t e0, e1;
+    HIPTS_HIP(hipEventCreate(&e0));
+    HIPTS_HIP(hipEventCreate(&e1));
+    int rc = HIPTS_OK;
+    for (int i = 0; i < 3 && rc == HIPTS_OK; ++i) rc = run();
+    HIPTS_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && rc == HIPTS_OK; ++i) rc = run();
+    HIPTS_HIP(hipEventRecord(e1, nullptr));
+    HIPTS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = 1e3 * ms / iters;
+    return rc;
+}
+
+extern "C" int hiptsdbg_attention2_stamps(unsigned long long* host, int n) { return attention2_read_stamps(host, n); }
+
 // Development aid: copy one workspace buffer of the last forward to the host (tools/determinism.py).
 extern "C" int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes) {
     HIPTS_REQUIRE(h && name && out_host && bytes, "null argument");

@@ -271,6 +271,13 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int batch, int heads, int tokens,
                      int tokens_pad, bool f16, hipStream_t s, int head_dim = 64, int out_tokens_stride = 0);
 
+// The same for head_dim 64 with V in its natural layout: q, k, v [B*H][tokens_pad][64] (attn2.hip: LDS-DMA ring, transposed LDS reads of V).
+// variant 0 = default geometry (HIPTS_ATTN2 overrides): 1: 4 waves x 64 query rows, 2: 8 waves x 32, 3: 4 waves x 32.
+int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, bool f16,
+                      hipStream_t s, int out_tokens_stride = 0, int variant = 0);
+
+int attention2_read_stamps(unsigned long long* host, int n);      // measurement-only builds (HIPTS_X_STAMPS)
+
 // out[row][:] = bf16((x[row][:] - mean) * rstd * g + b)  (b may be null: bias-free LayerNorm); D % 4 == 0, D <= 1024
 int launch_layernorm(const float* x, const float* g, const float* b, bf16_t* out, int64_t rows, int D, float eps, bool f16,
                      hipStream_t s);

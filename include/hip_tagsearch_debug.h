@@ -38,6 +38,12 @@ int hiptsdbg_attention_run(const uint16_t* q, const uint16_t* k, const uint16_t*
 int hiptsdbg_attention_time(const uint16_t* q, const uint16_t* k, const uint16_t* vT, int batch, int heads, int tokens, int tokens_pad,
                             int head_dim, int f16, int iters, double* avg_us);
 
+/* The head_dim-64 attention kernel of round 3 (csrc/attn2.hip) alone: as above but v in its natural layout [batch * heads][tokens_pad][64].
+ * iters == 0: one launch, result in out_host; iters > 0: average device microseconds of that many launches in *avg_us (out_host unused).
+ * variant 0: the default geometry; 1: 4 waves x 64 query rows, 2: 8 waves x 32, 3: 4 waves x 32. */
+int hiptsdbg_attention2(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out_host, int batch, int heads, int tokens, int tokens_pad,
+                        int f16, int variant, int iters, double* avg_us);
+
 /* One-query search path (hipts_search with nq == 1): how many candidates its threshold step collected for the last query and
  * whether the ranking used them (1) or fell through to the exact radix select (0). */
 int hiptsdbg_search1_last(hipts_bm25_t* h, uint32_t* candidates, uint32_t* took_candidate_path);

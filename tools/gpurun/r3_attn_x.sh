@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3: measurement-only builds of the attention kernel (HIPTS_X_* macros in csrc/attn2.hip): what is its time made of.
+# usage: r3_attn_x.sh <variant> <macro> [<macro> ...]   (each macro: one rebuild of attn2.o + relink + timing; "none" = the real kernel)
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
+V=$1; shift
+cd anime-illust-image-searcher_amd/csrc
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function -fno-honor-nans"
+for M in "$@"; do
+  D=""; [ "$M" != "none" ] && for m in ${M//+/ }; do D="$D -D$m"; done
+  /opt/rocm/bin/hipcc $FLAGS $D -c attn2.hip -o attn2.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhip_tagsearch.so *.o || exit 1
+  echo "== $M"; (cd ../.. && timeout -k 10 120 python tools/attn2_check.py time $V 2>&1 | grep "attn2 variant")
+done
+/opt/rocm/bin/hipcc $FLAGS -c attn2.hip -o attn2.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhip_tagsearch.so *.o
