@@ -47,7 +47,7 @@ struct hipts_eva {
     std::vector<EvaLayer> layers;
     DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope;
     std::vector<std::string> missing;
-    DevBuf img_in, a0, tmp, x, xn, q, k, vT, att, g1, stat_part, rowstat, xstat, pool_part, pooled2, logits, probs;
+    DevBuf img_in, a0, tmp, x, xn, q, k, v, att, g1, stat_part, rowstat, xstat, pool_part, pooled2, logits, probs;
     bool fold_ln = false, fold_dirty = true;      // as in the ViT forward (vit.hip)
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
@@ -225,7 +225,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     bf16_t* xn = h->xn.as<bf16_t>() + r0 * D;
     bf16_t* q_p = h->q.as<bf16_t>() + qo;
     bf16_t* k_p = h->k.as<bf16_t>() + qo;
-    bf16_t* vT_p = h->vT.as<bf16_t>() + qo;
+    bf16_t* v_p = h->v.as<bf16_t>() + qo;
     bf16_t* att_p = h->att.as<bf16_t>() + r0 * D;
     bf16_t* g1_p = h->g1.as<bf16_t>() + r0 * h->HK;
     const int sblocks = 2 * h->HK / 64;                                        // 64-column blocks of the fc1 launch
@@ -272,22 +272,14 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D; g.bias = L.qkv_b.as<float>();
-        g.out_bf16 = q_p; g.out2_bf16 = k_p;
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 3 * D; g.K = D; g.bias = L.qkv_b.as<float>();
+        g.out_bf16 = q_p; g.out2_bf16 = k_p; g.out3_bf16 = v_p;       // one launch: q and k rotated, v as it is, all [image][head][token][64]
         g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         g.qscale = 0.125f * 1.4426950408889634f;           // 64^-0.5 * log2(e); linear, so it commutes with the rotation
         g.rope = h->rope.as<float>(); g.rope_tokens = np;  // 2-D rotary embedding on the fp32 result, in the epilogue
         if (ln1_folded) folded(g, L.qkv_u.as<float>(), L.qkv_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_QK_ROPE, g, s));
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.shared_chip = shared_chip;
-        g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D; g.bias = L.qkv_b.as<float>() + 2 * D;
-        g.out_bf16 = vT_p;
-        g.tokens = TS; g.tokens_pad = Tp; g.heads = H; g.dim = D;
-        if (ln1_folded) folded(g, L.qkv_u.as<float>() + 2 * D, L.qkv_c.as<float>() + 2 * D);
-        HIPTS_TRY(launch_gemm(EPI_VT, g, s));
-        HIPTS_TRY(launch_attention(q_p, k_p, vT_p, att_p, batch, H, T, Tp, f16, s, 64, TS));
+        HIPTS_TRY(launch_attention2(q_p, k_p, v_p, att_p, batch, H, T, Tp, f16, s, TS));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
@@ -427,7 +419,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     const size_t qk = (size_t)B * cfg->heads * h->Tp * 64 * 2;
     int st = 0;
     if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
-        (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->vT, qk)) ||
+        (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->v, qk)) ||
         (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
         (st = h->stat_part.alloc((size_t)(2 * h->HK / 64) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
         (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {

@@ -690,13 +690,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!nv[j]) continue;
-                    const int which = nc[j] >= a.dim ? 1 : 0;
+                    const int which = nc[j] >= 2 * a.dim ? 2 : (nc[j] >= a.dim ? 1 : 0);       // q, k or (N = 3 dim) v
                     const int nn = nc[j] - which * a.dim;
                     const int head = nn >> a.hd_log2, d = nn & ((1 << a.hd_log2) - 1);
                     const float sc = which ? 1.0f : a.qscale;
                     const f32x4 v = acc[i][j] + bv[j];
                     const bf16x4 o = pack4<F16>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
-                    bf16_t* base = which ? a.out2_bf16 : a.out_bf16;
+                    bf16_t* base = which == 2 ? a.out3_bf16 : (which ? a.out2_bf16 : a.out_bf16);
                     *reinterpret_cast<bf16x4*>(base + ((((size_t)(b * a.heads + head) * a.tokens_pad + t)) << a.hd_log2) + d) = o;
                 }
             }
@@ -830,14 +830,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                                             [&](int i, int jj) { return acc[i][jj]; });
             return;
         }
-        const int which = (IS_QK && ncol0 >= a.dim) ? 1 : 0;       // q or k: uniform over the wave's 64 columns
+        const int which = !IS_QK ? 0 : (ncol0 >= 2 * a.dim ? 2 : (ncol0 >= a.dim ? 1 : 0));       // q, k or (N = 3 dim) v: uniform over the wave's 64 columns
         const float sc = (IS_QK && !which) ? a.qscale : 1.0f;
         const bool nvl = ncol0 + lc * 8 < a.N;
         const int ld = a.ld_out ? a.ld_out : a.N;
         bf16_t* qk_base = nullptr;
         int head = 0, hd_off = 0;          // this lane's 8 columns: head and offset inside the head
         if constexpr (IS_QK) {
-            qk_base = which ? a.out2_bf16 : a.out_bf16;
+            qk_base = which == 2 ? a.out3_bf16 : (which ? a.out2_bf16 : a.out_bf16);
             const int col = ncol0 - which * a.dim + lc * 8;
             head = col >> a.hd_log2;
             hd_off = col & ((1 << a.hd_log2) - 1);
@@ -862,7 +862,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                 if constexpr (EPI == EPI_QK_ROPE) {
                     const int m = mrow0 + i * 16 + lr;
                     const int t = m - (m / a.tokens) * a.tokens;
-                    rok = t >= 1 && t <= a.rope_tokens;
+                    rok = t >= 1 && t <= a.rope_tokens && which < 2;         // v (the third column range of a fused q | k | v launch) is not rotated
                     const f32x4* rr = reinterpret_cast<const f32x4*>(a.rope) + (size_t)(rok ? t - 1 : 0) * 16 + lq;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rp[j] = rr[j * 4];
@@ -1896,6 +1896,8 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     if (epi != EPI_HEAD) HIPTS_REQUIRE(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);
     if (epi == EPI_VT) HIPTS_REQUIRE(a.M % 4 == 0 && a.tokens % 4 == 0, "gemm: V^T epilogue needs tokens %% 4 == 0");
     if (epi == EPI_QK || epi == EPI_VT) HIPTS_REQUIRE(a.hd_log2 == 5 || a.hd_log2 == 6, "gemm: head_dim must be 32 or 64");
+    if (epi == EPI_QK || epi == EPI_QK_ROPE)
+        HIPTS_REQUIRE(a.out_bf16 && a.out2_bf16 && a.dim > 0 && a.N <= 3 * a.dim && (a.N <= 2 * a.dim || a.out3_bf16), "gemm: q / k / v outputs missing for N = %d, dim = %d", a.N, a.dim);
     if (epi == EPI_QK_ROPE)
         HIPTS_REQUIRE(a.hd_log2 == 6 && a.dim % 64 == 0 && a.rope && a.rope_tokens >= 0 && a.tokens >= 1, "gemm: QK_ROPE needs head_dim 64 and the rotary table");
     if (epi == EPI_RESID_XG) HIPTS_REQUIRE(!a.rowstat && !a.stat_in, "gemm: RESID_XG ignores an input fold; use RESID_XGI");

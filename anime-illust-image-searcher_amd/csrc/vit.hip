@@ -37,8 +37,8 @@ enum ProfCat { PC_PATCHIFY = 0, PC_GEMM_PATCH, PC_LAYERNORM, PC_GEMM_QK, PC_GEMM
                PC_GEMM_GELU, PC_POOL, PC_GEMM_HEAD, PC_OTHER, PC_COUNT };
 static_assert(PC_COUNT == HIPTS_VIT_PROF_CATEGORIES, "category count");
 static const char* const kProfNames[PC_COUNT] = {
-    "patchify_kernel", "gemm_kernel<EPI_PATCH>", "layernorm_kernel", "gemm_kernel<EPI_QK>", "gemm_kernel<EPI_VT>",
-    "attn_kernel", "gemm_kernel<EPI_RESID>", "gemm_kernel<EPI_GELU>", "pool_kernels", "gemm_kernel<EPI_HEAD>", "other"};
+    "patchify_kernel", "gemm_kernel<EPI_PATCH>", "layernorm_kernel", "gemm_kernel<EPI_QKV>", "gemm_kernel<EPI_VT>",
+    "attn2_kernel", "gemm_kernel<EPI_RESID>", "gemm_kernel<EPI_GELU>", "pool_kernels", "gemm_kernel<EPI_HEAD>", "other"};
 
 struct ProfRec {
     int cat;
@@ -62,7 +62,7 @@ struct hipts_vit {
     std::vector<float> h_patch_bias, h_patch_rowsum;   // bias and sum_k W[n][k] (of the bf16 values)
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
-    DevBuf img_in, a0, x, xn, q, k, vT, att, hmid, pool_part, pooled2, logits, probs, stat_part;
+    DevBuf img_in, a0, x, xn, q, k, v, att, hmid, pool_part, pooled2, logits, probs, stat_part;
     bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default; HIPTS_LN_FOLD=0 turns it off)
     bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
     int pool_splits = 1;
@@ -364,7 +364,7 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     h->pool_splits = h->tokens >= 64 ? 8 : 1;
     int st = HIPTS_OK;
     if ((st = h->a0.alloc(M * h->patch_k * 2 * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
-        (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->vT.alloc(qkv_elems * 2)) ||
+        (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->v.alloc(qkv_elems * 2)) ||
         (st = h->att.alloc(M * D * 2)) || (st = h->hmid.alloc(M * (size_t)cfg->mlp_dim * 2)) ||
         (st = h->pool_part.alloc(B * h->pool_splits * D * 4)) || (st = h->pooled2.alloc(B * 2 * D * 2)) ||
         (st = h->logits.alloc(B * (size_t)cfg->num_classes * 4)) || (st = h->probs.alloc(B * (size_t)cfg->num_classes * 4))) {
@@ -388,10 +388,10 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
                 return st;
             }
     }
-    // padded token rows of q / k / vT must be finite (zero): cleared once, never written afterwards
+    // padded token rows of q / k / v must be finite (zero): cleared once, never written afterwards
     hipError_t e;
     if ((e = hipMemset(h->q.p, 0, h->q.bytes)) != hipSuccess || (e = hipMemset(h->k.p, 0, h->k.bytes)) != hipSuccess ||
-        (e = hipMemset(h->vT.p, 0, h->vT.bytes)) != hipSuccess) {
+        (e = hipMemset(h->v.p, 0, h->v.bytes)) != hipSuccess) {
         delete h;
         return set_error(HIPTS_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
     }
@@ -600,7 +600,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     const size_t qoff = (size_t)i0 * H * Tp * 64;
     bf16_t* q = h->q.as<bf16_t>() + qoff;
     bf16_t* k = h->k.as<bf16_t>() + qoff;
-    bf16_t* vT = h->vT.as<bf16_t>() + qoff;
+    bf16_t* v = h->v.as<bf16_t>() + qoff;
     float* pool_part = h->pool_part.as<float>() + (size_t)i0 * h->pool_splits * D;
     bf16_t* pooled2 = h->pooled2.as<bf16_t>() + (size_t)i0 * 2 * D;
     const size_t img_bytes = (size_t)S * S * 3 * (is_u8 ? 1 : 4);
@@ -678,34 +678,24 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         Layer& L = h->layers[li];
         const bool ln1_folded = fold;                  // prepared by the previous layer's fc2 epilogue (layer 0: by the patch GEMM's)
         if (!ln1_folded) HIPTS_TRY(layernorm(L.ln1_g.as<float>(), L.ln1_b.as<float>()));
-        // q, k  (rows [0, 2D) of the fused qkv weight); q pre-scaled for the base-2 softmax
+        // q, k, v in ONE launch over the fused qkv weight (N = 3 D; round 3): all three leave in the [image][head][token][64] layout, V in
+        // its natural orientation -- the attention kernel reads it transposed out of LDS (attn2.hip), so no transposing epilogue, one
+        // launch and one pass over the activations less per layer.  q pre-scaled for the base-2 softmax.
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 2 * D; g.K = D;
-        g.bias = L.qkv_b.as<float>(); g.out_bf16 = q; g.out2_bf16 = k;
+        g.A = xn; g.W = L.qkv_w.as<bf16_t>(); g.M = M; g.N = 3 * D; g.K = D;
+        g.bias = L.qkv_b.as<float>(); g.out_bf16 = q; g.out2_bf16 = k; g.out3_bf16 = v;
         if (ln1_folded) folded(g, L.qkv_u.as<float>(), L.qkv_c.as<float>());
         g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
         g.qscale = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 (64^-0.5) * log2(e): attention works in base 2
         {
-            ProfScope ps(h, s, PC_GEMM_QK, 2.0 * dM * 2 * dD * dD, dM * dD * 2 + dM * 2 * dD * 2);
+            ProfScope ps(h, s, PC_GEMM_QK, 2.0 * dM * 3 * dD * dD, dM * dD * 2 + dM * 3 * dD * 2);
             HIPTS_TRY(launch_gemm(EPI_QK, g, s));
-        }
-        // v, written transposed
-        g = GemmArgs{};
-        g.f16 = f16;
-        g.shared_chip = shared_chip;
-        g.A = xn; g.W = L.qkv_w.as<bf16_t>() + (size_t)2 * D * D; g.M = M; g.N = D; g.K = D;
-        g.bias = L.qkv_b.as<float>() + 2 * D; g.out_bf16 = vT;
-        if (ln1_folded) folded(g, L.qkv_u.as<float>() + 2 * D, L.qkv_c.as<float>() + 2 * D);
-        g.tokens = T; g.tokens_pad = Tp; g.heads = H; g.dim = D;
-        {
-            ProfScope ps(h, s, PC_GEMM_VT, 2.0 * dM * dD * dD, dM * dD * 2 + dM * dD * 2);
-            HIPTS_TRY(launch_gemm(EPI_VT, g, s));
         }
         {
             ProfScope ps(h, s, PC_ATTENTION, 4.0 * nb * H * dT * dT * 64, dM * dD * 2 * 4);
-            HIPTS_TRY(launch_attention(q, k, vT, att, nb, H, T, Tp, f16, s));
+            HIPTS_TRY(launch_attention2(q, k, v, att, nb, H, T, Tp, f16, s));
         }
         // x += att Wp^T + b  (+ norm2 prepared)
         HIPTS_TRY(residual(att, L.proj_w.as<bf16_t>(), L.proj_b.as<float>(), D, fold ? L.ln2_g.as<float>() : nullptr, 2.0 * dM * dD * dD,
@@ -1254,7 +1244,7 @@ extern "C" int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_hos
     HIPTS_TRY(use_device(h->device));
     const std::string n(name);
     const DevBuf* b = n == "a0" ? &h->a0 : n == "x" ? &h->x : n == "xn" ? &h->xn : n == "q" ? &h->q : n == "k" ? &h->k
-                      : n == "vT" ? &h->vT : n == "att" ? &h->att : n == "hmid" ? &h->hmid : n == "pool_part" ? &h->pool_part
+                      : n == "v" ? &h->v : n == "att" ? &h->att : n == "hmid" ? &h->hmid : n == "pool_part" ? &h->pool_part
                       : n == "pooled2" ? &h->pooled2 : nullptr;
     HIPTS_REQUIRE(b, "unknown buffer %s", name);
     *bytes = b->bytes < max_bytes ? b->bytes : max_bytes;

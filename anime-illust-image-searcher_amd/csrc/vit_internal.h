@@ -188,7 +188,7 @@ inline int upload_matrix8(DevBuf& buf, const float* data, int rows, int cols, in
 // multiple of 256 rows; A rows beyond M are never read (row index clamped), stores are masked.
 enum GemmEpilogue {
     EPI_PATCH = 0,   // x[m][n]  = acc * qscale + bias[n] + pos[(m % tokens)][n]        (fp32 out)
-    EPI_QK = 1,      // q/k[b][h][t][d] = bf16((acc + bias[n]) * (n < dim ? qscale : 1)) (n in [0, 2*dim))
+    EPI_QK = 1,      // q/k[b][h][t][d] = bf16((acc + bias[n]) * (n < dim ? qscale : 1)) (n in [0, 2*dim)); with N = 3*dim also v (out3_bf16)
     EPI_VT = 2,      // vT[b][h][d][t] = bf16(acc + bias[dim2 + n])                      (n in [0, dim))
     EPI_RESID = 3,   // x[m][n] += acc + bias[n]                                        (fp32 in/out)
     EPI_GELU = 4,    // out[m][n] = bf16(gelu(acc + bias[n]))
@@ -229,6 +229,7 @@ struct GemmArgs {
     float* out2_f32 = nullptr;      // HEAD(probs, may be null)
     bf16_t* out_bf16 = nullptr;     // GELU; QK: q base; VT: vT base
     bf16_t* out2_bf16 = nullptr;    // QK: k base
+    bf16_t* out3_bf16 = nullptr;    // QK / QK_ROPE with N = 3 * dim: v base, same [b][h][t][d] layout as q and k (no scale, no rotation)
     const float* pos = nullptr;     // PATCH
     int tokens = 0;                 // tokens per image (PATCH, QK, VT)
     int tokens_pad = 0;             // padded token count of the q/k/vT layouts

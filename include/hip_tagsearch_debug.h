@@ -27,7 +27,7 @@ int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_
 /* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in
  * w_exp); kind 0: float32 output, 1: e4m3 output through the StarReLU epilogue's store path. */
 int hiptsdbg_gemm8_run(int M, int N, int K, const float* a_f32, const float* w_f32, int kind, void* out_host, int* w_exp);
-/* Copies a named workspace tensor of the last forward ("x", "xn", "q", "k", "vT", "att", "hmid") to the host. */
+/* Copies a named workspace tensor of the last forward ("x", "xn", "q", "k", "v", "att", "hmid") to the host. */
 int hiptsdbg_vit_dump(hipts_vit_t* h, const char* name, void* out_host, size_t max_bytes, size_t* bytes);
 
 /* The attention kernel alone: q, k 16-bit patterns [batch * heads][tokens_pad][head_dim] (q pre-scaled by head_dim^-0.5 * log2 e, rows past

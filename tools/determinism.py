@@ -15,7 +15,7 @@ model = ViTTagger(cfg, w, max_batch=B)
 lib = _lib.load()
 f = lib.hiptsdbg_vit_dump
 f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
-names = ["a0", "q", "k", "vT", "att", "xn", "hmid", "x", "pool_part", "pooled2"]
+names = ["a0", "q", "k", "v", "att", "xn", "hmid", "x", "pool_part", "pooled2"]
 def snap():
     logits, _ = model.forward_u8(imgs)
     out = {"logits": logits.copy()}

@@ -13,7 +13,7 @@ model = ViTTagger(cfg, w, max_batch=2)
 logits, _ = model.forward_u8(imgs)
 lib = _lib.load(); f = lib.hiptsdbg_vit_dump
 f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
-for n, dt in [("a0", "h"), ("q", "h"), ("k", "h"), ("vT", "h"), ("att", "h"), ("xn", "h"), ("hmid", "h"), ("x", "f"), ("pool_part", "f"), ("pooled2", "h")]:
+for n, dt in [("a0", "h"), ("q", "h"), ("k", "h"), ("v", "h"), ("att", "h"), ("xn", "h"), ("hmid", "h"), ("x", "f"), ("pool_part", "f"), ("pooled2", "h")]:
     buf = np.empty(64 << 20, dtype=np.uint8); nb = ctypes.c_size_t()
     assert f(model._h, n.encode(), buf.ctypes.data, buf.nbytes, ctypes.byref(nb)) == 0
     raw = buf[:nb.value]
