@@ -392,9 +392,15 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(smem + sl + g * 4096 + ka[s]);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads
+#ifdef HIPTS_X_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) sacc = mfma_32x32x16<F16>(kf[s], qf[s], sacc);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMA
+#ifdef HIPTS_X_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         HIPTS_STAMP(t * 16 + g * 8 + 2);
         bf16x8 vf[2][2];
 #pragma unroll
@@ -432,11 +438,24 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 #endif
         l_run += ls0 + ls1;
         HIPTS_STAMP(t * 16 + g * 8 + 3);
+#ifdef HIPTS_X_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef HIPTS_X_PVORDER                               // the two O^T chains interleaved instead of one after the other
+        o[0] = mfma_32x32x16<F16>(vf[0][0], w0, o[0]);
+        o[1] = mfma_32x32x16<F16>(vf[1][0], w0, o[1]);
+        o[0] = mfma_32x32x16<F16>(vf[0][1], w1, o[0]);
+        o[1] = mfma_32x32x16<F16>(vf[1][1], w1, o[1]);
+#else
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             o[blk] = mfma_32x32x16<F16>(vf[blk][0], w0, o[blk]);
             o[blk] = mfma_32x32x16<F16>(vf[blk][1], w1, o[blk]);
         }
+#endif
+#ifdef HIPTS_X_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         HIPTS_STAMP(t * 16 + g * 8 + 4);
     };
     auto step = [&](int t, auto first_c, auto last_c) __attribute__((always_inline)) {

@@ -1126,8 +1126,8 @@ __global__ __launch_bounds__(S1_COLLECT_THREADS) void search1_collect_kernel(con
 // per (device, purpose), intentionally never freed (freeing at static-destruction time would
 // race the HIP runtime's own teardown).  Callers are single-threaded per device by contract.
 DevBuf& scratch_buf(int device, int which) {
-    static DevBuf* bufs = new DevBuf[64 * 2];
-    return bufs[(device & 63) * 2 + which];
+    static DevBuf* bufs = new DevBuf[64 * 4];
+    return bufs[(device & 63) * 4 + (which & 3)];
 }
 
 int copy_out(void* dst, const void* src_dev, size_t bytes, int memspace, hipStream_t s) {
@@ -1778,6 +1778,30 @@ int hipts_topk(const double* vals, int nq, int64_t n, int k, int32_t* ids_out, d
             vals_out[(size_t)q * k + i] = i < kk ? hv[(size_t)q * kk + i] : -INFINITY;
         }
     return HIPTS_OK;
+}
+
+// scores ranked at or before (after_val, after_id) in the order (value descending, index ascending) become -inf: the top k of the
+// result are the NEXT k of that order
+__global__ __launch_bounds__(256) void mask_ranked_before_kernel(const double* __restrict__ vals, int64_t n, double after_val, int64_t after_id,
+                                                                 double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = vals[i];
+    const bool later = v < after_val || (v == after_val && i > after_id);
+    out[i] = later ? v : -INFINITY;
+}
+
+int hipts_topk_after(const double* vals, int64_t n, int k, double after_val, int64_t after_id, int32_t* ids_out, double* vals_out,
+                     int device, void* stream) {
+    HIPTS_REQUIRE(vals && ids_out && vals_out && n >= 1 && k >= 1 && k <= TOPK_MAX_K, "hipts_topk_after: bad arguments");
+    HIPTS_REQUIRE(after_val == after_val, "hipts_topk_after: after_val is NaN");
+    HIPTS_TRY(use_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf& mbuf = scratch_buf(device, 2);
+    HIPTS_TRY(mbuf.reserve((size_t)n * 8));
+    mask_ranked_before_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(vals, n, after_val, after_id, mbuf.as<double>());
+    HIPTS_LAUNCH_CHECK();
+    return hipts_topk(mbuf.as<double>(), 1, n, k, ids_out, vals_out, HIPTS_HOST, device, stream);
 }
 
 int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights,

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "hipts_rowmax": [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_combine_with_max": [c_void_p, c_void_p, c_int, c_int64, c_double, c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_topk": [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "hipts_topk_after": [c_void_p, c_int64, c_int, c_double, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                      c_void_p, c_void_p, c_void_p, c_void_p],
     "hipts_query_profile_enable": [c_void_p, c_int],

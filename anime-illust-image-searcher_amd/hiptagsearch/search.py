@@ -63,7 +63,7 @@ class SearchEngine:
         self.search_mode = search_mode
         self.compat_rerank = compat_rerank
         self.cindex = None                     # cfeatures.CharacterFeatureIndex for 'character oriented' mode
-        self.stats = {"queries": 0, "full_rank_fallbacks": 0}
+        self.stats = {"queries": 0, "full_rank_fallbacks": 0, "rank_continuations": 0}     # full_rank_fallbacks: always 0 since round 3
         self._search_fn = _lib.load().hipts_search
         self._w_bm25, self._w_sim = c_double(BM25_WEIGHT), c_double(DOC2VEC_WEIGHT)
         # webui.py:623-646: path -> {tag: True} and path -> doc id, built from the same index file
@@ -224,26 +224,29 @@ class SearchEngine:
                   c_double(RERANKED_SCORE_WEIGHT), 0, 0, _lib.ptr(rf_dev), self.index.device, _lib.current_stream_ptr())   # :208
         k = min(TOPK_MAX, D)
         rids, rvals = self._ranked_prefix(rf_dev, k)
+        last_id, last_val = int(rids[-1]), float(rvals[-1])                          # the last ranked entry as the device holds it
         mx = rvals[0]
         if mx > 0:
             rvals = rvals / mx                                                        # :210-211
         top10_set = set(top10_ids)
         final = [(d, 1.0) for d in top10_ids]                                         # :219-222
         final += [(int(i), float(v)) for i, v in zip(rids, rvals) if int(i) not in top10_set]   # :217,225-237
-        if k < D and not self._two_cut_points(final):
-            # The gap filter looks for its *second* cut point anywhere in the ranked list.  It is almost
-            # always inside the first 1024 entries; if not, rank all D scores (host, rare path) -- counted in
-            # self.stats and announced once, so that a corpus on which it is NOT rare does not go unnoticed.
-            self.stats["full_rank_fallbacks"] += 1
-            if self.stats["full_rank_fallbacks"] == 1:
-                import sys
-                print("hiptagsearch: the result filter found no second cut point in the first %d ranks; ranking all %d scores on the "
-                      "host for this query (SearchEngine.stats counts these)" % (k, D), file=sys.stderr)
-            rf = rf_dev[0].cpu().numpy()
-            if mx > 0:
-                rf = rf / mx
-            order = np.lexsort((np.arange(D), -rf))
-            final = [(d, 1.0) for d in top10_ids] + [(int(i), float(rf[i])) for i in order if int(i) not in top10_set]
+        # The gap filter (webui.py:63-80) cuts at the SECOND near-tie of the whole ranked list, wherever that is.  Almost always it lies
+        # inside the first 1024 ranks; while it does not, the ranking is continued on the device 1024 entries at a time
+        # (hipts_topk_after) -- until two cut points are in hand or only -inf scores remain (they produce no cut point: inf - inf is
+        # nan).  Round 2 ranked all D scores on the host in that case (27 ms, one query in 20 on the bench corpus).
+        n_ranked = k
+        while n_ranked < D and last_val > -math.inf and not self._two_cut_points(final):
+            self.stats["rank_continuations"] = self.stats.get("rank_continuations", 0) + 1
+            kk = min(TOPK_MAX, D - n_ranked)
+            mids = np.empty((1, kk), dtype=np.int32)
+            mvals = np.empty((1, kk), dtype=np.float64)
+            _lib.call("hipts_topk_after", _lib.ptr(rf_dev), c_int64(D), kk, c_double(last_val), c_int64(last_id), _lib.ptr(mids), _lib.ptr(mvals),
+                      self.index.device, _lib.current_stream_ptr())
+            last_id, last_val = int(mids[0, -1]), float(mvals[0, -1])
+            more = mvals[0] / mx if mx > 0 else mvals[0]
+            final += [(int(i), float(v)) for i, v in zip(mids[0], more) if int(i) not in top10_set]
+            n_ranked += kk
         final = filter_searched_result(final)                                         # :240
         return final[:min(topn, len(final))]
 

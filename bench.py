@@ -263,7 +263,8 @@ def query_section(device):
             "cpu_port_qps": cpu_qps, "cpu_port_sample": "%d queries, numpy CSR BM25 + C fma-chain + lexsort, 1 thread" % nq_cpu,
             "d2v_infer_docs_per_s": d2v_gpu, "d2v_sample": "%d docs x 100 epochs, host buffers in/out" % n_gpu,
             "find_similar_documents_ms": {"median": fs_ms[len(fs_ms) // 2], "min": fs_ms[0], "max": fs_ms[-1],
-                                          "sample": "20 queries of 1-4 tags, topn=800, 100-epoch inference of the query tags and of the top-10 documents"},
+                                          "sample": "20 queries of 1-4 tags, topn=800, 100-epoch inference of the query tags and of the top-10 documents",
+                                          "full_rank_fallbacks": full.stats["full_rank_fallbacks"], "rank_continuations": full.stats["rank_continuations"]},
             "d2v_train_doc_epochs_per_s": d2v_train, "d2v_train_sample": "%d docs x %d epochs, parallel schedule, host arrays in/out" % (n_tr, ep_tr),
             "d2v_train_cpu_port_doc_epochs_per_s": d2v_train_cpu, "d2v_train_cpu_sample": "%d docs x %d epochs, C oracle, 1 thread (reference: workers=1)" % (n_trc, ep_trc),
             "d2v_cpu_port_docs_per_s": d2v_cpu, "d2v_cpu_sample": "%d docs, C oracle, 1 thread (reference: workers=1)" % n_cpu}

@@ -299,6 +299,13 @@ int hipts_combine_with_max(const double* a, const float* b, int nq, int64_t n, d
  * vals is device memory; outputs in out_memspace. */
 int hipts_topk(const double* vals, int nq, int64_t n, int k, int32_t* ids_out, double* vals_out,
                int out_memspace, int device, void* stream);
+/* The ranking continued past a prefix already in hand: the next k entries of one query's order (value descending, ties by ascending
+ * index) AFTER the entry (after_val, after_id) -- i.e. among the scores with  v < after_val  or  v == after_val and index > after_id.
+ * vals: device float64 [n]; outputs on the host, padded with (-1, -inf) when fewer than k entries remain.  webui.py:191-192 sorts all
+ * documents and :63-80 then looks for its second cut point anywhere in that list; the device path ranks 1024 at a time and asks
+ * for more only while the filter still needs them (hiptagsearch/search.py::_doc2vec_rerank). */
+int hipts_topk_after(const double* vals, int64_t n, int k, double after_val, int64_t after_id, int32_t* ids_out, double* vals_out,
+                     int device, void* stream);
 /* the fused query of webui.py:352-383 for nq queries: BM25 + index product + normalise +
  * w_bm25/w_sim combine + top-k.  final_out (optional, device, float64 [nq][len]) receives the
  * combined scores for the rerank stage (webui.py:189-253). */

@@ -44,6 +44,10 @@ int hiptsdbg_attention_time(const uint16_t* q, const uint16_t* k, const uint16_t
 int hiptsdbg_attention2(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out_host, int batch, int heads, int tokens, int tokens_pad,
                         int f16, int variant, int iters, double* avg_us);
 
+/* Measurement-only builds of csrc/attn2.hip (-DHIPTS_X_STAMPS=<workgroup>): the cycle stamps of one wave (tools/attn2_check.py stamps);
+ * HIPTS_ERR_STATE in an ordinary build. */
+int hiptsdbg_attention2_stamps(unsigned long long* host, int n);
+
 /* One-query search path (hipts_search with nq == 1): how many candidates its threshold step collected for the last query and
  * whether the ranking used them (1) or fell through to the exact radix select (0). */
 int hiptsdbg_search1_last(hipts_bm25_t* h, uint32_t* candidates, uint32_t* took_candidate_path);

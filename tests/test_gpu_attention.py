@@ -1,5 +1,8 @@
-"""GPU: the attention kernel alone (hiptsdbg_attention_run) against a float64 softmax -- including inputs that FORCE the
-fallback of the max-free fast path (cdna_hip_programming.md rule 26: a rare data-dependent branch needs its own test).
+"""GPU: the attention kernels alone against a float64 softmax -- including inputs that FORCE the fallback of the max-free fast path
+(cdna_hip_programming.md rule 26: a rare data-dependent branch needs its own test).
+
+Two kernels: csrc/attn2.hip (head_dim 64: the ViT and EVA02 forwards since round 3; V in its natural layout; hiptsdbg_attention2, geometry
+variants 5 = default, 3, 1) and csrc/attn.hip (head_dim 32 and 64, V transposed: the CAFormer's; hiptsdbg_attention_run).
 
 Fast path: no running maximum.  bf16 operands: P = 2^S, valid while the row sum stays inside [2^-100, 2^100]; IEEE-half operands:
 P = 2^(S - m_ref) with m_ref the row's maximum over the first key tile, valid while the row sum stays below 2^15.  Otherwise the
@@ -40,7 +43,10 @@ def _from_bits(b, f16=0):
     return (b.astype(np.uint32) << 16).view(np.float32)
 
 
-def _run(q, k, v, tokens, hd, f16=0):
+KERNELS64 = ["attn2", "attn2:3", "attn2:1", "attn"]      # head_dim 64: the round-3 kernel (default geometry and two others) and the round-2 one
+
+
+def _run(q, k, v, tokens, hd, f16=0, kernel="attn"):
     """q, k, v: float32 (representable in the operand type) [BH, tokens, hd]; q already in the log2 domain.  Returns float32 [BH, tokens, hd]."""
     from hiptagsearch import _lib
     lib = _lib.load()
@@ -48,6 +54,15 @@ def _run(q, k, v, tokens, hd, f16=0):
     tp = (tokens + 63) // 64 * 64
     qp = np.zeros((BH, tp, hd), np.float32); qp[:, :tokens] = q
     kp = np.zeros((BH, tp, hd), np.float32); kp[:, :tokens] = k
+    if kernel.startswith("attn2"):
+        assert hd == 64
+        variant = int(kernel.split(":")[1]) if ":" in kernel else 0
+        vp = np.zeros((BH, tp, hd), np.float32); vp[:, :tokens] = v
+        out = np.zeros((1, tokens, BH * hd), np.uint16)
+        fn = lib.hiptsdbg_attention2
+        fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+        _lib.check(fn(_lib.ptr(_bits(qp, f16)), _lib.ptr(_bits(kp, f16)), _lib.ptr(_bits(vp, f16)), _lib.ptr(out), 1, BH, tokens, tp, int(f16), variant, 0, None))
+        return _from_bits(out, f16).reshape(tokens, BH, hd).transpose(1, 0, 2)
     vT = np.zeros((BH, hd, tp), np.float32); vT[:, :, :tokens] = v.transpose(0, 2, 1)
     out = np.zeros((1, tokens, BH * hd), np.uint16)
     lib.hiptsdbg_attention_run.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6
@@ -70,18 +85,19 @@ TOL = {0: 2e-2, 1: 3e-3}      # bf16 P and output: 2^-8 relative on O(1) values;
 # 16: one tile cut to its first half; 64 / 128: no masked tail; 96: the last tile holds exactly 32 keys (half); 97: 33 (masked, both halves);
 # 784 / 1025: waves past the last query row (three of 28 / of 36) that only stage
 @pytest.mark.parametrize("f16", [0, 1])
-@pytest.mark.parametrize("tokens,hd", [(784, 64), (1025, 64), (144, 32), (50, 64), (16, 64), (64, 64), (96, 64), (97, 64), (128, 32)])
+@pytest.mark.parametrize("tokens,hd", [(784, 64), (1025, 64), (144, 32), (50, 64), (16, 64), (64, 64), (96, 64), (97, 64), (128, 32), (200, 64)])
 def test_attention_matches_float64_softmax(tokens, hd, f16):
     rng = np.random.default_rng(tokens + hd)
     BH = 6
     q = _op(rng.standard_normal((BH, tokens, hd)) * 0.6, f16)       # scores of a few units, like the ViT's
     k = _op(rng.standard_normal((BH, tokens, hd)), f16)
     v = _op(rng.standard_normal((BH, tokens, hd)), f16)
-    got = _run(q, k, v, tokens, hd, f16)
     want = _reference(q, k, v)
-    err = np.abs(got - want).max()
-    print("attention %dx%d f16=%d: max |error| %.3e" % (tokens, hd, f16, err))
-    assert err <= TOL[f16]
+    for kernel in (KERNELS64 if hd == 64 else ["attn"]):
+        got = _run(q, k, v, tokens, hd, f16, kernel)
+        err = np.abs(got - want).max()
+        print("%s %dx%d f16=%d: max |error| %.3e" % (kernel, tokens, hd, f16, err))
+        assert err <= TOL[f16], kernel
 
 
 def _spike(q, k, b, row, key, score, f16):
@@ -94,8 +110,9 @@ def _spike(q, k, b, row, key, score, f16):
     return float(q[b, row].astype(np.float64) @ k[b, key].astype(np.float64))
 
 
+@pytest.mark.parametrize("kernel", KERNELS64)
 @pytest.mark.parametrize("f16", [0, 1])
-def test_attention_fallback_when_scores_leave_the_fast_window(f16):
+def test_attention_fallback_when_scores_leave_the_fast_window(f16, kernel):
     """Rows whose unnormalised sum overflows (a key with a score of +300), underflows (every score below -160) or mixes both ends
     must come out right: the fast path detects them (row sum outside its window: [2^-100, 2^100] with bf16 operands, [0.5, 2^15]
     relative to the first tile's maximum with half operands) and the workgroup reruns classically.
@@ -115,7 +132,7 @@ def test_attention_fallback_when_scores_leave_the_fast_window(f16):
     _spike(q, k, 2, 700, 3, 200.0, f16)
     s1 = float(q[1, 300].astype(np.float64) @ k[1, 0].astype(np.float64))
     assert s05 > 250 and s1 < -160, (s05, s1)
-    got = _run(q, k, v, tokens, hd, f16)
+    got = _run(q, k, v, tokens, hd, f16, kernel)
     want = _reference(q, k, v)
     assert np.isfinite(got).all()
     for (b, r) in [(0, 5), (1, 300), (1, 303), (2, 700)]:
@@ -126,8 +143,9 @@ def test_attention_fallback_when_scores_leave_the_fast_window(f16):
     np.testing.assert_allclose(got[0, 5], v[0, 600], atol=TOL[f16])   # the spike takes all the weight
 
 
+@pytest.mark.parametrize("kernel", ["attn2", "attn2:3", "attn"])
 @pytest.mark.parametrize("f16", [0, 1])
-def test_attention_window_edges(f16):
+def test_attention_window_edges(f16, kernel):
     """The range in which the fast path stays ACTIVE but P or O could be at risk: scores just inside and just outside each
     window edge, with |V| up to 8 so that O = sum P V is larger than the row sum.
       half: P = 2^(S - m_ref), m_ref = the row's maximum over the first 64 keys; a later key 13 above it stays on the fast path
@@ -167,7 +185,7 @@ def test_attention_window_edges(f16):
             k[1 + i] = _op(-base[None, :] * ((-sc / hd) * (1.0 + 0.01 * rng.random((tokens, 1)))), f16)
             q[1 + i, 300:302] = base
             rows += [(1 + i, 300)]
-    got = _run(q, k, v, tokens, hd, f16)
+    got = _run(q, k, v, tokens, hd, f16, kernel)
     want = _reference(q, k, v)
     assert np.isfinite(got).all()
     scale = np.abs(want).max(axis=2, keepdims=True) + 1.0
@@ -178,7 +196,8 @@ def test_attention_window_edges(f16):
     assert (np.abs(got - want) / scale).max() <= TOL[f16]
 
 
-def test_attention_classic_path_agrees():
+@pytest.mark.parametrize("kernel", ["attn2", "attn"])
+def test_attention_classic_path_agrees(kernel):
     """HIPTS_ATTN_CLASSIC=1 (per-tile running maximum everywhere) and the default fast path give the same output up to bf16 rounding."""
     code = r"""
 import sys, numpy as np
@@ -186,13 +205,13 @@ sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
 from test_gpu_attention import _run, _bf16
 rng = np.random.default_rng(3)
 q = _bf16(rng.standard_normal((3, 784, 64)) * 0.6); k = _bf16(rng.standard_normal((3, 784, 64))); v = _bf16(rng.standard_normal((3, 784, 64)))
-np.save(sys.argv[1], _run(q, k, v, 784, 64))
+np.save(sys.argv[1], _run(q, k, v, 784, 64, 0, sys.argv[2]))
 """ % (ROOT, os.path.join(ROOT, "anime-illust-image-searcher_amd"), os.path.join(ROOT, "tests"))
     import tempfile
     outs = []
     for classic in ("0", "1"):
         f = tempfile.mktemp(suffix=".npy")
-        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, env=dict(os.environ, HIPTS_ATTN_CLASSIC=classic), timeout=300)
+        r = subprocess.run([sys.executable, "-c", code, f, kernel], capture_output=True, text=True, env=dict(os.environ, HIPTS_ATTN_CLASSIC=classic), timeout=300)
         assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
         outs.append(np.load(f))
         os.remove(f)

@@ -346,6 +346,74 @@ def test_find_similar_documents_matches_oracle():
         want = osearch.rerank(final, 50, rerank_sims)
         assert [d for d, _ in got] == [d for d, _ in want], query
         np.testing.assert_array_equal(np.array([s for _, s in got]), np.array([s for _, s in want]))
+    assert eng.stats["full_rank_fallbacks"] == 0
+    print("rank continuations:", eng.stats["rank_continuations"])
+
+
+def test_rerank_continues_past_rank_1024_on_the_device():
+    """The gap filter's second cut point far down the list (ranks ~1500 and ~2000 of 2500, no near-tie before them): round 2 ranked all
+    scores on the host for such a query; now the device ranking is continued 1024 entries at a time.  Same result as the oracle's full
+    sort, no host fallback, and the continuation really ran."""
+    import torch
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from oracle import search as osearch
+    D, dim = 2500, 4
+    a = (1.0 - 3e-4 * np.arange(D)).astype(np.float32)            # spacing 3e-4 >> 1e-6 after the 0.3 weight and the normalisation
+    a[1500] = np.nextafter(a[1499], np.float32(0))                # two planted near-ties (one float32 step apart)
+    a[2000] = np.nextafter(a[1999], np.float32(0))
+    perm = np.random.default_rng(3).permutation(D)
+    rows = np.zeros((D, dim), np.float32)
+    rows[perm, 0] = a                                             # document perm[i] has rerank similarity a[i]
+
+    class StubModel:                                              # every document infers to e0: the rerank query is e0, rs = rows[:, 0]
+        vector_size = dim
+        def infer_vectors(self, docs):
+            v = np.zeros((len(docs), dim), np.float32); v[:, 0] = 1.0
+            return v
+
+    index = Similarity("idx", None, dim, capacity=D)
+    index.add_matrix(rows)                                        # stored as given (genmodel.py:171-173)
+    lines = ["img%05d.png,t" % d for d in range(D)]
+    eng = SearchEngine(StubModel(), index, {"t": 0}, None, lines)
+    final = np.full(D, 1e-3, np.float64)                          # first-stage scores all equal: its top 10 are documents 0..9
+    final_dev = torch.from_numpy(final).cuda().reshape(1, D)
+    ids = np.arange(1024, dtype=np.int32); vals = np.full(1024, 1e-3)
+    got = eng._doc2vec_rerank(final_dev, ids, vals, topn=5000)
+    want = osearch.rerank(final, 5000, lambda top_ids, top_scores: osearch.similarity(rows, np.array([1, 0, 0, 0], np.float32)))
+    assert [d for d, _ in got] == [d for d, _ in want]
+    np.testing.assert_array_equal(np.array([s for _, s in got]), np.array([s for _, s in want]))
+    assert eng.stats["full_rank_fallbacks"] == 0 and eng.stats["rank_continuations"] >= 1, eng.stats
+    assert len(got) > 1024
+
+
+def test_topk_after_continues_the_ranking():
+    """hipts_topk_after: the ranking 1024 entries at a time equals one full sort by (value descending, index ascending), through
+    exact ties and into the -inf tail (what _doc2vec_rerank relies on when the gap filter's second cut point lies past rank 1024)."""
+    import ctypes
+    import torch
+    from hiptagsearch import _lib
+    rng = np.random.default_rng(12)
+    n = 5000
+    v = np.round(rng.standard_normal(n), 2)                       # many exact ties
+    v[rng.choice(n, 1500, replace=False)] = -np.inf               # a masked tail
+    dev = torch.from_numpy(v).cuda()
+    order = np.lexsort((np.arange(n), -v))
+    ids = np.empty((1, 1024), np.int32); vals = np.empty((1, 1024), np.float64)
+    _lib.call("hipts_topk", _lib.ptr(dev), 1, ctypes.c_int64(n), 1024, _lib.ptr(ids), _lib.ptr(vals), _lib.HOST, 0, _lib.current_stream_ptr())
+    got_ids, got_vals = list(ids[0]), list(vals[0])
+    while len(got_ids) < n:
+        kk = min(1024, n - len(got_ids))
+        mi = np.empty((1, kk), np.int32); mv = np.empty((1, kk), np.float64)
+        _lib.call("hipts_topk_after", _lib.ptr(dev), ctypes.c_int64(n), kk, ctypes.c_double(got_vals[-1]), ctypes.c_int64(int(got_ids[-1])), _lib.ptr(mi),
+                  _lib.ptr(mv), 0, _lib.current_stream_ptr())
+        if got_vals[-1] == -np.inf:
+            break                                                 # nothing ranks after a -inf entry with a larger index ... except later -inf entries
+        got_ids += list(mi[0]); got_vals += list(mv[0])
+    finite = int(np.isfinite(v).sum())
+    assert got_ids[:finite] == list(order[:finite])
+    np.testing.assert_array_equal(np.array(got_vals[:finite]), v[order[:finite]])
+    assert all(x == -np.inf for x in got_vals[finite:])
 
 
 # --------------------------------------------------------------------------------- character features (config[4] rerank)
