@@ -185,3 +185,32 @@ def iter_shards(shard_dir: str, batch: int = 64) -> Iterator[Tuple[List[str], np
             raise ValueError("%s: %d rows but %d paths" % (n, arr.shape[0], len(paths)))
         for s in range(0, len(paths), batch):
             yield paths[s:s + batch], np.ascontiguousarray(arr[s:s + batch])
+
+
+def index_shards(shard_dir: str) -> Tuple[List[Tuple[str, int, int]], List[str]]:
+    """([(npy path, first global row, rows)], all paths in shard order) of a directory written by write_shards: what every rank needs to
+    find its own slice of the rows (Predictor.process_directory_sharded)."""
+    names = sorted(f for f in os.listdir(shard_dir) if f.startswith("shard-") and f.endswith(".npy"))
+    index: List[Tuple[str, int, int]] = []
+    paths: List[str] = []
+    for n in names:
+        with open(os.path.join(shard_dir, n[:-4] + ".txt"), encoding="utf-8") as f:
+            p = [l.rstrip("\n") for l in f]
+        index.append((os.path.join(shard_dir, n), len(paths), len(p)))
+        paths.extend(p)
+    return index, paths
+
+
+def iter_shard_rows(index: Sequence[Tuple[str, int, int]], lo: int, hi: int, batch: int = 64) -> Iterator[Tuple[int, np.ndarray]]:
+    """(first global row, uint8 [b,S,S,3]) batches of the global rows [lo, hi) across the shards of `index` (memory-mapped: a rank touches
+    only the bytes of its own slice)."""
+    for path, first, rows in index:
+        a, b = max(lo, first), min(hi, first + rows)
+        if a >= b:
+            continue
+        arr = np.load(path, mmap_mode="r")
+        if arr.shape[0] != rows:
+            raise ValueError("%s: %d rows but %d paths" % (path, arr.shape[0], rows))
+        for s0 in range(a, b, batch):
+            e = min(b, s0 + batch)
+            yield s0, np.ascontiguousarray(arr[s0 - first:e - first])

@@ -259,7 +259,8 @@ class Predictor:
             self.tagger_model = cls_.from_safetensors(checkpoint, self.cfg, max_batch=self.max_batch, device=self.device)
         else:
             print("No checkpoint given: using the seeded synthetic %s weights (no network in this environment)." % ("EVA02" if eva else "ViT"))
-            weights = synth.eva_weights(self.cfg, seed) if eva else synth.vit_weights(self.cfg, seed)
+            # the trained-like variant (peaked attention, sparse probabilities: tens of labels per image, as a real tagger selects)
+            weights = synth.eva_weights(self.cfg, seed, trained_like=True) if eva else synth.vit_weights(self.cfg, seed, trained_like=True)
             self.tagger_model = cls_(self.cfg, weights, self.max_batch, self.device)
         if labels_csv:
             import pandas as pd
@@ -309,24 +310,46 @@ class Predictor:
         return out
 
     # ---- multi-GPU form of tagging.py:276-359 --------------------------------------------------
-    ROW_WIDTH = 2 + 254          # int32 {n_general, n_character, ids[254]}: 1 KiB per image on the wire
+    ROW_WIDTH = int(os.environ.get("HIPTS_ROW_WIDTH", 2 + 254))     # int32 {n_general, n_character, ids[254]}: 1 KiB per image on the wire
+    #                                                                  (HIPTS_ROW_WIDTH: tests force every row through the second gather)
 
     def process_directory_sharded(self, dir_path: str, added_date: Optional[datetime.date], batch_size: int, dist, rank: int,
-                                  world: int) -> None:
+                                  world: int, workers: int = 0, shards: Optional[str] = None, synthetic: int = 0,
+                                  synthetic_seed: int = 1234) -> None:
         """One process per GPU (launched by torch.distributed.run; hiptagsearch.dist.init_from_env ran first).  Rank r tags
-        the contiguous block shard_range(n, r, world) of the file list with its own copy of the model, keeps fixed-width
+        the contiguous block shard_range(n, r, world) of the corpus with its own copy of the model, keeps fixed-width
         tag rows on its device (hipts_tagsel_run_rows), ONE all-gather puts them in rank order == file order, rank 0 formats
-        and appends the lines.  The file written is the file the single-process loop writes."""
+        and appends the lines.  The file written is the file the single-process loop writes.
+
+        Where a rank's images come from (round 3: every source is cut by rank, none is rank-0-only):
+          files      its block of the directory listing, decoded on 8 threads (the reference's pool, tagging.py:52) or, with
+                     `workers`, by its own pipeline.DecodePool;
+          shards     its slice of the rows of the packed uint8 shards `tagging.py --write-shards` wrote (memory-mapped);
+          synthetic  `synthetic` images of the benchmark corpus generated on its own GPU (hipts_synth_images_u8, keyed by
+                     the global image index: BASELINE.json configs[3], no host I/O).
+        A row that selected more labels than the 254 a wire row holds is completed by the rank that OWNS it -- the image is
+        fetched again from the rank's source, selected without a cap -- and those few full lines travel in a second gather
+        (round 2 redid them all on rank 0, i.e. serially)."""
         import torch
         from . import dist as hdist
         from .shard import gather_rows, padded_rows_per_rank, rows_to_lines, shard_range
+        size = None
+        shard_index = None                      # [(npy path, first global row, rows)]
         file_list = None
         if rank == 0:
-            file_list = self.list_files_recursive(dir_path)
-            print(f'{len(file_list)} files found')
+            if synthetic:
+                file_list = synthetic           # names are a function of the index: nothing to broadcast but the count
+            elif shards:
+                from . import pipeline
+                shard_index, file_list = pipeline.index_shards(shards)
+                print(f'{len(file_list)} images in {len(shard_index)} shards')
+            else:
+                file_list = self.list_files_recursive(dir_path)
+                print(f'{len(file_list)} files found')
+                if added_date is not None:
+                    file_list = self.filter_files_by_date(file_list, added_date)
+                    print(f'{len(file_list)} files found after {added_date}')
             if added_date is not None:
-                file_list = self.filter_files_by_date(file_list, added_date)
-                print(f'{len(file_list)} files found after {added_date}')
                 if os.path.exists('tags-wd-tagger.txt'):
                     with open('tags-wd-tagger.txt', 'r', encoding='utf-8') as f, \
                             open('tags-wd-tagger.txt.bak', 'w', encoding='utf-8') as f_bak:
@@ -334,12 +357,15 @@ class Predictor:
                 else:
                     print('tags-wd-tagger.txt not found')
                     file_list = 1                                   # every rank leaves with the reference's exit code
-        file_list = hdist.broadcast_object(file_list, dist)
+        file_list, shard_index = hdist.broadcast_object((file_list, shard_index), dist)
         if file_list == 1:
             raise SystemExit(1)
+        if synthetic:
+            file_list = ["synthetic/%07d.png" % i for i in range(int(file_list))]
         if self.compat and file_list:
             file_list = file_list[:(max(0, (len(file_list) + 9) // 10 - 1)) * 10]     # the reference's dropped tail (tagging.py:309), batch 10
         self.load_model()
+        size = self.cfg["image_size"]
         n = len(file_list)
         lo, hi = shard_range(n, rank, world)
         per = padded_rows_per_rank(n, world)
@@ -350,44 +376,95 @@ class Predictor:
         probs = torch.empty((bs, self.tagger_model.num_classes), dtype=torch.float32, device=dev)
         tmp = torch.empty((bs, W), dtype=torch.int32, device=dev)
         start = time.perf_counter()
-        mine = file_list[lo:hi]
-        batches = [mine[i:i + bs] for i in range(0, len(mine), bs)]
-        with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as ex:
-            nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[0]] if batches else []
-            for bi, paths in enumerate(batches):
-                futs = nxt
-                nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[bi + 1]] if bi + 1 < len(batches) else []
-                imgs, pos = [], []
-                for j, fu in enumerate(futs):
-                    t = fu.result()
-                    if t is not None:
-                        imgs.append(t)
-                        pos.append(bi * bs + j)
-                if not imgs:
-                    continue
-                k = len(imgs)
-                self.tagger_model.forward_u8(np.stack(imgs), probs=probs[:k], want="probs")
+
+        # ---- this rank's image source: batches of (block positions, uint8 images [k,S,S,3] on the host or on the device) + a fetch-one-again
+        def synthetic_images(first: int, k: int):
+            buf = torch.empty((k, size, size, 3), dtype=torch.uint8, device=dev)
+            _lib.call("hipts_synth_images_u8", _lib.ptr(buf), ctypes.c_int64(first), ctypes.c_int64(k), size, ctypes.c_uint64(synthetic_seed),
+                      self.device, _lib.current_stream_ptr())
+            return buf
+        pool = None
+        if synthetic:
+            def batches():
+                for s0 in range(lo, hi, bs):
+                    k = min(bs, hi - s0)
+                    yield list(range(s0 - lo, s0 - lo + k)), synthetic_images(s0, k)
+            fetch = lambda gi: synthetic_images(gi, 1).cpu().numpy()
+        elif shards:
+            from . import pipeline
+            def batches():
+                for first, arr in pipeline.iter_shard_rows(shard_index, lo, hi, bs):
+                    yield list(range(first - lo, first - lo + arr.shape[0])), arr
+            fetch = lambda gi: next(pipeline.iter_shard_rows(shard_index, gi, gi + 1, 1))[1]
+        elif workers > 0 and not self.compat:
+            from . import pipeline
+            mine = file_list[lo:hi]
+            where = {p: i for i, p in enumerate(mine)}
+            pool = pipeline.DecodePool(workers, size, bs, pipeline.TAGGER)
+            def batches():
+                for kept, images in pool.batches(mine):
+                    yield [where[p] for p in kept], images
+            fetch = lambda gi: (lambda t: None if t is None else t[None])(self.gen_image_tensor(file_list[gi]))
+        else:
+            mine = file_list[lo:hi]
+            def batches():
+                chunks = [mine[i:i + bs] for i in range(0, len(mine), bs)]
+                with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as ex:
+                    nxt = [ex.submit(self.gen_image_tensor, p) for p in chunks[0]] if chunks else []
+                    for bi in range(len(chunks)):
+                        futs = nxt
+                        nxt = [ex.submit(self.gen_image_tensor, p) for p in chunks[bi + 1]] if bi + 1 < len(chunks) else []
+                        imgs, pos = [], []
+                        for j, fu in enumerate(futs):
+                            t = fu.result()
+                            if t is not None:
+                                imgs.append(t)
+                                pos.append(bi * bs + j)
+                        if imgs:
+                            yield pos, np.stack(imgs)
+            fetch = lambda gi: (lambda t: None if t is None else t[None])(self.gen_image_tensor(file_list[gi]))
+
+        done = 0
+        try:
+            for pos, images in batches():
+                k = len(pos)
+                self.tagger_model.forward_u8(images, probs=probs[:k], want="probs")
                 self.selector.run_device(probs[:k], tmp[:k], 0.3, True, 0.3, True)     # tagging.py:333
                 rows[torch.as_tensor(pos, device=dev)] = tmp[:k]
-                if rank == 0 and (bi + 1) % max(1, PROGRESS_INTERVAL // bs) == 0:
+                done += k
+                if rank == 0 and done // PROGRESS_INTERVAL != (done - k) // PROGRESS_INTERVAL:
                     diff = time.perf_counter() - start
-                    print(f'{(bi + 1) * bs * world} files processed (all ranks)\n{diff:.2f} seconds elapsed\n', flush=True)
+                    print(f'{done * world} files processed (all ranks)\n{diff:.2f} seconds elapsed\n', flush=True)
+        finally:
+            if pool is not None:
+                pool.close()
+        # rows that did not fit the wire width: completed HERE, by their owner
+        mine_rows = rows[:max(hi - lo, 0)]
+        over = torch.nonzero((mine_rows[:, 0] >= 0) & (mine_rows[:, 0] + mine_rows[:, 1] > W - 2)).flatten().cpu().numpy()
+        wide = {}
+        for i in over:
+            img = fetch(lo + int(i))
+            if img is not None:
+                wide[lo + int(i)] = self.predict(img, 0.3, True, 0.3, True)[0]
         full = gather_rows(rows[:per] if per else rows[:0], n, dist)                   # [n, W] in file order, on every rank
+        wide_all = [None] * world
+        if dist is not None and dist.is_initialized() and world > 1:
+            dist.gather_object(wide, wide_all if rank == 0 else None, dst=0)           # the second, variable-width gather: over-wide rows only
+        else:
+            wide_all = [wide]
         if rank == 0:
+            redo = {}
+            for w_ in wide_all:
+                redo.update(w_ or {})
             full = full.cpu().numpy()
             ok = full[:, 0] >= 0
-            over = np.nonzero(ok & (full[:, 0] + full[:, 1] > W - 2))[0]             # more tags than the row holds: redo those few in full
-            redo = {}
-            for i in over:
-                t = self.gen_image_tensor(file_list[int(i)])
-                if t is not None:
-                    redo[int(i)] = self.predict([t], 0.3, True, 0.3, True)[0]
             with open('tags-wd-tagger.txt', 'a', encoding='utf-8') as f:              # tagging.py:293
                 lines = rows_to_lines(full, self.tag_names, file_list)
                 for i in range(n):
                     if ok[i]:
                         f.write((file_list[i] + ',' + redo[i] if i in redo else lines[i]) + '\n')
-            print(f'{int(ok.sum())} of {n} files tagged by {world} ranks in {time.perf_counter() - start:.2f} seconds', flush=True)
+            print(f'{int(ok.sum())} of {n} files tagged by {world} ranks in {time.perf_counter() - start:.2f} seconds '
+                  f'({len(redo)} rows wider than {W - 2} labels completed by their ranks)', flush=True)
 
     def write_to_file(self, csv_line: str) -> None:
         self.f.write(csv_line + '\n')

@@ -32,6 +32,8 @@ def main(arg_str: list) -> None:
                         help='decode / resize in this many processes (shared-memory pipeline) instead of 8 threads')
     parser.add_argument('--write-shards', default=None, help='decode --dir once into packed uint8 shards in this directory and exit')
     parser.add_argument('--shards', default=None, help='tag the pre-decoded shards in this directory (written by --write-shards)')
+    parser.add_argument('--synthetic', type=int, default=0, metavar='N',
+                        help='tag N images of the synthetic benchmark corpus generated on the device (BASELINE.json configs[3]; --dir is ignored)')
     parser.add_argument('--device', type=int, default=0)
     args = parser.parse_args(arg_str)
     # under torch.distributed.run (WORLD_SIZE > 1): one process per GPU, the process group comes up before any GPU call
@@ -59,10 +61,11 @@ def main(arg_str: list) -> None:
         print(f'{n} of {len(files)} images written to {args.write_shards}')
         return
     predictor.load_model(args.checkpoint, args.labels, cfg=model_cfg)
-    if dist is not None:
-        if args.workers or args.shards:
-            print('--workers / --shards are single-process input pipelines; under torch.distributed.run every rank decodes its own block on 8 threads')
-        predictor.process_directory_sharded(args.dir[0], after_date, 10 if args.compat else args.batch, dist, rank, world)
+    if dist is not None or args.synthetic:
+        # every rank feeds itself: its block of the files (8 threads, or its own --workers pool), its slice of --shards, or its block of
+        # the --synthetic corpus generated on its own GPU
+        predictor.process_directory_sharded(args.dir[0], after_date, 10 if args.compat else args.batch, dist, rank, world,
+                                            workers=args.workers, shards=args.shards, synthetic=args.synthetic)
         hdist.finish(dist)
         return
     predictor.process_directory(args.dir[0], after_date, batch_size=10 if args.compat else args.batch, workers=args.workers, shards=args.shards)

@@ -416,9 +416,17 @@ def main():
     names, cat = synth.label_table(cfg["num_classes"])
     selector = TagSelector(cat, max_batch=BATCH, device=local_rank)
 
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    images = torch.randint(0, 256, (BATCH, cfg["image_size"], cfg["image_size"], 3), dtype=torch.uint8, device=dev, generator=gen)
+    # the synthetic corpus is generated ON THE DEVICE by a counter-based generator keyed by the GLOBAL image
+    # index (hipts_synth_images_u8) -- rank r holds images r * 64 .. r * 64 + 63 of corpus 1234, and any rank can reproduce any image
+    # (the order check of the gathered rows below does).
+    CORPUS_SEED = 1234
+
+    def corpus_images(first, count):
+        buf = torch.empty((count, cfg["image_size"], cfg["image_size"], 3), dtype=torch.uint8, device=dev)
+        _lib.call("hipts_synth_images_u8", _lib.ptr(buf), ctypes.c_int64(first), ctypes.c_int64(count), cfg["image_size"], ctypes.c_uint64(CORPUS_SEED),
+                  local_rank, _lib.current_stream_ptr())
+        return buf
+    images = corpus_images(rank * BATCH, BATCH)
     probs = torch.empty((BATCH, cfg["num_classes"]), dtype=torch.float32, device=dev)
     rows = torch.zeros((BATCH, ROW_WIDTH), dtype=torch.int32, device=dev)
     gathered = torch.empty((world * BATCH, ROW_WIDTH), dtype=torch.int32, device=dev) if world > 1 else None
@@ -520,6 +528,20 @@ def main():
         assert same_rows and same_probs, "timed-region outputs differ from a fresh single-stream forward"
         check = {"rows_equal_single_stream_forward": same_rows, "probs_bit_equal": same_probs,
                  "tags_selected_per_image_mean": float((last_rows[:, 0] + last_rows[:, 1]).float().mean().item())}
+        if world > 1:
+            # ORDER of the all-gathered rows: rank 0 regenerates images that OTHER ranks tagged (first and last image of every rank's batch:
+            # global indices r * 64 and r * 64 + 63), tags them itself and compares with the rows at those positions of `gathered`
+            idx = sorted({r * BATCH + o for r in range(world) for o in (0, BATCH - 1)})
+            spot = torch.cat([corpus_images(i, 1) for i in idx])
+            sp_probs = torch.empty((len(idx), cfg["num_classes"]), dtype=torch.float32, device=dev)
+            sp_rows = torch.zeros((len(idx), ROW_WIDTH), dtype=torch.int32, device=dev)
+            model.forward_u8(spot, probs=sp_probs, want="probs")
+            selector.run_device(sp_probs, sp_rows)
+            torch.cuda.synchronize()
+            got = gathered[torch.as_tensor(idx, device=dev)]
+            order_ok = bool(torch.equal(got, sp_rows))
+            assert order_ok, "all-gathered tag rows are not in rank order == corpus order"
+            check["gathered_rows_in_corpus_order"] = {"ok": order_ok, "global_indices_recomputed_on_rank0": idx}
         _lib.call("hipts_vit_set_sub_batches", model._h, 0)
         _lib.call("hipts_vit_set_deferred_join", model._h, 1 if deferred else 0)
 

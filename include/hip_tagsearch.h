@@ -201,6 +201,14 @@ int hipts_ccip_forward_f32(hipts_ccip_t* h, const float* x, int x_memspace, int 
                            int out_memspace, void* stream);
 int hipts_ccip_flops_per_image(const hipts_ccip_t* h, double* flops);
 
+/* The synthetic image corpus of the benchmark configurations (BASELINE.json configs[3]: "1M synthetic images sharded
+ * 8xMI355X"), generated on the device with no host I/O: images first_index .. first_index + count - 1 of the corpus `seed`, uint8
+ * [count][image_size][image_size][3], every byte a counter-hash of (seed, GLOBAL image index, byte offset) -- so a rank produces its own
+ * contiguous block (tagging.py:276-359 cut by rank) and any rank can reproduce any image.  Replaces the decode of tagging.py:100-120 for
+ * benchmark input only. */
+int hipts_synth_images_u8(uint8_t* images_device, int64_t first_index, int64_t count, int image_size, uint64_t seed, int device,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tag selection.   Replaces the per-image numpy/Python post-processing   tagging.py:61-66,185-227
  * (float64 MCut threshold per category, strict '>' filter, stable descending order).

@@ -73,6 +73,54 @@ def test_tagging_cli_two_ranks_write_the_single_process_file(tmp_path, nproc):
     assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read().splitlines() == want
 
 
+def test_tagging_cli_vit_b16_shards_two_ranks(tmp_path):
+    """The contract model (--model vit-b16, trained-like synthetic checkpoint: tens of labels per image) from packed shards: under
+    torch.distributed.run every rank maps only its slice of the shard rows.  Same file as the single-process run, and no row needed
+    the second gather (31-33 labels fit the 254 of a wire row)."""
+    _make_images(str(tmp_path / "imgs"), 21, seed=3, broken=False)
+    cli = os.path.join(PKG, "tagging.py")
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--write-shards", "shards", "--workers", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--shards", "shards", "--batch", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    single = open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read()
+    assert len(single.splitlines()) == 21
+    n_tags = [len(l.split(",")) - 1 for l in single.splitlines()]
+    assert 10 <= min(n_tags) and max(n_tags) <= 60, n_tags                         # the regime a trained tagger runs in
+    os.remove(tmp_path / "tags-wd-tagger.txt")
+    r = _torchrun(2, "tagging.py", ["--dir", "imgs", "--shards", "shards", "--batch", "8"], tmp_path)
+    assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
+    assert "21 of 21 files tagged by 2 ranks" in r.stdout and "(0 rows wider" in r.stdout
+    # a rank with its own decode pool (--workers under torch.distributed.run)
+    os.remove(tmp_path / "tags-wd-tagger.txt")
+    _torchrun(2, "tagging.py", ["--dir", "imgs", "--workers", "2", "--batch", "8"], tmp_path)
+    assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
+
+
+def test_tagging_cli_synthetic_corpus_and_wide_rows(tmp_path):
+    """--synthetic N: every rank generates its block of the benchmark corpus on its GPU (hipts_synth_images_u8, keyed by the global
+    image index), so 1, 2 and 3 ranks write the same file.  With the tiny model's 200-class random-init... the trained-like head keeps
+    rows narrow; a second run with a wire row of only 8 labels forces EVERY row through the owner-completes-it second gather."""
+    cli = os.path.join(PKG, "tagging.py")
+    args = ["--dir", "unused", "--synthetic", "37", "--model", "vit-tiny", "--batch", "8"]
+    r = subprocess.run([sys.executable, cli] + args, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    single = open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read()
+    assert len(single.splitlines()) == 37 and single.splitlines()[36].startswith("synthetic/0000036.png,")
+    for nproc in (2, 3):
+        os.remove(tmp_path / "tags-wd-tagger.txt")
+        _torchrun(nproc, "tagging.py", args, tmp_path)
+        assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
+    os.remove(tmp_path / "tags-wd-tagger.txt")
+    env_w = dict(os.environ, HIPTS_ROW_WIDTH="10")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), cli] + args
+    r = subprocess.run(cmd, cwd=tmp_path, env=dict(env_w, HIPTS_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
+    assert "(37 rows wider than 8 labels completed by their ranks)" in r.stdout
+
+
 def test_gen_cfeatures_cli_two_ranks_build_the_single_process_index(tmp_path):
     sys.path.insert(0, PKG)
     from hiptagsearch.index import Similarity
