@@ -139,6 +139,19 @@ class EvaTagger(ViTTagger):
             self._h = c_void_p()
 
 
+def device_resize_u8(image: np.ndarray, out_h: int, out_w: int, pil_filter: int = 3, device: int = 0, out=None):
+    """uint8 [H,W,3] (host numpy or CUDA tensor) -> uint8 [out_h,out_w,3] CUDA tensor: PIL's Image.resize((out_w, out_h), filter) on the
+    device, bit for bit (pil_filter 3 = BICUBIC: tagging.py:241's transform; 2 = BILINEAR: gen_cfeatures.py:101)."""
+    import torch
+    if isinstance(image, np.ndarray):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+    if out is None:
+        out = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device="cuda:%d" % device)
+    _lib.call("hipts_resize_u8", _lib.ptr(image), _lib.memspace_of(image), int(image.shape[0]), int(image.shape[1]), _lib.ptr(out), out_h, out_w,
+              pil_filter, device, _lib.current_stream_ptr())
+    return out
+
+
 class TagSelector:
     def __init__(self, category: np.ndarray, max_batch: int = 64, device: int = 0):
         self.category = np.ascontiguousarray(category, dtype=np.int32)
@@ -202,10 +215,11 @@ class Predictor:
     the reference downloads from the HF hub (tagging.py:146-151); offline it takes local files or the
     seeded synthetic stand-ins."""
 
-    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False) -> None:
+    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False, gpu_resize: bool = False) -> None:
         self.device = device
         self.max_batch = max_batch
         self.compat = compat            # reproduce the reference's dropped tail batch (SURVEY.md section 0.4)
+        self.gpu_resize = gpu_resize    # the decode threads only decode and pad; Resize(bicubic) runs on the device (hipts_resize_u8)
         self.tagger_model: Optional[ViTTagger] = None
         self.selector: Optional[TagSelector] = None
         self.tag_names: Optional[List[str]] = None
@@ -271,7 +285,9 @@ class Predictor:
             self.load_labels(names, cat)
 
     # ---- tagging.py:234-252: returns the uint8 HWC image (the device kernel applies the transform)
-    def gen_image_tensor(self, file_path: str):
+    def gen_image_tensor(self, file_path: str, gpu_resize: bool = False):
+        """gpu_resize: decode and pad on the host, Resize(bicubic) on the device (hipts_resize_u8: Pillow's resample bit for bit) --
+        returns a uint8 [S,S,3] CUDA tensor instead of a numpy array."""
         from PIL import Image
         img = None
         try:
@@ -279,6 +295,8 @@ class Predictor:
             img.load()
             img_tmp = self.prepare_image(img)
             size = self.cfg["image_size"]
+            if gpu_resize:
+                return device_resize_u8(np.asarray(img_tmp, dtype=np.uint8), size, size, 3, self.device)
             if img_tmp.size != (size, size):
                 img_tmp = img_tmp.resize((size, size), Image.BICUBIC)   # timm eval transform: Resize(bicubic) + CenterCrop
             return np.asarray(img_tmp, dtype=np.uint8)
@@ -298,6 +316,9 @@ class Predictor:
             chunk = tensors[s:s + self.max_batch]
             if packed:
                 _, probs = self.tagger_model.forward_u8(chunk, want="probs")
+            elif hasattr(first, "is_cuda") and first.is_cuda:                     # uint8 [S,S,3] device tensors (gpu_resize)
+                import torch
+                _, probs = self.tagger_model.forward_u8(torch.stack(list(chunk)), want="probs")
             elif hasattr(first, "dtype") and str(first.dtype) in ("uint8", "torch.uint8"):
                 batch = np.stack([np.asarray(t) for t in chunk])
                 _, probs = self.tagger_model.forward_u8(batch, want="probs")
@@ -410,10 +431,10 @@ class Predictor:
             def batches():
                 chunks = [mine[i:i + bs] for i in range(0, len(mine), bs)]
                 with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as ex:
-                    nxt = [ex.submit(self.gen_image_tensor, p) for p in chunks[0]] if chunks else []
+                    nxt = [ex.submit(self.gen_image_tensor, p, self.gpu_resize) for p in chunks[0]] if chunks else []
                     for bi in range(len(chunks)):
                         futs = nxt
-                        nxt = [ex.submit(self.gen_image_tensor, p) for p in chunks[bi + 1]] if bi + 1 < len(chunks) else []
+                        nxt = [ex.submit(self.gen_image_tensor, p, self.gpu_resize) for p in chunks[bi + 1]] if bi + 1 < len(chunks) else []
                         imgs, pos = [], []
                         for j, fu in enumerate(futs):
                             t = fu.result()
@@ -421,7 +442,7 @@ class Predictor:
                                 imgs.append(t)
                                 pos.append(bi * bs + j)
                         if imgs:
-                            yield pos, np.stack(imgs)
+                            yield pos, (torch.stack(imgs) if self.gpu_resize else np.stack(imgs))
             fetch = lambda gi: (lambda t: None if t is None else t[None])(self.gen_image_tensor(file_list[gi]))
 
         done = 0
@@ -522,10 +543,10 @@ class Predictor:
         if self.compat and batches:
             batches = batches[:-1]      # the reference never consumes its last submitted batch (tagging.py:309)
         with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as ex:
-            nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[0]] if batches else []
+            nxt = [ex.submit(self.gen_image_tensor, p, self.gpu_resize) for p in batches[0]] if batches else []
             for bi, paths in enumerate(batches):
                 futs = nxt
-                nxt = [ex.submit(self.gen_image_tensor, p) for p in batches[bi + 1]] if bi + 1 < len(batches) else []   # prefetch
+                nxt = [ex.submit(self.gen_image_tensor, p, self.gpu_resize) for p in batches[bi + 1]] if bi + 1 < len(batches) else []   # prefetch
                 tensors, kept = [], []
                 for p, fu in zip(paths, futs):
                     t = fu.result()

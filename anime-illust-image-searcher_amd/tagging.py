@@ -32,6 +32,8 @@ def main(arg_str: list) -> None:
                         help='decode / resize in this many processes (shared-memory pipeline) instead of 8 threads')
     parser.add_argument('--write-shards', default=None, help='decode --dir once into packed uint8 shards in this directory and exit')
     parser.add_argument('--shards', default=None, help='tag the pre-decoded shards in this directory (written by --write-shards)')
+    parser.add_argument('--gpu-resize', action='store_true',
+                        help='decode threads only decode and pad; the Resize(bicubic) of the transform runs on the device (Pillow-exact kernel)')
     parser.add_argument('--synthetic', type=int, default=0, metavar='N',
                         help='tag N images of the synthetic benchmark corpus generated on the device (BASELINE.json configs[3]; --dir is ignored)')
     parser.add_argument('--device', type=int, default=0)
@@ -40,7 +42,7 @@ def main(arg_str: list) -> None:
     from hiptagsearch import dist as hdist
     dist, rank, world, device = hdist.init_from_env(args.device)
     from hiptagsearch.tagger import Predictor
-    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat)
+    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat, gpu_resize=args.gpu_resize)
     from hiptagsearch import synth
     model_cfg = {'vit-b16': synth.VIT_B16_448, 'eva02-l14': synth.EVA02_L14_448, 'vit-tiny': synth.VIT_TINY}[args.model]   # vit-tiny: test geometry
     after_date = None

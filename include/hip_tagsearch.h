@@ -201,6 +201,14 @@ int hipts_ccip_forward_f32(hipts_ccip_t* h, const float* x, int x_memspace, int 
                            int out_memspace, void* stream);
 int hipts_ccip_flops_per_image(const hipts_ccip_t* h, double* flops);
 
+/* PIL's resample on the device, bit for bit (Pillow libImaging/Resample.c, 8-bit RGB): replaces the host-side resize of the input
+ * pipeline -- the timm eval transform's Resize(bicubic) applied to the padded square of tagging.py:100-120 (tagging.py:241), and
+ * image.resize((384, 384), BILINEAR) of gen_cfeatures.py:101 -- so that decode workers only decode.
+ * src: uint8 [src_h][src_w][3] (host or device memory); dst_device: uint8 [dst_h][dst_w][3]; filter: PIL's enumerator, 2 = BILINEAR,
+ * 3 = BICUBIC (both with PIL's antialiasing: the filter support grows with the shrink factor). */
+int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, int src_w, uint8_t* dst_device, int dst_h, int dst_w, int filter,
+                    int device, void* stream);
+
 /* The synthetic image corpus of the benchmark configurations (BASELINE.json configs[3]: "1M synthetic images sharded
  * 8xMI355X"), generated on the device with no host I/O: images first_index .. first_index + count - 1 of the corpus `seed`, uint8
  * [count][image_size][image_size][3], every byte a counter-hash of (seed, GLOBAL image index, byte offset) -- so a rank produces its own
