@@ -95,6 +95,7 @@ _SIGNATURES = {
     "hipts_topk": [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "hipts_synth_images_u8": [c_void_p, c_int64, c_int64, c_int, ctypes.c_uint64, c_int, c_void_p],
     "hipts_resize_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "hipts_ccip_metric": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "hipts_topk_after": [c_void_p, c_int64, c_int, c_double, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                      c_void_p, c_void_p, c_void_p, c_void_p],

@@ -25,8 +25,9 @@ DEFAULT_THRESHOLD = 0.17847511429108218                  # docstring value, gen_
 # The reference cuts at metrics.json's threshold / 1.5 (gen_cfeatures.py:298-299) on the output of its METRIC MODEL.  That
 # constant is calibrated for that model's difference scale and does not transfer to 1 - cosine of the encoder features,
 # which is what BASELINE.json configs[4] restates the rerank as.  The cosine cut is therefore its own parameter
-# (CharacterFeatureIndex.cosine_diff_threshold); the default below only reuses the reference's number as a placeholder and
-# must be calibrated on same-character / different-character pairs of a real checkpoint (none is reachable here).
+# (CharacterFeatureIndex.cosine_diff_threshold); the default below only reuses the reference's number as a placeholder:
+# calibrate_threshold() derives the cut from labelled features the way the reference's constant was derived (best F1 over
+# same- / different-character pairs; tests/test_gpu_flows.py::test_ccip_metric_and_calibrated_threshold).
 DEFAULT_COSINE_DIFF_THRESHOLD = DEFAULT_THRESHOLD / 1.5
 INDEX_PREFIX = 'charactor-featues-idx'                   # gen_cfeatures.py:311 (the reference's spelling)
 
@@ -222,6 +223,44 @@ class CharacterFeatureIndex:
         if nq > 0:
             q = q / nq
         return np.float32(1.0) - self.index.query(q)[0]
+
+
+def ccip_batch_differences(features: np.ndarray, device: int = 0) -> np.ndarray:
+    """gen_cfeatures.py:257-274: the matrix of pairwise differences of a list of feature vectors -- float32 [n, n].  The reference runs its
+    metric model here; this is the cosine restatement (hipts_ccip_metric, kind 0): 1 - cosine of the unit-normalised rows."""
+    from . import _lib
+    f = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float32) for x in features]), dtype=np.float32)
+    out = np.empty((f.shape[0], f.shape[0]), dtype=np.float32)
+    _lib.call("hipts_ccip_metric", _lib.ptr(f), _lib.HOST, int(f.shape[0]), int(f.shape[1]), 0, _lib.ptr(out), _lib.HOST, device, _lib.current_stream_ptr())
+    return out
+
+
+def ccip_difference(x: np.ndarray, y: np.ndarray, device: int = 0) -> float:
+    """gen_cfeatures.py:212-244."""
+    return float(ccip_batch_differences([x, y], device)[0, 1])
+
+
+def calibrate_threshold(features: np.ndarray, labels: Sequence[int], device: int = 0) -> Tuple[float, float]:
+    """The cut for `difference < threshold` = "same character", chosen the way the reference's constant was (the metric model's
+    metrics.json carries the threshold with the best F1 on labelled pairs; gen_cfeatures.py:186-196 only reads it): all pairwise
+    differences of labelled features, every midpoint between consecutive distinct values as a candidate, the one with the highest
+    F1 over pairs.  Returns (threshold, its F1).  webui.py:298-299 then cuts at threshold / 1.5; CharacterFeatureIndex keeps that
+    ratio (set `cindex.cosine_diff_threshold = calibrate_threshold(...)[0] / 1.5`)."""
+    labels = np.asarray(labels)
+    d = ccip_batch_differences(features, device).astype(np.float64)
+    iu = np.triu_indices(len(labels), 1)
+    diffs, same = d[iu], (labels[:, None] == labels[None, :])[iu]
+    order = np.argsort(diffs, kind="stable")
+    diffs, same = diffs[order], same[order]
+    tp = np.cumsum(same)                                   # pairs called "same" when the cut sits right after position i
+    fp = np.cumsum(~same)
+    fn = same.sum() - tp
+    f1 = 2 * tp / np.maximum(2 * tp + fp + fn, 1)
+    valid = np.ones(len(diffs), dtype=bool)
+    valid[:-1] = diffs[1:] > diffs[:-1]                    # a cut is only possible between distinct values
+    i = int(np.argmax(np.where(valid, f1, -1.0)))
+    hi = diffs[i + 1] if i + 1 < len(diffs) else diffs[i] + 1e-3
+    return float((diffs[i] + hi) / 2), float(f1[i])
 
 
 def cfeatures_rerank(final_scores_top10: Sequence[Tuple[int, float]], top10_features: Sequence[np.ndarray],

@@ -339,6 +339,50 @@ def ccip_section(device):
     return out
 
 
+def input_pipeline_section(device):
+    """what one host core spends per image on decode alone and on decode + the transform's Resize(bicubic), and what the device
+    resize (hipts_resize_u8, Pillow-exact) sustains -- 1024 x 768 JPEGs, the padded 1024^2 square resized to 448^2 (tagging.py:100-120,241)."""
+    import io
+    from PIL import Image
+    from hiptagsearch.tagger import Predictor, device_resize_u8
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    blobs = []
+    for i in range(24):
+        buf = io.BytesIO()
+        Image.fromarray(np.roll(base, i, axis=0)).resize((1024, 768), Image.BICUBIC).save(buf, format="JPEG", quality=90)
+        blobs.append(buf.getvalue())
+    pr = Predictor(device=device)
+
+    def decode(b):
+        img = Image.open(io.BytesIO(b))
+        img.load()
+        return pr.prepare_image(img)
+    decode(blobs[0])
+    t0 = time.perf_counter()
+    padded = [decode(b) for b in blobs]
+    t_dec = (time.perf_counter() - t0) / len(blobs)
+    t0 = time.perf_counter()
+    for im in padded:
+        np.asarray(im.resize((448, 448), Image.BICUBIC), dtype=np.uint8)
+    t_res = (time.perf_counter() - t0) / len(blobs)
+    arrs = [torch.from_numpy(np.asarray(im, dtype=np.uint8)).cuda() for im in padded]
+    out = torch.empty((448, 448, 3), dtype=torch.uint8, device="cuda:%d" % device)
+    for a in arrs[:4]:
+        device_resize_u8(a, 448, 448, 3, device, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        for a in arrs:
+            device_resize_u8(a, 448, 448, 3, device, out=out)
+    torch.cuda.synchronize()
+    t_gpu = (time.perf_counter() - t0) / (4 * len(arrs))
+    return {"sample": "%d JPEGs 1024x768 (quality 90), padded to 1024^2, resized to 448^2 bicubic; one host core" % len(blobs),
+            "host_decode_only_images_per_s_per_core": 1.0 / t_dec, "host_decode_plus_resize_images_per_s_per_core": 1.0 / (t_dec + t_res),
+            "host_resize_share_of_decode_plus_resize": t_res / (t_dec + t_res),
+            "device_resize_images_per_s": 1.0 / t_gpu, "device_resize_note": "hipts_resize_u8, source already on the device, one call per image"}
+
+
 def eva_section(device):
     """The model the reference really loads (tagging.py:45): EVA02-L/14 @448, 723.5 GFLOP/image, bf16 MFMA."""
     from hiptagsearch import synth
@@ -669,6 +713,11 @@ def main():
             result["eva02_large"] = eva_section(local_rank)
         except Exception as e:
             result["eva02_large"] = {"error": repr(e)}
+    if world == 1 and not args.no_query:
+        try:
+            result["input_pipeline"] = input_pipeline_section(local_rank)
+        except Exception as e:
+            result["input_pipeline"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         # the oracle as the CHECKER of what the benched configuration computes on structured images (flat, posterised, gradient, line
         # art, half flat, flat tiles) and two noise images -- its forward over them is also the first part of the CPU sample

@@ -217,6 +217,15 @@ int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, int src_w, 
 int hipts_synth_images_u8(uint8_t* images_device, int64_t first_index, int64_t count, int image_size, uint64_t seed, int device,
                           void* stream);
 
+/* Pairwise CCIP differences.   Replaces `metric_model.run(['output'], {'input': features})` of ccip_batch_differences /
+ * ccip_difference                                                                  gen_cfeatures.py:212-274 (used by webui.py:303-335).
+ * features: float32 [n][dim] (dim = 768); diff_out: float32 [n][n].  kind 0: 1 - cosine of the rows (unit-normalised in float32, Gram
+ * matrix as the k-ordered fmaf chain of the dense index) -- how BASELINE.json configs[4] restates the reference's opaque metric graph;
+ * other kinds are reserved for a real metric head (HIPTS_ERR_INVALID until one is loaded).  The cut applied to these differences is a
+ * calibrated parameter of the caller (hiptagsearch.cfeatures.calibrate_threshold), not the reference's metric-model constant. */
+int hipts_ccip_metric(const float* features, int features_memspace, int n, int dim, int kind, float* diff_out, int out_memspace,
+                      int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tag selection.   Replaces the per-image numpy/Python post-processing   tagging.py:61-66,185-227
  * (float64 MCut threshold per category, strict '>' filter, stable descending order).

@@ -279,3 +279,33 @@ def test_safetensors_checkpoint_loaders(tmp_path):
                         str(tmp_path / "ViTTagger.safetensors")], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(open(tmp_path / "tags-wd-tagger.txt").read().splitlines()) == 3
+
+
+def test_ccip_metric_and_calibrated_threshold():
+    """hipts_ccip_metric (gen_cfeatures.py:257-274's call shape: features [n,768] -> differences [n,n]) in its cosine form, bit-equal to
+    the oracle's restatement (unit rows, k-ordered fmaf chain), and the rerank cut DERIVED from labelled features the way the
+    reference's constant was (best F1 over same- / different-character pairs) instead of borrowed from the metric model's scale."""
+    from hiptagsearch import cfeatures
+    from oracle import search as osearch
+    rng = np.random.default_rng(21)
+    n_cl, per, dim = 6, 8, 768
+    centers = rng.standard_normal((n_cl, dim)).astype(np.float32)
+    feats = np.concatenate([c + 0.35 * rng.standard_normal((per, dim)).astype(np.float32) for c in centers]) * np.float32(3.7)
+    labels = np.repeat(np.arange(n_cl), per)
+    got = cfeatures.ccip_batch_differences(feats)
+    # oracle: x / sqrt(fmaf-chain sum of squares) in float32, Gram rows by the same chain, 1 - s
+    unit = np.empty_like(feats)
+    for i, row in enumerate(feats):
+        s = osearch.similarity(row[None, :], row)[0]
+        unit[i] = row / np.sqrt(s, dtype=np.float32)
+    want = np.stack([np.float32(1.0) - osearch.similarity(unit, unit[i]) for i in range(len(unit))])
+    assert got.dtype == np.float32 and got.shape == (n_cl * per, n_cl * per)
+    np.testing.assert_array_equal(got, want)
+    assert np.abs(np.diag(got)).max() < 1e-5 and np.array_equal(got, got.T)
+    assert cfeatures.ccip_difference(feats[0], feats[1]) == float(got[0, 1])
+    thr, f1 = cfeatures.calibrate_threshold(feats, labels)
+    same = labels[:, None] == labels[None, :]
+    off = ~np.eye(len(labels), dtype=bool)
+    assert f1 == 1.0 and got[same & off].max() < thr < got[~same].min(), (thr, f1)
+    # the reference's number is on another scale altogether: applied to 1 - cosine it would reject every same-character pair here
+    assert cfeatures.DEFAULT_THRESHOLD < got[same & off].min()
