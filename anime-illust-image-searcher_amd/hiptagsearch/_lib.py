@@ -96,6 +96,10 @@ _SIGNATURES = {
     "hipts_synth_images_u8": [c_void_p, c_int64, c_int64, c_int, ctypes.c_uint64, c_int, c_void_p],
     "hipts_resize_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "hipts_ccip_metric": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "hipts_comm_unique_id": [c_void_p, c_size_t],
+    "hipts_comm_create": [c_void_p, c_size_t, c_int, c_int, c_int, POINTER(c_void_p)],
+    "hipts_comm_destroy": [c_void_p],
+    "hipts_allgather_rows": [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     "hipts_topk_after": [c_void_p, c_int64, c_int, c_double, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                      c_void_p, c_void_p, c_void_p, c_void_p],

@@ -251,6 +251,22 @@ int hipts_tagsel_run_rows(hipts_tagsel_t* h, const float* probs_device, int batc
                           int32_t* rows_device, int row_width, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The one collective of the indexing path: ranks tag contiguous blocks of the file list -- the loop of
+ * tagging.py:276-359 cut by rank, one process per GPU -- and ONE all-gather of their fixed-width rows (hipts_tagsel_run_rows; float32
+ * feature rows reinterpreted as int32 for gen_cfeatures.py:337-459) restores file order: out_device [world][rows_per_rank][row_width],
+ * rank order == file order.  RCCL over xGMI; resolved at run time (a PyTorch process uses the librccl it already maps).  The Python CLIs
+ * use torch.distributed for the same exchange; these entry points are for hosts in other languages.  Rank 0 creates the 128-byte id
+ * and hands it to the other ranks by its own means (file, socket, MPI ...).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hipts_comm hipts_comm_t;
+#define HIPTS_COMM_ID_BYTES 128
+int hipts_comm_unique_id(uint8_t* id_out, size_t bytes);
+int hipts_comm_create(const uint8_t* id, size_t bytes, int rank, int world, int device, hipts_comm_t** out);
+int hipts_comm_destroy(hipts_comm_t* comm);
+int hipts_allgather_rows(hipts_comm_t* comm, const int32_t* rows_device, int64_t rows_per_rank, int row_width, int32_t* out_device,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * BM25.   build replaces gen_and_save_bm25_index                            genmodel.py:51-99
  *         score replaces compute_bm25_scores(query_weights=...)             webui.py:119-172
  * ---------------------------------------------------------------------------------------- */

@@ -138,3 +138,22 @@ def test_gen_cfeatures_cli_two_ranks_build_the_single_process_index(tmp_path):
     assert open(tmp_path / "charactor-featues-idx.csv", encoding="utf-8").read() == paths
     rows2 = Similarity.load(str(tmp_path / "charactor-featues-idx")).matrix()
     np.testing.assert_array_equal(rows2, rows)                                     # the encoder is batch-invariant: same bits
+
+
+def test_c_abi_allgather_rows_single_rank():
+    """hipts_comm_* / hipts_allgather_rows: the all-gather of the indexing path for hosts that do not go through torch.distributed.  One GPU
+    here, so a world of one rank (two ranks on one GPU are refused by RCCL): the id / communicator / collective / destroy sequence runs
+    inside a PyTorch process -- i.e. against the librccl that process already maps -- and the gathered block equals the rows."""
+    import ctypes
+    import torch
+    from hiptagsearch import _lib
+    uid = (ctypes.c_uint8 * 128)()
+    _lib.call("hipts_comm_unique_id", uid, 128)
+    comm = ctypes.c_void_p()
+    _lib.call("hipts_comm_create", uid, 128, 0, 1, 0, ctypes.byref(comm))
+    rows = torch.arange(64 * 256, dtype=torch.int32, device="cuda").reshape(64, 256)
+    out = torch.zeros_like(rows)
+    _lib.call("hipts_allgather_rows", comm, _lib.ptr(rows), ctypes.c_int64(64), 256, _lib.ptr(out), _lib.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, rows)
+    _lib.call("hipts_comm_destroy", comm)
