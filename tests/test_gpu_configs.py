@@ -200,10 +200,11 @@ def test_config0_tagging_cli_on_32_synthetic_448_images(tmp_path):
     by_path = {l.split(",")[0]: l for l in lines}
     assert sorted(by_path) == sorted(os.path.join("imgs", "%02d.png" % i) for i in range(32))
     cfg = dict(synth.VIT_B16_448)
-    model = ViTTagger(cfg, synth.vit_weights(cfg, seed=0), max_batch=32)
+    model = ViTTagger(cfg, synth.vit_weights(cfg, seed=0, trained_like=True), max_batch=32)      # the CLI's stand-in checkpoint (Predictor.load_model)
     _, probs = model.forward_u8(imgs)
     names, cat = synth.label_table(cfg["num_classes"])
     want = otags.predict_lines(probs, names, cat)                      # tagging.py:185-227 restated (pinned by g4)
+    assert all(10 <= len(w.split(",")) <= 60 for w in want)            # tens of labels per image, as a trained tagger selects
     for i in range(32):
         p = os.path.join("imgs", "%02d.png" % i)
         assert by_path[p] == p + "," + want[i], "image %d" % i
