@@ -63,7 +63,10 @@ struct PinBuf {
         p = nullptr;
         bytes = 0;
         n = (n + 4095) / 4096 * 4096;
-        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        // coherent (fine-grained) on purpose: hipts_search's one-query path lets its last kernel store results and a completion
+        // sequence number here while the host spins on it -- with a non-coherent allocation (HIP_HOST_COHERENT=0 makes the default
+        // one) the stores would become visible only when the kernel ends and every query would burn its whole spin budget
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocCoherent | hipHostMallocMapped);
         if (e != hipSuccess) {
             p = nullptr;
             return set_error(HIPTS_ERR_OOM, "hipHostMalloc(%zu) failed: %s", n, hipGetErrorString(e));

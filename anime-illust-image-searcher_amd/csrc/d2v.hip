@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void d2v_infer_kernel(const float* __restrict_
 constexpr int PLAN_WORDS = 32;            // words per chunk
 constexpr int PLAN_MAX_NEG = 5;             // a word's group: 1 positive + up to 5 negative samples (gensim's default negative = 5)
 constexpr int PLAN_GROUP = 1 + PLAN_MAX_NEG;
-constexpr int PLAN_CAP = PLAN_WORDS * (1 + PLAN_MAX_NEG);     // 512 plan entries per wave
+constexpr int PLAN_CAP = PLAN_WORDS * (1 + PLAN_MAX_NEG);     // 32 x 6 = 192 plan entries per wave
 constexpr int PLAN_COARSE = 1024;
 constexpr uint32_t PLAN_POS = 0x80000000u;
 

@@ -1828,6 +1828,11 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         const int cus0 = cus_dev;
         if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && a.stat_part)) variant = 4;
     }
+    {   // A/B: HIPTS_GEMM_DW_MASK = bit mask over epilogue numbers whose launches take the two-workgroups-per-CU 256 x 128 kernel (its
+        // residents run out of phase, so one's epilogue overlaps the other's main loop; it pays only where the epilogue is long and K short)
+        static const unsigned dw_mask = getenv("HIPTS_GEMM_DW_MASK") ? (unsigned)strtoul(getenv("HIPTS_GEMM_DW_MASK"), nullptr, 0) : 0u;
+        if (variant == 1 && ((dw_mask >> (int)EPI) & 1u) && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && a.stat_part)) variant = 4;
+    }
     HIPTS_REQUIRE(!a.f16 || variant == 1 || variant == 4, "half-precision operands are only built for the pp and dw GEMM loops");
     if (variant == 4) {
         const int tiles_n = (a.N + DW_BN - 1) / DW_BN;

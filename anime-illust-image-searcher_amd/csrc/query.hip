@@ -770,7 +770,7 @@ constexpr int S1_LDS_TERMS = 6144;   // term ids of one workgroup's 128 document
 constexpr int S1_GROUPS = 4096;      // at most this many document groups (a group = 64 * gw consecutive documents, one wave of search1_combine_kernel)
 
 struct Search1Query {            // passed by value: 3.3 KB of the 4 KB kernel-argument segment
-    int32_t nt, n_required, masking, dim;
+    int32_t nt, dim;
     int32_t terms[S1_MAX_TERMS];
     double weights[S1_MAX_TERMS];
     float q[S1_MAX_DIM];

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dim,V,ndocs,epochs,with_sample", [(300, 2000, 300, 20, True), (300, 2000, 64, 100, False),
-                                                            (64, 500, 100, 7, True), (100, 70, 50, 5, True)])
+                                                            (64, 500, 100, 7, True), (100, 70, 50, 5, True),
+                                                            (64, 500, 8, 3, True)])      # the shape a round-2 bring-up build of the planned kernel faulted on (tools/gpurun/r2_dbg.sh)
 def test_d2v_infer_bit_exact(dim, V, ndocs, epochs, with_sample):
     from hiptagsearch import synth
     from hiptagsearch.d2v import Doc2VecInference
