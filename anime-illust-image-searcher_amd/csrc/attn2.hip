@@ -373,36 +373,15 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     using T_ = std::true_type;
     using F_ = std::false_type;
 
-    // one 32-key half: S, softmax, P V.  The four K fragments are requested together before the first S MFMA and the eight V^T pieces
-    // before the softmax, so that each group's LDS latency is paid once and the V^T pieces land under the exponentials
-    // (left to itself hipcc reads one fragment, waits, multiplies, reads the next: the matrix pipe idles ~100 cycles per MFMA).
-    auto half = [&](int t, int sl, int g, auto first_c, auto last_c) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
-        // half operands: the accumulator starts at -m_ref, so S - m_ref comes out of the MFMAs (hipcc keeps the 16-register tuple across the
-        // loop; 32 v_sub per tile otherwise).  The very first half (FIRST) defines m_ref and subtracts explicitly.
-        constexpr bool PRESUB = F16 && !FIRST;
-        const float c0 = PRESUB ? -m_ref : 0.f;
-        f32x16 sacc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if constexpr (LAST) sacc[i] = (t * KV + g * 32 + crow(i, h) >= tokens) ? -INFINITY : c0;
-            else sacc[i] = c0;
-        }
-        bf16x8 kf[4];
+    // A tile's two 32-key halves go S -> softmax -> P V one after the other.  LDS reads are requested in groups, ahead of their use
+    // (left to itself hipcc reads one fragment, waits, multiplies, reads the next: the matrix pipe idles ~100 cycles per MFMA): the four
+    // K fragments of a half together; the eight V^T pieces of a half right after its S MFMAs, so that they land under the exponentials;
+    // and the K fragments of the SECOND half before the softmax of the first, so that S of the second half starts without an LDS wait.
+    auto k_reads = [&](int sl, int g, bf16x8 (&kf)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(smem + sl + g * 4096 + ka[s]);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads
-#ifdef HIPTS_X_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sacc = mfma_32x32x16<F16>(kf[s], qf[s], sacc);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMA
-#ifdef HIPTS_X_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        HIPTS_STAMP(t * 16 + g * 8 + 2);
-        bf16x8 vf[2][2];
+    };
+    auto v_reads = [&](int sl, int g, bf16x8 (&vf)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const char* p0 = smem + sl + va[blk] + (32 * g) * 128;
@@ -410,14 +389,30 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
             vf[blk][0] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
             vf[blk][1] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // 8 DS reads (transposed)
+    };
+    // half operands: the accumulator starts at -m_ref, so S - m_ref comes out of the MFMAs (hipcc keeps the 16-register tuple across the
+    // loop; 32 v_sub per tile otherwise).  The very first half (FIRST) defines m_ref and subtracts explicitly.
+    auto s_mfma = [&](const bf16x8 (&kf)[4], int t, int g, f32x16& sacc, auto first_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        constexpr bool PRESUB = F16 && !FIRST;
+        const float c0 = PRESUB ? -m_ref : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (LAST) sacc[i] = (t * KV + g * 32 + crow(i, h) >= tokens) ? -INFINITY : c0;
+            else sacc[i] = c0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc = mfma_32x32x16<F16>(kf[s], qf[s], sacc);
+    };
+    auto soft = [&](const f32x16& sacc, bf16x8& w0, bf16x8& w1, auto first_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        constexpr bool PRESUB = F16 && !FIRST;
         if constexpr (F16 && FIRST) {                // the reference: this row's maximum over the first 32 keys
             float mx = sacc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
             m_ref = fmaxf(mx, __shfl_xor(mx, 32));
         }
-        bf16x8 w0, w1;
         float ls0 = 0.f, ls1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -437,26 +432,13 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
         ls0 = sacc[0];
 #endif
         l_run += ls0 + ls1;
-        HIPTS_STAMP(t * 16 + g * 8 + 3);
-#ifdef HIPTS_X_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef HIPTS_X_PVORDER                               // the two O^T chains interleaved instead of one after the other
-        o[0] = mfma_32x32x16<F16>(vf[0][0], w0, o[0]);
-        o[1] = mfma_32x32x16<F16>(vf[1][0], w0, o[1]);
-        o[0] = mfma_32x32x16<F16>(vf[0][1], w1, o[0]);
-        o[1] = mfma_32x32x16<F16>(vf[1][1], w1, o[1]);
-#else
+    };
+    auto pv = [&](const bf16x8 (&vf)[2][2], const bf16x8& w0, const bf16x8& w1) __attribute__((always_inline)) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             o[blk] = mfma_32x32x16<F16>(vf[blk][0], w0, o[blk]);
             o[blk] = mfma_32x32x16<F16>(vf[blk][1], w1, o[blk]);
         }
-#endif
-#ifdef HIPTS_X_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        HIPTS_STAMP(t * 16 + g * 8 + 4);
     };
     auto step = [&](int t, auto first_c, auto last_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_c)::value;
@@ -472,8 +454,41 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
         if (!active) return;
         HIPTS_STAMP(t * 16 + 1);
         const int sl = (t & 1) * TILE;
-        half(t, sl, 0, first_c, last_c);
-        if (!(LAST && tail_keys <= 32)) half(t, sl, 1, F_{}, last_c);
+        const bool two = !(LAST && tail_keys <= 32);
+        bf16x8 kf0[4], kf1[4], vf[2][2], w0, w1;
+        f32x16 sacc;
+        k_reads(sl, 0, kf0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads
+        s_mfma(kf0, t, 0, sacc, first_c, last_c);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMA
+        HIPTS_STAMP(t * 16 + 2);
+        v_reads(sl, 0, vf);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // 8 DS reads (transposed)
+#ifndef HIPTS_ATTN2_NO_KPREFETCH
+        if (two) {
+            k_reads(sl, 1, kf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+#endif
+        soft(sacc, w0, w1, first_c);
+        HIPTS_STAMP(t * 16 + 3);
+        pv(vf, w0, w1);
+        HIPTS_STAMP(t * 16 + 4);
+        if (two) {
+#ifdef HIPTS_ATTN2_NO_KPREFETCH
+            k_reads(sl, 1, kf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#endif
+            s_mfma(kf1, t, 1, sacc, F_{}, last_c);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            HIPTS_STAMP(t * 16 + 10);
+            v_reads(sl, 1, vf);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            soft(sacc, w0, w1, F_{});
+            HIPTS_STAMP(t * 16 + 11);
+            pv(vf, w0, w1);
+            HIPTS_STAMP(t * 16 + 12);
+        }
     };
     if (nkv == 1) step(0, T_{}, T_{});
     else {
