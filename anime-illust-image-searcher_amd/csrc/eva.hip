@@ -228,7 +228,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     bf16_t* v_p = h->v.as<bf16_t>() + qo;
     bf16_t* att_p = h->att.as<bf16_t>() + r0 * D;
     bf16_t* g1_p = h->g1.as<bf16_t>() + r0 * h->HK;
-    const int sblocks = 2 * h->HK / 64;                                        // 64-column blocks of the fc1 launch
+    const int sblocks = (2 * h->HK + 255) / 256;                               // 256-column tiles of the fc1 launch: one partial (sum, sum of squares) pair per tile and row
     float* stat_p = h->stat_part.as<float>() + 2 * (size_t)sblocks * r0;      // [sblocks][M] float2, this sub-batch's region
     float* rowstat_p = h->rowstat.as<float>() + 2 * r0;
     bf16_t* pooled2_p = h->pooled2.as<bf16_t>() + (size_t)i0 * 2 * D;
@@ -301,12 +301,20 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.ln_gamma = L.mn_g.as<float>();
         if (fold) folded(g, L.gx_u.as<float>(), L.gx_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_SWIGLU, g, s));
-        HIPTS_TRY(launch_rowstat(stat_p, rowstat_p, M, M, sblocks, c.mlp_hidden, c.ln_eps, s));      // 86 partial pairs per row -> (rstd, rstd * mean)
+        // (round 3) no rowstat kernel between the two GEMMs: the SwiGLU epilogue leaves ONE partial pair per (256-column tile, row) -- the four
+        // waves of a row meet in LDS -- and fc2's workgroups finish the 22 pairs of their tile's rows into an LDS table before their epilogue
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
         g.A = g1_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_c.as<float>(); g.out_f32 = x;
-        g.rowstat = rowstat_p; g.col_u = L.fc2_u.as<float>();
+        static const bool rowstat_kernel = getenv("HIPTS_EVA_ROWSTAT_KERNEL") && atoi(getenv("HIPTS_EVA_ROWSTAT_KERNEL"));      // A/B: finish the pairs in a kernel of its own
+        if (rowstat_kernel) {
+            HIPTS_TRY(launch_rowstat(stat_p, rowstat_p, M, M, sblocks, c.mlp_hidden, c.ln_eps, s));
+            g.rowstat = rowstat_p;
+        } else {
+            g.stat_in = stat_p; g.stat_in_blocks = sblocks; g.stat_in_stride = M; g.ln_dim = c.mlp_hidden; g.ln_eps = c.ln_eps;
+        }
+        g.col_u = L.fc2_u.as<float>();
         if (fold && li + 1 < c.depth) {      // the next layer's norm1 prepared here
             g.out_bf16 = xn; g.ln_gamma = h->layers[li + 1].ln1_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
             HIPTS_TRY(launch_gemm(EPI_RESID_XGI, g, s));
@@ -421,7 +429,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->v, qk)) ||
         (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
-        (st = h->stat_part.alloc((size_t)(2 * h->HK / 64) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
+        (st = h->stat_part.alloc((size_t)((2 * h->HK + 255) / 256) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
         (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
         delete h;
         return st;

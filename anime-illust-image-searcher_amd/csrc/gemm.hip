@@ -122,7 +122,18 @@ __device__ __forceinline__ float2 row_stat(const GemmArgs& a, int m) {
     m = m < a.M ? m : a.M - 1;
     if (a.stat_in) {
         float s1 = 0.f, s2 = 0.f;
-        for (int b = 0; b < a.stat_in_blocks; ++b) {
+        int b = 0;
+        for (; b + 8 <= a.stat_in_blocks; b += 8) {      // eight loads in flight, added in index order
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(a.stat_in + 2 * ((size_t)(b + u) * a.stat_in_stride + m));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s1 += v[u].x;
+                s2 += v[u].y;
+            }
+        }
+        for (; b < a.stat_in_blocks; ++b) {
             const float2 v = *reinterpret_cast<const float2*>(a.stat_in + 2 * ((size_t)b * a.stat_in_stride + m));
             s1 += v.x;
             s2 += v.y;
@@ -341,7 +352,9 @@ __device__ __forceinline__ void staged_store_half_rows(char* region, int lane, i
 // latencies overlap instead of forming a chain of 32 dependent round trips.
 template <int EPI, int MR = 8, bool F16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                              int lane, const f32x4* bias_pre = nullptr, char* scratch = nullptr) {
+                                              int lane, const f32x4* bias_pre = nullptr, char* scratch = nullptr, const float2* st_lds = nullptr) {
+    // st_lds: (rstd, rstd * mean) of the tile's rows m0 .. m0 + 255 finished into LDS by the caller (RESID_ROWSTAT / RESID_XGI with the
+    // statistics still as the producer's partials); null: read per lane (row_stat)
     const int lr = lane & 15, lq = lane >> 4;
     const int ld = a.ld_out ? a.ld_out : a.N;
     f32x4 bias_v[4];
@@ -516,7 +529,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     const int mc = m < a.M ? m : a.M - 1;
                     // a.pos: the patch embedding as the first "residual" GEMM -- x = acc * qscale + bias + pos[token] instead of x += ...
                     const float* row = a.pos ? a.pos + (size_t)(mc % a.tokens) * a.N : a.out_f32 + (size_t)mc * ld;
-                    st[u] = fold ? row_stat(a, mc) : make_float2(1.f, 0.f);
+                    st[u] = fold ? (st_lds ? st_lds[mc - m0] : row_stat(a, mc)) : make_float2(1.f, 0.f);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -612,7 +625,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                         const int mc = (INTERIOR || m < a.M) ? m : a.M - 1;
                         float* row = a.out_f32 + (size_t)mc * ld;
                         float2 st = make_float2(1.f, 0.f);
-                        if constexpr (EPI == EPI_RESID_ROWSTAT) st = *reinterpret_cast<const float2*>(a.rowstat + 2 * (size_t)mc);
+                        if constexpr (EPI == EPI_RESID_ROWSTAT) st = st_lds ? st_lds[mc - m0] : row_stat(a, mc);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             f32x4 v;
@@ -712,7 +725,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 // Wave-private image: no workgroup barrier, LDS operations of one wave execute in order.
 template <int EPI, int MR, bool F16>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                                     int lane, char* region, const f32x4* bias_pre = nullptr, const float2* st_lds = nullptr) {
+                                                     int lane, char* region, const f32x4* bias_pre = nullptr, const float2* st_lds = nullptr,
+                                                     float2* red = nullptr) {
+    // red (SWIGLU with stat_part, persistent loop): [256 rows][4 waves] in LDS -- the four waves of a row leave their partial row sums
+    // there and the caller adds them into ONE pair per (256-column tile, row)
     // st_lds: (rstd, rstd * mean) of the tile's rows m0 .. m0 + 255, finished from the producer's partials by the caller
     f32x4 bias_v[4];
     if (bias_pre) {
@@ -813,7 +829,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
                     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
                     const int m = mrow0 + i * 16 + lr;
-                    if (lq == 0 && m < a.M && ncol0 < a.N)
+                    if (red) {
+                        if (lq == 0) red[(mrow0 - m0 + i * 16 + lr) * 4 + wave_n] = ncol0 < a.N ? make_float2(s1, s2) : make_float2(0.f, 0.f);
+                    } else if (lq == 0 && m < a.M && ncol0 < a.N)
                         *reinterpret_cast<float2*>(a.stat_part + 2 * ((size_t)(ncol0 >> 6) * a.stat_stride + m)) = make_float2(s1, s2);
                 }
                 // the gamma of the LayerNorm that follows, applied to the stored operand (the statistics above are of the raw
@@ -1024,6 +1042,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
     constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float2 st_table[256];        // folded LayerNorm: (rstd, rstd * mean) of the current tile's rows
+    __shared__ float2 sw_red[EPI == EPI_SWIGLU ? 1024 : 1];      // SWIGLU: [256 rows][4 waves] partial row sums of the product
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
@@ -1275,10 +1294,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
         // latency is covered by the epilogue; the stage of the last K-tile is the epilogue's scratch.
         f32x4 bias_pre[4];
         load_bias<EPI>(a, n0, wave_n, lane, bias_pre);      // in flight while the next prologue is issued
-        constexpr bool FOLDABLE = EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU;
+        constexpr bool FOLDABLE = EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU ||
+                                  EPI == EPI_RESID_ROWSTAT || EPI == EPI_RESID_XGI;
         const bool fold_st = FOLDABLE && a.stat_in != nullptr;
+        const bool fold_many = fold_st && a.stat_in_blocks > 4;      // EVA02's fc2: 22 partial pairs per row (one per 256-column tile of the SwiGLU launch)
         float2 st_pv[4];
-        if (fold_st && tid < TBM) row_stat_request(a, m0 + tid, st_pv);
+        if (fold_st && !fold_many && tid < TBM) row_stat_request(a, m0 + tid, st_pv);
         const int next = tile + gridDim.x;
         const bool has_next = next < nwg;
         int m0n = 0, n0n = 0;
@@ -1291,7 +1312,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
         }
         PPSTAMP(4);
         if (fold_st) {      // uniform over the workgroup
-            if (tid < TBM) st_table[tid] = row_stat_finish(a, st_pv);
+            if (fold_many) {
+                if (tid < TBM) st_table[tid] = row_stat(a, m0 + tid);       // sums the partials in index order (deterministic), 8 loads in flight
+            } else if (tid < TBM) st_table[tid] = row_stat_finish(a, st_pv);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1302,12 +1325,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
                             : (EPI == EPI_QK || EPI == EPI_QK_ROPE) ? (a.dim % 64 == 0)
                                                                      : ((a.ld_out ? a.ld_out : a.N) % 8 == 0);
             if (ok) {
+                float2* red = (EPI == EPI_SWIGLU && a.stat_part) ? sw_red : nullptr;
                 gemm_epilogue_staged<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane,
-                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192, bias_pre, fold_st ? st_table : nullptr);
+                                                   smem + ((par + nt + 1) & 1) * STAGE_BYTES + wave * 8192, bias_pre, fold_st ? st_table : nullptr, red);
                 staged = true;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    if (red) {      // uniform: the four waves that hold a row meet; sw_red is written again only after the next tile's main loop
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (tid < TBM) {
+                            const float2 p0 = red[tid * 4], p1 = red[tid * 4 + 1], p2 = red[tid * 4 + 2], p3 = red[tid * 4 + 3];
+                            const int m = m0 + tid;
+                            if (m < a.M)
+                                *reinterpret_cast<float2*>(a.stat_part + 2 * ((size_t)(n0 >> 8) * a.stat_stride + m)) =
+                                    make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+                        }
+                    }
+                }
             }
         }
-        if (!staged) gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre, smem + ((par + nt + 1) & 1) * STAGE_BYTES);
+        if (!staged)
+            gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre, smem + ((par + nt + 1) & 1) * STAGE_BYTES,
+                                        fold_st ? st_table : nullptr);
         PPSTAMP(5);
         ++stamp_tile;
         if (!has_next) break;
@@ -1826,7 +1866,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
         const int cus0 = cus_dev;
-        if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && a.stat_part)) variant = 4;
+        if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_SWIGLU) && a.stat_part)) variant = 4;
     }
     {   // A/B: HIPTS_GEMM_DW_MASK = bit mask over epilogue numbers whose launches take the two-workgroups-per-CU 256 x 128 kernel (its
         // residents run out of phase, so one's epilogue overlaps the other's main loop; it pays only where the epilogue is long and K short)
@@ -1910,7 +1950,7 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_RESID_XG || epi == EPI_RESID_XGI)
         HIPTS_REQUIRE(a.out_f32 && (!a.out_bf16 || (a.ln_gamma && a.N % 8 == 0 && (!a.stat_part || a.stat_stride >= a.M))),
                       "gemm: RESID_XG needs the fp32 stream, col_u with rowstat, and gamma (N %% 8 == 0) with the 16-bit copy");
-    if (a.stat_in) HIPTS_REQUIRE(a.stat_in_blocks <= 4 && a.stat_in_blocks >= 1 && a.stat_in_stride >= a.M && a.ln_dim >= 1, "gemm: stat_in needs its block count, stride and ln_dim");
+    if (a.stat_in) HIPTS_REQUIRE(a.stat_in_blocks <= 64 && a.stat_in_blocks >= 1 && a.stat_in_stride >= a.M && a.ln_dim >= 1, "gemm: stat_in needs its block count (<= 64), stride and ln_dim");
     if ((a.rowstat || a.stat_in) && epi != EPI_RESID_ROWSTAT && epi != EPI_RESID_XGI)
         HIPTS_REQUIRE(a.col_u && (epi == EPI_QK || epi == EPI_QK_ROPE || epi == EPI_VT || epi == EPI_GELU || epi == EPI_SWIGLU || epi == EPI_STAR),
                       "gemm: a folded LayerNorm (rowstat) is built for the QK, QK_ROPE, VT, GELU, STAR and SWIGLU epilogues");
@@ -1922,7 +1962,7 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
                                                                   : ldo % 8 == 0;
         HIPTS_REQUIRE(staged && (gemm_variant() == 1 || gemm_variant() == 4), "gemm: a folded LayerNorm needs the staged epilogue (pp / dw loops, aligned outputs)");
     }
-    if (epi == EPI_RESID_ROWSTAT) HIPTS_REQUIRE(a.rowstat && a.col_u && a.out_f32, "gemm: RESID_ROWSTAT needs rowstat, col_u and the fp32 stream");
+    if (epi == EPI_RESID_ROWSTAT) HIPTS_REQUIRE((a.rowstat || a.stat_in) && a.col_u && a.out_f32, "gemm: RESID_ROWSTAT needs rowstat / stat_in, col_u and the fp32 stream");
     if (epi == EPI_SWIGLU) HIPTS_REQUIRE(!a.stat_part || a.stat_stride >= a.M, "gemm: SWIGLU stat_stride must cover M rows");
     if (epi == EPI_SWIGLU)
         HIPTS_REQUIRE(a.N % 64 == 0 && (a.ld_out ? a.ld_out : a.N / 2) % 8 == 0 && a.out_bf16, "gemm: SWIGLU needs N %% 64 == 0 and an output stride that is a multiple of 8");
