@@ -406,6 +406,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     __shared__ uint32_t cid[TOPK_CAP];
     __shared__ int scratch[17];
     __shared__ int sh_digit, sh_need, sh_bin, sh_cnt;
+    __shared__ unsigned long long sh_z0;       // largest order key among the scores of digit 0 (fast path that has to dip into that bin)
     __shared__ int soff[S1_GATHER_BLOCKS];
     const int tid = threadIdx.x;
     const double* __restrict__ v = vals + (int64_t)blockIdx.x * n;
@@ -473,9 +474,20 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
-        for (int64_t base = 0; base < n; base += 8192) {       // the first 1024 of every 8192 scores
-            const int64_t i = base + tid;
-            hist_add(hist, i < n ? value_digit(v[i]) : 0u, i < n);
+        // the first 1024 of every 8192 scores; TOPK_U loads per thread in flight (one load per step made the sample a chain of ~13
+        // dependent round trips for 100 k scores: ~25 us of the kernel's ~80 per workgroup)
+        for (int64_t base0 = 0; base0 < n; base0 += (int64_t)TOPK_U * 8192) {
+            double sx[TOPK_U];
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = base0 + (int64_t)u * 8192 + tid;
+                sx[u] = i < n ? v[i] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int64_t i = base0 + (int64_t)u * 8192 + tid;
+                hist_add(hist, i < n ? value_digit(sx[u]) : 0u, i < n);
+            }
         }
         __syncthreads();
         const int want = k / 8 + 3 * (int)ceilf(sqrtf((float)k / 8.0f)) + 4;
@@ -498,28 +510,66 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
             }
         }
         __syncthreads();
-        const uint32_t dmin = (uint32_t)sh_digit;
+        // The sample holds fewer than `want` entries above digit 0 when a required term has left most of the row -inf (digit 0): the top k
+        // then reach into that bin.  Round 2 took "everything", overflowed the candidate buffer and fell to the exact radix select -- six
+        // passes, 130-200 us for a row with fewer than ~300 finite scores, and the slowest row sets the launch time (measured:
+        // tools/topk_cases.py).  Now: collect everything ABOVE digit 0 and look at what the bin holds; if nothing but -inf (the common case),
+        // the candidates are all results and the rest are -inf ties in index order (the ordered fill at the end of the kernel).
+        const bool dip = sh_digit == 0;
+        const uint32_t dmin = dip ? 1u : (uint32_t)sh_digit;
+        if (tid == 0) sh_z0 = 0ull;
+        __syncthreads();
+        unsigned long long z0 = 0ull;
+        // the next step's TOPK_U loads are requested before this step's values are examined (two register sets): the pass was a chain of
+        // load round trips, one per 16 k scores
+        double x[TOPK_U], xn[TOPK_U];
+#pragma unroll
+        for (int u = 0; u < TOPK_U; ++u) {
+            const int64_t i = (int64_t)u * 1024 + tid;
+            x[u] = i < n ? v[i] : -INFINITY;
+        }
         for (int64_t i0 = 0; i0 < n; i0 += TOPK_U * 1024) {
-            double x[TOPK_U];
+            const int64_t i1 = i0 + TOPK_U * 1024;
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
-                const int64_t i = i0 + u * 1024 + tid;
-                x[u] = i < n ? v[i] : -INFINITY;
+                const int64_t i = i1 + u * 1024 + tid;
+                xn[u] = i < n ? v[i] : -INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
                 const int64_t i = i0 + u * 1024 + tid;
-                if (i < n && value_digit(x[u]) >= dmin) {
-                    const int slot = atomicAdd(&sh_cnt, 1);
-                    if (slot < TOPK_CAP) {
-                        ckey[slot] = order_key(x[u]);
-                        cid[slot] = (uint32_t)i;
+                if (i < n) {
+                    if (value_digit(x[u]) >= dmin) {
+                        const int slot = atomicAdd(&sh_cnt, 1);
+                        if (slot < TOPK_CAP) {
+                            ckey[slot] = order_key(x[u]);
+                            cid[slot] = (uint32_t)i;
+                        }
+                    } else if (dip) {
+                        const unsigned long long kx = order_key(x[u]);
+                        z0 = kx > z0 ? kx : z0;
                     }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) x[u] = xn[u];
+        }
+        if (dip) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(z0, o);
+                z0 = other > z0 ? other : z0;
+            }
+            if ((tid & 63) == 0) atomicMax(&sh_z0, z0);
         }
         __syncthreads();
-        done_fast = sh_cnt >= k && sh_cnt <= TOPK_CAP;
+        if (dip) {
+            // digit 0 empty (z0 == 0: every score was collected) or nothing but -inf in it
+            done_fast = sh_cnt <= TOPK_CAP && (sh_z0 == 0ull || sh_z0 == order_key(-INFINITY));
+            if (done_fast && sh_cnt < k) fill_need = k - sh_cnt;
+        } else {
+            done_fast = sh_cnt >= k && sh_cnt <= TOPK_CAP;
+        }
         __syncthreads();
     }
     uint64_t prefix = 0;
