@@ -383,8 +383,9 @@ def input_pipeline_section(device):
             "device_resize_images_per_s": 1.0 / t_gpu, "device_resize_note": "hipts_resize_u8, source already on the device, one call per image"}
 
 
-def eva_section(device):
-    """The model the reference really loads (tagging.py:45): EVA02-L/14 @448, 723.5 GFLOP/image, bf16 MFMA."""
+def eva_section(device, oracle_check=False):
+    """The model the reference really loads (tagging.py:45): EVA02-L/14 @448, 723.5 GFLOP/image.  oracle_check (the cpu_baseline leg): the
+    trained-like checkpoint's logits on a noise and a flat image against the float32 CPU oracle, absolute and rms-relative."""
     from hiptagsearch import synth
     from hiptagsearch.tagger import EvaTagger
     cfg = dict(synth.EVA02_L14_448)
@@ -409,6 +410,24 @@ def eva_section(device):
         out["flops_per_image"] = fl
         m.close()
     out["published_reference"] = "0.59 images/sec CPU (Ryzen 7 5700X), ~2 images/sec GTX 1660 SUPER (reference README, this model)"
+    if oracle_check:
+        from oracle import eva as oeva
+        wt = synth.eva_weights(cfg, seed=0, trained_like=True)
+        chk = np.concatenate([synth.images_u8(1, 448, seed=5), synth.structured_images_u8(448, seed=77, kinds=("flat",))])
+        m = EvaTagger(cfg, wt, max_batch=2, device=device)
+        got, _ = m.forward_u8(chk, want="logits")
+        m.close()
+        t0 = time.perf_counter()
+        from oracle import vit as ovit
+        want = oeva.eva_forward(oeva.to_torch(wt), ovit.preprocess_u8_nhwc(chk), patch=cfg["patch"], heads=cfg["heads"], eps=cfg["ln_eps"],
+                                ref_grid=cfg["rope_ref_grid"]).numpy()
+        if want is not None:
+            d = got.astype(np.float64) - want.astype(np.float64)
+            rms_l = np.sqrt((want.astype(np.float64) ** 2).mean(axis=1))
+            out["oracle_check"] = {"checkpoint": "trained-like", "images": ["noise", "flat"], "logit_rms": float(rms_l.mean()),
+                                   "max_abs_logit_error": [float(v) for v in np.abs(d).max(axis=1)],
+                                   "rms_relative_logit_error": [float(v) for v in np.sqrt((d ** 2).mean(axis=1)) / rms_l],
+                                   "cpu_oracle_seconds": time.perf_counter() - t0}
     return out
 
 
@@ -710,7 +729,7 @@ def main():
         except Exception as e:
             result["ccip"] = {"error": repr(e)}
         try:
-            result["eva02_large"] = eva_section(local_rank)
+            result["eva02_large"] = eva_section(local_rank, oracle_check=not args.no_cpu_baseline)
         except Exception as e:
             result["eva02_large"] = {"error": repr(e)}
     if world == 1 and not args.no_query:

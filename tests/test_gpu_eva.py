@@ -69,6 +69,38 @@ def test_eva02_large_448_matches_oracle(f16):
         np.testing.assert_array_equal(dflt.forward_u8(imgs)[0], logits)
 
 
+def test_eva02_large_trained_like_checkpoint():
+    """EVA02-L/14 (the model the reference loads) in the regime a trained tagger runs in -- synth.eva_weights(trained_like=True): peaked
+    attention with a heavy tail (the half-safe softmax and its fallback run), logit rms ~10, tens of labels selected -- on a noise image, a
+    flat one and a cel-shaded one.  Absolute AND rms-relative logit error are reported; the relative one and the selected labels are
+    asserted (the absolute 1e-3 of BASELINE.json is stated at the random init's logit scale, 15x smaller)."""
+    from hiptagsearch import synth
+    from hiptagsearch.tagger import EvaTagger, TagSelector
+    from oracle import tags as otags
+    cfg = dict(synth.EVA02_L14_448)
+    w = synth.eva_weights(cfg, seed=0, trained_like=True)
+    imgs = np.concatenate([synth.images_u8(1, 448, seed=5), synth.structured_images_u8(448, seed=77, kinds=("flat", "blocks"))])
+    want, _ = _oracle(cfg, w, imgs)
+    model = EvaTagger(cfg, w, max_batch=4)
+    logits, probs = model.forward_u8(imgs)
+    assert np.isfinite(logits).all()
+    d = logits.astype(np.float64) - want.astype(np.float64)
+    rms_l = np.sqrt((want.astype(np.float64) ** 2).mean(axis=1))
+    mx, rel = np.abs(d).max(axis=1), np.sqrt((d ** 2).mean(axis=1)) / rms_l
+    for name, a, r in zip(("noise", "flat", "blocks"), mx, rel):
+        print("EVA02-L trained-like, %-6s max |dlogit| %.3e  rms-relative %.3e  (logit rms %.2f)" % (name, a, r, rms_l.mean()))
+    assert rel.max() <= 2e-3 and mx.max() <= 1e-1, (mx, rel)
+    names, cat = synth.label_table(cfg["num_classes"])
+    counts, ids, _ = TagSelector(cat, max_batch=4).run(probs, 0.3, True, 0.3, True)
+    gi, ci = list(np.where(cat == 0)[0]), list(np.where(cat == 4)[0])
+    wp = otags.sigmoid_f32(want)
+    for i in range(len(imgs)):
+        g, c, _, _ = otags.select_indices(wp[i], gi, ci, 0.3, True, 0.3, True)
+        got = sorted(ids[i, :counts[i, 0] + counts[i, 1]])
+        assert got == sorted(list(g) + list(c)), i
+        assert 10 <= len(got) <= 60
+
+
 def test_eva_missing_tensor_is_reported():
     from hiptagsearch import synth, _lib
     from hiptagsearch.tagger import EvaTagger
