@@ -444,9 +444,11 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
         constexpr bool LAST = decltype(last_c)::value;
         HIPTS_STAMP(t * 16 + 0);
         wait_vm<0>();                                // tile t (requested one step ago) has landed for this wave ...
+        HIPTS_STAMP(t * 16 + 5);
 #ifndef HIPTS_X_NOBARRIER                            // (HIPTS_X_*: measurement-only builds, tools/gpurun/r3_attn_x.sh -- results are wrong with them)
         __builtin_amdgcn_s_barrier();                // ... and for every wave; tile t - 1's slots are free
 #endif
+        HIPTS_STAMP(t * 16 + 6);
 #ifdef HIPTS_X_NODMA
         if (t == 0)
 #endif

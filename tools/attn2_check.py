@@ -101,8 +101,8 @@ def stamps(variant, f16=0, T=784, B=32):
     for t in range(TP // 64):
         s = st[t * 16: t * 16 + 16]
         nxt = st[(t + 1) * 16] if t + 1 < TP // 64 else s[12]
-        print("  tile %2d: wait %5d | h0: S %5d sm %5d pv %5d | h1: S %5d sm %5d pv %5d | total %6d" % (
-            t, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[10] - s[4], s[11] - s[10], s[12] - s[11], nxt - s[0]))
+        print("  tile %2d: vmcnt %5d barrier %5d dma %5d | h0: S %5d sm %5d pv %5d | h1: S %5d sm %5d pv %5d | total %6d" % (
+            t, s[5] - s[0], s[6] - s[5], s[1] - s[6], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[10] - s[4], s[11] - s[10], s[12] - s[11], nxt - s[0]))
 
 
 if __name__ == "__main__":
