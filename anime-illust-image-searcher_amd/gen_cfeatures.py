@@ -43,12 +43,12 @@ def list_files_recursive(dir_path: str):
     return out
 
 
-def encode_files(file_list, batch, cindex_encode, on_batch, size=384):
+def encode_files(file_list, batch, cindex_encode, on_batch, size=384, gpu_resize=False, device=0):
     """The decode-ahead loop of gen_cfeatures.py:386-424: 8 threads prepare batch i+1 while the device encodes batch i.
     on_batch(paths_kept, features) is called per batch; failed loads are skipped (:392-395)."""
     import functools
     from hiptagsearch import cfeatures
-    gen_image_ndarray = functools.partial(cfeatures.gen_image_ndarray, size=size)
+    gen_image_ndarray = functools.partial(cfeatures.gen_image_ndarray, size=size, gpu_resize=gpu_resize, device=device)
     with concurrent.futures.ThreadPoolExecutor(max_workers=WORKER_NUM) as pool:
         nxt = pool.map(gen_image_ndarray, file_list[:batch])
         for s in range(0, len(file_list), batch):
@@ -72,6 +72,8 @@ def main(arg_str: list) -> None:
     parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='half',
                         help='MFMA operand type of the encoder GEMMs (half: same matrix rate as bf16, 8x smaller activation rounding; '
                              'e4m3 = the fp8 mode: 3 mantissa bits)')
+    parser.add_argument('--gpu-resize', action='store_true',
+                        help='decode threads only decode; the bilinear resize of gen_cfeatures.py:101 runs on the device (Pillow-exact kernel)')
     parser.add_argument('--arch', choices=['b36', 'tiny'], default='b36', help='b36: CAFormer-B36 widths @384 (the CCIP encoder); tiny: test geometry')
     args = parser.parse_args(arg_str)
     after_date = None
@@ -133,6 +135,9 @@ def main(arg_str: list) -> None:
         print(f'{done[0]} files processed\n{el:.2f} seconds elapsed\n{el / max(done[0], 1):.4f} seconds per file\n', flush=True)
 
     def extract(arrs):                                                                  # :133-159
+        if hasattr(arrs[0], "is_cuda"):                                                 # --gpu-resize: uint8 [S,S,3] device tensors
+            import torch
+            return np.asarray(encoder.forward_u8(torch.stack(list(arrs))), dtype=np.float32)
         return np.asarray(encoder(np.stack(arrs).astype(np.float32)), dtype=np.float32)
 
     if dist is not None:
@@ -147,7 +152,7 @@ def main(arg_str: list) -> None:
         def keep_rows(idx, feats):
             rows[idx, 0] = 1.0
             rows[idx, 1:] = feats
-        encode_files(file_list[lo:hi], args.batch, extract, keep_rows, cfg['image_size'])
+        encode_files(file_list[lo:hi], args.batch, extract, keep_rows, cfg['image_size'], args.gpu_resize, device)
         cdev = hdist.collective_device(dist, device)
         full = gather_rows(torch.from_numpy(rows[:per] if per else rows[:0]).to(cdev), n, dist).cpu().numpy()
         if rank == 0:
@@ -175,7 +180,8 @@ def main(arg_str: list) -> None:
                 for kept, images in dpool.batches(file_list):
                     add(kept, encoder.forward_u8(images))                               # /255 and the CLIP normalisation on the device
         else:
-            encode_files(file_list, args.batch, extract, lambda idx, feats: add([file_list[i] for i in idx], feats), cfg['image_size'])
+            encode_files(file_list, args.batch, extract, lambda idx, feats: add([file_list[i] for i in idx], feats), cfg['image_size'],
+                         args.gpu_resize, device)
     cindex.index.save(save_name)                                                        # :459
 
 

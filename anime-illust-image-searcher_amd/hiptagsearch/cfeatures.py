@@ -77,8 +77,10 @@ def _preprocess_image(image, size: int = 384):
     return _normalize(data)
 
 
-def gen_image_ndarray(file_path: str, size: int = 384) -> Optional[np.ndarray]:
-    """gen_cfeatures.py:285-295 (imgutils.load_images(mode='RGB') = alpha composited on white)."""
+def gen_image_ndarray(file_path: str, size: int = 384, gpu_resize: bool = False, device: int = 0):
+    """gen_cfeatures.py:285-295 (imgutils.load_images(mode='RGB') = alpha composited on white).
+    gpu_resize: the host only decodes; the bilinear resize of gen_cfeatures.py:101 runs on the device (hipts_resize_u8, Pillow's resample
+    bit for bit) and a uint8 [size,size,3] CUDA tensor is returned for CCIPEncoder.forward_u8, which applies :102-110 in its first kernel."""
     from PIL import Image
     try:
         img = Image.open(file_path)
@@ -89,6 +91,9 @@ def gen_image_ndarray(file_path: str, size: int = 384) -> Optional[np.ndarray]:
             img = bg
         else:
             img = img.convert("RGB")
+        if gpu_resize:
+            from .tagger import device_resize_u8
+            return device_resize_u8(np.asarray(img, dtype=np.uint8), size, size, 2, device)
         return _preprocess_image(img, size)
     except Exception as e:
         print('%s: %s' % (type(e), str(e)))

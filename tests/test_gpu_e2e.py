@@ -111,5 +111,13 @@ def test_gen_cfeatures_cli_builds_and_extends_the_feature_index(tmp_path, monkey
     assert len(p3) == 21
     for i, p in enumerate(paths):
         np.testing.assert_allclose(m3[14 + p3[14:].index(p)], m[i], atol=1e-5)
+    # --gpu-resize: the threads only decode, the bilinear resize is the device kernel (Pillow's result bit for bit) -- the same features
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "2000-01-01", "--batch", "4", "--gpu-resize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m4 = Similarity.load("charactor-featues-idx3").matrix()
+    p4 = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
+    assert len(p4) == 28
+    for i, p in enumerate(paths):
+        np.testing.assert_allclose(m4[21 + p4[21:].index(p)], m[i], atol=1e-5)
     r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "not-a-date"], capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid date format" in r.stdout
