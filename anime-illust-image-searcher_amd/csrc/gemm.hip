@@ -1054,6 +1054,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
     auto tile_origin = [&](int id, int& m0, int& n0) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if (a.raster_gn > 0) {
+            // Column groups outermost: all row panels x raster_gn column tiles, row-major inside the group, then the next group.
+            // An XCD's contiguous chunk of the order then lies inside one group (or two): its slice of W (raster_gn panels) is all the
+            // W it ever reads and stays in its L2, a round is 32 / raster_gn row panels x raster_gn column tiles, and a row panel of A
+            // is fetched once per column group.
+            const int per = tiles_m * a.raster_gn, grp = bid / per, rem = bid - grp * per;
+            const int left = tiles_n - grp * a.raster_gn, gn = left < a.raster_gn ? left : a.raster_gn;
+            m0 = (rem / gn) * TBM;
+            n0 = (grp * a.raster_gn + rem % gn) * BN;
+            return;
+        }
         if (a.raster_gm > 0) {
             // Wide outputs (fc1: 12 column tiles): row-major order hands the 32 workgroups of an XCD 2.7 row panels x ALL column
             // tiles per round -- the whole W (4.7 MB) plus 1 MB of A against a 4 MB L2, so W is pulled through the fabric again every
@@ -1127,7 +1138,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
                     const int e = 2 * wave + u;
                     slot(6 + u, false, e < 8 ? 8 + e : 2 * MR + 8 + (e - 8));
                 }
+            } else if constexpr (MR == 6) {
+                // 8 sub-tiles: group 0 blocks 8..11, group 1 blocks 2MR+8 .. 2MR+11; one per wave
+                slot(6, false, wave < 4 ? 8 + wave : 2 * MR + 8 + (wave - 4));
+                src[7] = src[6];
+                dst[7] = dst[6];
             } else {
+                static_assert(MR == 7, "tile heights: 256, 224 or 192 rows");
                 // 12 sub-tiles: group 0 blocks 8..13, group 1 blocks 2MR+8 .. 2MR+13; waves 0..3 take two, 4..7 one
                 auto hi = [](int f) { return f < 6 ? 8 + f : 2 * MR + 8 + (f - 6); };
                 if (wave < 4) {
@@ -1140,7 +1157,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
                 }
             }
         }
-        const int n_hi = (MR == 8 || wave < 4) ? 2 : 1;
+        const int n_hi = (MR == 8 || (MR == 7 && wave < 4)) ? 2 : 1;
         // K-tile 0 landed; for every tile but the first this also retires the previous epilogue's stores,
         // which had that epilogue and these address computations to drain
         PPSTAMP(0);
@@ -1827,6 +1844,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_s3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
         HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_dw_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS));
@@ -1895,30 +1913,43 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             gemm_pp2_kernel<EPI><<<tiles_m * tiles_n, 512, LDS_BYTES, s>>>(a, tiles_m, tiles_n);
         }
         else if (variant == 1) {
-            // 256- or 224-row tiles, whichever needs fewer (size-weighted) rounds over the CUs
+            // 256-, 224- or 192-row tiles, whichever needs fewer (size-weighted) rounds over the CUs
             const int cus = cus_dev;
-            static const bool allow224 = !(getenv("HIPTS_GEMM_BM") && strcmp(getenv("HIPTS_GEMM_BM"), "256") == 0);
-            const int tiles_m7 = (a.M + 223) / 224;
-            const long r8 = ((long)tiles_m * tiles_n + cus - 1) / cus * 256;
-            const long r7 = ((long)tiles_m7 * tiles_n + cus - 1) / cus * 224;
+            static const int min_mr = !getenv("HIPTS_GEMM_BM") ? 6 : strcmp(getenv("HIPTS_GEMM_BM"), "256") == 0 ? 8 : strcmp(getenv("HIPTS_GEMM_BM"), "224") == 0 ? 7 : 6;
+            auto tiles_of = [&](int mr) { return (a.M + 32 * mr - 1) / (32 * mr); };
+            auto cost_of = [&](int mr) { return ((long)tiles_of(mr) * tiles_n + cus - 1) / cus * (32 * mr); };
             // measured (r01): the switch pays when the predicted saving is large (N = 768: 2.625 vs 3 rounds,
             // -4..6 %) and costs 3 % when it is marginal (N = 3072: 9.6 vs 10) -- smaller tiles re-read W more.
             // ... and only when the launch has the chip to itself: with sub-batches on several streams the
-            // partial last round is filled by the other stream's kernel and full tiles win (4.50 -> 4.59 k img/s)
-            const bool use7 = allow224 && !a.shared_chip && r7 * 100 < r8 * 93;
+            // partial last round is filled by the other stream's kernel and full tiles win (4.50 -> 4.59 k img/s).
+            // 192 rows (round 3, half operands only): EVA02-L at the reference's batch of 10 -- 10 250 rows x 1024 columns are 164
+            // tiles of 256 rows on 256 CUs (one round, 64 % of the chip) but 216 tiles of 192 rows (one round of 3/4 the length).
+            int mr = 8;
+            if (!a.shared_chip) {
+                long best = cost_of(8) * 93;
+                for (int c = 7; c >= (a.f16 ? min_mr : (min_mr > 7 ? min_mr : 7)); --c)
+                    if (cost_of(c) * 100 < best) {
+                        best = cost_of(c) * 100;
+                        mr = c;
+                    }
+            }
+            const int tiles_mr = tiles_of(mr);
             // persistent grid: one workgroup per CU (a multiple of 8 so that a workgroup's tiles keep their XCD)
             static const bool persist = !(getenv("HIPTS_GEMM_PERSIST") && strcmp(getenv("HIPTS_GEMM_PERSIST"), "0") == 0);
-            const int ntile = (use7 ? tiles_m7 : tiles_m) * tiles_n;
+            const int ntile = tiles_mr * tiles_n;
             const int slots = cus >= 8 ? cus / 8 * 8 : cus;
             const int grid = (persist && ntile > slots) ? slots : ntile;
             static const int raster = getenv("HIPTS_GEMM_RASTER") ? atoi(getenv("HIPTS_GEMM_RASTER")) : 8;      // measured: 8 +0.4..0.8 % on the ViT forward, 4 / 16 +-0
+            static const int raster_gn = getenv("HIPTS_GEMM_RASTER_GN") ? atoi(getenv("HIPTS_GEMM_RASTER_GN")) : 6;      // measured (r03): fc1 fetches 251 -> 207 MB, q|k|v 194 -> 167 MB per launch, images/s +-0; 0 = off
             GemmArgs ar = a;
             ar.raster_gm = (raster > 0 && tiles_n >= 8) ? raster : 0;
+            ar.raster_gn = (raster_gn > 0 && tiles_n >= 8 && tiles_n > raster_gn) ? raster_gn : 0;
             if (a.f16) {
-                if (use7) gemm_pp_kernel<EPI, 7, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m7, tiles_n);
+                if (mr == 6) gemm_pp_kernel<EPI, 6, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_mr, tiles_n);
+                else if (mr == 7) gemm_pp_kernel<EPI, 7, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_mr, tiles_n);
                 else gemm_pp_kernel<EPI, 8, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
             } else {
-                if (use7) gemm_pp_kernel<EPI, 7, false><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m7, tiles_n);
+                if (mr == 7) gemm_pp_kernel<EPI, 7, false><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_mr, tiles_n);
                 else gemm_pp_kernel<EPI, 8, false><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
             }
         }

@@ -258,6 +258,7 @@ struct GemmArgs {
     int op8 = 0;                    // A and W are e4m3 bytes (K counts elements, K % 128 == 0; W holds W * 2^w_exp); 16-bit outputs are half
     int w_exp = 0;                  // op8: the weight scale exponent
     int out8 = 0;                   // STAR / RESID_LN: the 16-bit output (out_bf16) is written as e4m3 bytes instead (ld_out in bytes)
+    int raster_gn = 0;                      // > 0: column groups of this many column tiles outermost, row-major inside (set by the launcher)
     int raster_gm = 0;                      // > 0: tile order in groups of this many row panels, column-major inside (set by the launcher)
     int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
     int trace = 0;                          // diagnostic: per-workgroup timeline records instead of stamps (dw loop)
