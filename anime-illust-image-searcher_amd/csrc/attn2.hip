@@ -34,6 +34,9 @@ namespace {
 constexpr int KV = 64;                   // keys per tile
 constexpr int HD = 64;
 constexpr int TILE = KV * HD * 2;        // 8 KiB
+#ifndef HIPTS_ATTN2_SEQ_SLOTS
+#define HIPTS_ATTN2_SEQ_SLOTS 2
+#endif
 constexpr int NSK = 3, NSV = 3;          // ring slots: K two tiles ahead, V one (its tile t - 1 is still being multiplied during step t)
 constexpr int V_BASE = NSK * TILE;
 constexpr int LDS_BYTES = (NSK + NSV) * TILE;      // 48 KiB: three workgroups per CU
@@ -316,7 +319,8 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
                                                const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
                                                int bh, int blk0, int nblk, int out_stride) {
     constexpr int PCS = 8 / NW;
-    constexpr int VB = 2 * TILE;                     // V slots behind the two K slots
+    constexpr int SNS = HIPTS_ATTN2_SEQ_SLOTS;       // ring slots per operand: 2 = one tile in flight, 3 = two
+    constexpr int VB = SNS * TILE;                   // V slots behind the K slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: LDS-DMA bases and the active test stay scalar
     const int r = lane & 31, h = lane >> 5;
@@ -338,7 +342,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     const bf16_t* kb = k + (size_t)bh * tokens_pad * HD;
     const bf16_t* vb = v + (size_t)bh * tokens_pad * HD;
     auto stage = [&](int t) __attribute__((always_inline)) {
-        const int sl = (t & 1) * TILE;
+        const int sl = (t % SNS) * TILE;
 #pragma unroll
         for (int pc = 0; pc < PCS; ++pc) glds16(kb + (size_t)t * (KV * HD) + kgo[pc], smem + sl + (wave + NW * pc) * 1024);
 #pragma unroll
@@ -353,6 +357,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
     stage(0);
+    if (SNS == 3 && nkv > 1) stage(1);
     int ka[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) ka[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) * 16);
@@ -443,7 +448,9 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     auto step = [&](int t, auto first_c, auto last_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_c)::value;
         HIPTS_STAMP(t * 16 + 0);
-        wait_vm<0>();                                // tile t (requested one step ago) has landed for this wave ...
+        // tile t (requested SNS - 1 steps ago) has landed for this wave; with three slots tile t + 1's pieces stay in flight ...
+        if (SNS == 3 && t + 1 < nkv) wait_vm<2 * PCS>();
+        else wait_vm<0>();
         HIPTS_STAMP(t * 16 + 5);
 #ifndef HIPTS_X_NOBARRIER                            // (HIPTS_X_*: measurement-only builds, tools/gpurun/r3_attn_x.sh -- results are wrong with them)
         __builtin_amdgcn_s_barrier();                // ... and for every wave; tile t - 1's slots are free
@@ -452,10 +459,11 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 #ifdef HIPTS_X_NODMA
         if (t == 0)
 #endif
-        if (t + 1 < nkv) stage(t + 1);
+        if (t + SNS - 1 < nkv) stage(t + SNS - 1);
         if (!active) return;
         HIPTS_STAMP(t * 16 + 1);
-        const int sl = (t & 1) * TILE;
+        int sl = (t % SNS) * TILE;
+        if (SNS == 3) asm volatile("" : "+s"(sl));      // a per-step scalar: three hoisted sets of LDS addresses would not fit the register budget
         const bool two = !(LAST && tail_keys <= 32);
         bf16x8 kf0[4], kf1[4], vf[2][2], w0, w1;
         f32x16 sacc;
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) voi
     // ALL of the kernel's LDS is this one array (ring + the fallback flag word): with a second LDS object in the kernel -- __syncthreads_or()
     // brings one -- hipcc puts an s_waitcnt vmcnt(0) in front of the first ds_read of every tile step and the DMA ring never runs ahead
     // (cdna_hip_programming.md section 5, "three .s-level traps" (a); seen in this kernel's .s).
-    constexpr int RING = MODE == 1 ? 4 * TILE : LDS_BYTES;
+    constexpr int RING = MODE == 1 ? 2 * HIPTS_ATTN2_SEQ_SLOTS * TILE : LDS_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[RING + 16];
     int* redo = reinterpret_cast<int*>(smem + RING);
     if (threadIdx.x == 0) *redo = classic;           // ordered before every reader by the barriers of the tile loop

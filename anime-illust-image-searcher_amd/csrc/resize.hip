@@ -9,6 +9,7 @@
 // multiply-adds), cached per (source size, output size, filter) and handed to two small kernels: the decode workers then only decode.
 #include <cmath>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -137,6 +138,7 @@ struct ResizeState {
     std::mutex mu;
     std::map<std::tuple<int, int, int, int>, DevCoeffs*> cache;      // (device, in, out, filter)
     DevBuf stage[64], tmp[64];                                         // per device: host-source staging, horizontal-pass temporary
+    hipEvent_t last[64] = {};                                          // per device: end of the last call that used tmp (callers may be on different streams)
 };
 ResizeState& state() {
     static ResizeState* s = new ResizeState;       // never destroyed: see scratch_buf() in query.hip
@@ -149,7 +151,7 @@ int get_coeffs(int device, int in, int out, int filter, DevCoeffs** res) {
     auto it = st.cache.find(key);
     if (it == st.cache.end()) {
         const Coeffs c = precompute(in, out, filter);
-        DevCoeffs* d = new DevCoeffs;
+        std::unique_ptr<DevCoeffs> d(new DevCoeffs);
         d->ksize = c.ksize;
         d->first = c.bounds[0];
         d->last = c.bounds[(size_t)out * 2 - 2] + c.bounds[(size_t)out * 2 - 1];
@@ -157,7 +159,7 @@ int get_coeffs(int device, int in, int out, int filter, DevCoeffs** res) {
         HIPTS_TRY(d->kk.alloc(c.kk.size() * 4));
         HIPTS_TRY(upload(d->bounds.p, c.bounds.data(), c.bounds.size() * 4));
         HIPTS_TRY(upload(d->kk.p, c.kk.data(), c.kk.size() * 4));
-        it = st.cache.emplace(key, d).first;
+        it = st.cache.emplace(key, d.release()).first;
     }
     *res = it->second;
     return HIPTS_OK;
@@ -197,11 +199,16 @@ extern "C" int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, 
     const int y0 = need_v ? cv->first : 0, y1 = need_v ? cv->last : src_h;
     const uint8_t* vin = sp;
     int vin_w = src_w, v_y0 = 0;
+    bool used_tmp = false;
     if (need_h) {
         uint8_t* out_h = dst_device;
         if (need_v) {
+            // the temporary is shared by every caller of this device: order this call behind the last one that used it
+            if (st.last[device]) HIPTS_HIP(hipStreamWaitEvent(s, st.last[device], 0));
+            else HIPTS_HIP(hipEventCreateWithFlags(&st.last[device], hipEventDisableTiming));
             HIPTS_TRY(st.tmp[device].reserve((size_t)(y1 - y0) * dst_w * 3));
             out_h = st.tmp[device].as<uint8_t>();
+            used_tmp = true;
         }
         const int total = (y1 - y0) * dst_w;
         resample_h_kernel<<<(total + 255) / 256, 256, 0, s>>>(sp, src_w, out_h, dst_w, y0, y1 - y0, ch->bounds.as<int>(), ch->kk.as<int>(), ch->ksize);
@@ -215,6 +222,7 @@ extern "C" int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, 
         resample_v_kernel<<<(total + 255) / 256, 256, 0, s>>>(vin, vin_w, dst_device, dst_h, v_y0, cv->bounds.as<int>(), cv->kk.as<int>(), cv->ksize);
         HIPTS_LAUNCH_CHECK();
     }
+    if (used_tmp) HIPTS_HIP(hipEventRecord(st.last[device], s));
     if (src_memspace != HIPTS_DEVICE) HIPTS_HIP(hipStreamSynchronize(s));       // the staging buffer is reused by the next call
     return HIPTS_OK;
 }

@@ -1102,6 +1102,7 @@ extern "C" int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, co
     HIPTS_TRY(upload(W.p, w_bf16, (size_t)N * K * 2));
     GemmArgs g{};
     g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>(); g.out_f32 = out.as<float>();
+    g.f16 = getenv("HIPTS_DBG_GEMM_F16") ? 1 : 0;       // the 16-bit patterns are IEEE half (tests/test_gpu_gemm.py: the 192-row tiles exist for half operands only)
     HIPTS_TRY(launch_gemm(EPI_RESID, g, nullptr));
     HIPTS_HIP(hipMemcpy(out_host, out.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return HIPTS_OK;

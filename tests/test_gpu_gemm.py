@@ -63,6 +63,25 @@ def test_gemm_default_dispatch_persistent_and_underfilled():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_gemm_half_operands_and_tile_heights():
+    """IEEE-half operands (the product default) through the persistent loop at each tile height the launcher picks:
+    (10250, 1024, 1024) = EVA02-L's proj at the reference batch of 10 -> 192-row tiles (216 tiles, one round);
+    (50176, 768, 768) -> 224 rows; (66000, 1024, 320) -> 256 rows; (1025, 1024, 1024) one ragged round of 192."""
+    env = {k: v for k, v in os.environ.items() if k != "HIPTS_GEMM"}
+    env["HIPTS_DBG_GEMM_F16"] = "1"
+    code = _CHILD % {"pkg": os.path.join(ROOT, "anime-illust-image-searcher_amd"),
+                     "shapes": [(10250, 1024, 1024), (50176, 768, 768), (66000, 1024, 320), (1025, 1024, 1024), (10250, 1024, 2752)]}
+    code = code.replace("a = synth.round_to_bf16(rng.standard_normal((M, K)).astype(np.float32))",
+                        "a = rng.standard_normal((M, K)).astype(np.float16).astype(np.float32)")
+    code = code.replace("w = synth.round_to_bf16((rng.standard_normal((N, K)) * 0.05).astype(np.float32))",
+                        "w = (rng.standard_normal((N, K)) * 0.05).astype(np.float16).astype(np.float32)")
+    code = code.replace("a16 = (a.view(np.uint32) >> 16).astype(np.uint16); w16 = (w.view(np.uint32) >> 16).astype(np.uint16)",
+                        "a16 = a.astype(np.float16).view(np.uint16); w16 = w.astype(np.float16).view(np.uint16)")
+    assert "np.float16" in code and "round_to_bf16" not in code
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_forward_is_deterministic_and_batch_invariant():
     from hiptagsearch import synth
     from hiptagsearch.tagger import ViTTagger
