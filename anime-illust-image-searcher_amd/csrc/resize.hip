@@ -114,6 +114,31 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
     o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
 }
 
+// The same pass over an image that sits at (top, left) inside a white canvas (Predictor.prepare_image's centred padding, tagging.py:100-120):
+// canvas row y0 + y, canvas columns xmin ..; pixels outside the image are 255.
+__global__ __launch_bounds__(256) void resample_h_pad_kernel(const uint8_t* __restrict__ src, int img_h, int img_w, int top, int left, uint8_t* __restrict__ tmp,
+                                                             int out_w, int y0, int rows, const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * out_w) return;
+    const int y = i / out_w, xx = i - y * out_w;
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int* k = kk + (size_t)xx * ksize;
+    const int sy = y0 + y - top;
+    const bool row_in = sy >= 0 && sy < img_h;
+    const uint8_t* p = src + (size_t)(row_in ? sy : 0) * img_w * 3;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < n; ++x) {
+        const int w = k[x];
+        const int sx = xmin + x - left;
+        const bool in = row_in && sx >= 0 && sx < img_w;
+        s0 += (in ? p[3 * sx] : 255) * w;
+        s1 += (in ? p[3 * sx + 1] : 255) * w;
+        s2 += (in ? p[3 * sx + 2] : 255) * w;
+    }
+    uint8_t* o = tmp + (size_t)i * 3;
+    o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+}
+
 // dst[yy][x][c] = clip8(2^21 + sum_y tmp[ymin - y0 + y][x][c] * k[yy][y])
 __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restrict__ tmp, int w, uint8_t* __restrict__ dst, int out_h, int y0,
                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
@@ -138,6 +163,7 @@ struct ResizeState {
     std::mutex mu;
     std::map<std::tuple<int, int, int, int>, DevCoeffs*> cache;      // (device, in, out, filter)
     DevBuf stage[64], tmp[64];                                         // per device: host-source staging, horizontal-pass temporary
+    DevBuf bstage[64];                                                 // per device: the batch entry's staging of host images
     hipEvent_t last[64] = {};                                          // per device: end of the last call that used tmp (callers may be on different streams)
 };
 ResizeState& state() {
@@ -224,5 +250,71 @@ extern "C" int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, 
     }
     if (used_tmp) HIPTS_HIP(hipEventRecord(st.last[device], s));
     if (src_memspace != HIPTS_DEVICE) HIPTS_HIP(hipStreamSynchronize(s));       // the staging buffer is reused by the next call
+    return HIPTS_OK;
+}
+
+
+// A batch of decoded images of different sizes -> uint8 [n][size][size][3]: image i is h x w (hw[2 i], hw[2 i + 1]) at src_base + i * slot_stride
+// (a ring slot of hiptagsearch/pipeline.py's decode-only workers).  pad_square != 0: centred on a white max(h, w) square first (the tagger's
+// prepare_image), then Resize(bicubic / bilinear) as hipts_resize_u8.  Host sources are copied with hipMemcpyAsync (asynchronous when the
+// caller has registered the ring as pinned memory); everything is ordered on `stream`, nothing is synchronised.
+extern "C" int hipts_resize_batch_u8(const uint8_t* src_base, int src_memspace, int64_t slot_stride, const int32_t* hw, int n, int pad_square,
+                                     uint8_t* dst_device, int size, int filter, int device, void* stream) {
+    HIPTS_REQUIRE(src_base && hw && dst_device && n >= 1 && size >= 1 && slot_stride >= 1, "hipts_resize_batch_u8: bad arguments");
+    HIPTS_REQUIRE(filter == 2 || filter == 3, "hipts_resize_batch_u8: filter must be 2 (PIL BILINEAR) or 3 (PIL BICUBIC)");
+    HIPTS_REQUIRE(device >= 0 && device < 64, "hipts_resize_batch_u8: device index");
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        HIPTS_REQUIRE(hw[2 * i] >= 1 && hw[2 * i + 1] >= 1 && (int64_t)hw[2 * i] * hw[2 * i + 1] * 3 <= slot_stride,
+                      "hipts_resize_batch_u8: image %d is %d x %d, slot stride %lld", i, hw[2 * i], hw[2 * i + 1], (long long)slot_stride);
+        total += ((size_t)hw[2 * i] * hw[2 * i + 1] * 3 + 255) / 256 * 256;
+    }
+    HIPTS_TRY(use_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    ResizeState& st = state();
+    std::lock_guard<std::mutex> lock(st.mu);
+    // staging and temporary are shared by every caller of this device: order this call behind the last one that used them
+    if (st.last[device]) HIPTS_HIP(hipStreamWaitEvent(s, st.last[device], 0));
+    else HIPTS_HIP(hipEventCreateWithFlags(&st.last[device], hipEventDisableTiming));
+    const bool host = src_memspace != HIPTS_DEVICE;
+    if (host) HIPTS_TRY(st.bstage[device].reserve(total));
+    {   // the temporary of the tallest canvas, reserved once (growing it between launches would free memory that kernels in flight still read)
+        int max_ch = 1;
+        for (int i = 0; i < n; ++i) {
+            const int h = hw[2 * i], w = hw[2 * i + 1];
+            const int ch = pad_square ? (h > w ? h : w) : h;
+            max_ch = ch > max_ch ? ch : max_ch;
+        }
+        HIPTS_TRY(st.tmp[device].reserve((size_t)max_ch * size * 3));
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        const size_t bytes = (size_t)h * w * 3;
+        const uint8_t* sp = src_base + (size_t)i * slot_stride;
+        if (host) {
+            uint8_t* d = st.bstage[device].as<uint8_t>() + off;
+            HIPTS_HIP(hipMemcpyAsync(d, sp, bytes, hipMemcpyHostToDevice, s));
+            sp = d;
+            off += (bytes + 255) / 256 * 256;
+        }
+        const int m = pad_square ? (h > w ? h : w) : 0;
+        const int ch = pad_square ? m : h, cw = pad_square ? m : w;                 // canvas
+        const int top = pad_square ? (m - h) / 2 : 0, left = pad_square ? (m - w) / 2 : 0;
+        DevCoeffs *chz = nullptr, *cvt = nullptr;
+        HIPTS_TRY(get_coeffs(device, cw, size, filter, &chz));
+        HIPTS_TRY(get_coeffs(device, ch, size, filter, &cvt));
+        const int y0 = cvt->first, y1 = cvt->last;
+        uint8_t* t = st.tmp[device].as<uint8_t>();
+        const int total_h = (y1 - y0) * size;
+        resample_h_pad_kernel<<<(total_h + 255) / 256, 256, 0, s>>>(sp, h, w, top, left, t, size, y0, y1 - y0, chz->bounds.as<int>(), chz->kk.as<int>(),
+                                                                    chz->ksize);
+        HIPTS_LAUNCH_CHECK();
+        const int total_v = size * size;
+        resample_v_kernel<<<(total_v + 255) / 256, 256, 0, s>>>(t, size, dst_device + (size_t)i * size * size * 3, size, y0, cvt->bounds.as<int>(),
+                                                                cvt->kk.as<int>(), cvt->ksize);
+        HIPTS_LAUNCH_CHECK();
+    }
+    HIPTS_HIP(hipEventRecord(st.last[device], s));
     return HIPTS_OK;
 }

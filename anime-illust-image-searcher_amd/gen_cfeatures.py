@@ -176,7 +176,8 @@ def main(arg_str: list) -> None:
             progress(len(paths))
         if args.workers > 0:
             from hiptagsearch import pipeline
-            with pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP) as dpool:
+            with pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP, device_resize=args.gpu_resize,
+                                     device=device) as dpool:
                 for kept, images in dpool.batches(file_list):
                     add(kept, encoder.forward_u8(images))                               # /255 and the CLIP normalisation on the device
         else:

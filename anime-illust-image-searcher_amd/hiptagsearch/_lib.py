@@ -95,6 +95,7 @@ _SIGNATURES = {
     "hipts_topk": [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "hipts_synth_images_u8": [c_void_p, c_int64, c_int64, c_int, ctypes.c_uint64, c_int, c_void_p],
     "hipts_resize_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "hipts_resize_batch_u8": [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "hipts_ccip_metric": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "hipts_comm_unique_id": [c_void_p, c_size_t],
     "hipts_comm_create": [c_void_p, c_size_t, c_int, c_int, c_int, POINTER(c_void_p)],

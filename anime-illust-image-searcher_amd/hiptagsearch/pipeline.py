@@ -13,6 +13,12 @@ resize on the host, which the reference does on 8 threads inside the GIL (taggin
   iter_shards    format: `shard-00000.npy` = uint8 [n,S,S,3] (memory-mappable) + `shard-00000.txt` = one path per
                  row; the reference stores one float32 torch tensor file per image (2.4 MB each, 4x the bytes).
 
+  DecodePool(device_resize=True)   the workers only decode and composite: the image goes into its ring slot at its own size and the
+                 consumer pads (tagger) and resizes it on the device with the Pillow-exact kernel (`hipts_resize_u8`), yielding
+                 uint8 [B,S,S,3] CUDA tensors.  Decode alone is ~3.5x cheaper than decode + resize per core (bench.py
+                 `input_pipeline`), so N workers feed ~3.5x the images; the ring is registered as pinned memory so the copies
+                 are asynchronous DMA.  Images larger than a slot (`max_pixels`) are resized by the worker as before.
+
 Workers are started with the `forkserver` method so that no child is forked from a process that holds a GPU
 context; create the pool before or after the model, either is safe.
 """
@@ -27,8 +33,9 @@ TAGGER = "tagger"      # white composite, centred pad to square, bicubic resize 
 CCIP = "ccip"          # white composite, bilinear resize (gen_cfeatures.py:285-295, 106)
 
 
-def decode_image(path: str, size: int, mode: str = TAGGER) -> Optional[np.ndarray]:
-    """One image file -> uint8 [size,size,3] RGB, or None (error printed, like the reference's per-file handler)."""
+def decode_image(path: str, size: int, mode: str = TAGGER, raw_max_pixels: int = 0) -> Optional[np.ndarray]:
+    """One image file -> uint8 [size,size,3] RGB, or None (error printed, like the reference's per-file handler).
+    raw_max_pixels > 0: an image of at most that many pixels is returned composited but neither padded nor resized ([h,w,3])."""
     from PIL import Image
     img = None
     try:
@@ -38,8 +45,12 @@ def decode_image(path: str, size: int, mode: str = TAGGER) -> Optional[np.ndarra
             bg = Image.new("RGB", img.size, (255, 255, 255))
             bg.paste(img, mask=img.split()[-1])
             img = bg
+        elif raw_max_pixels > 0 and img.mode == "RGB":
+            pass                                         # already what the composite would produce: no extra copies in the decode-only worker
         else:
             img = img.copy().convert("RGB") if mode == TAGGER else img.convert("RGB")
+        if raw_max_pixels > 0 and img.size[0] * img.size[1] <= raw_max_pixels:
+            return np.asarray(img, dtype=np.uint8)
         if mode == TAGGER:
             w, h = img.size
             m = max(w, h)
@@ -61,19 +72,27 @@ def decode_image(path: str, size: int, mode: str = TAGGER) -> Optional[np.ndarra
 _W = {}
 
 
-def _worker_init(shm_name: str, slots: int, size: int, mode: str) -> None:
+def _worker_init(shm_name: str, slots: int, size: int, mode: str, raw_max_pixels: int = 0) -> None:
     shm = shared_memory.SharedMemory(name=shm_name)
     _W["shm"] = shm
-    _W["ring"] = np.ndarray((slots, size, size, 3), dtype=np.uint8, buffer=shm.buf)
+    if raw_max_pixels > 0:
+        _W["ring"] = np.ndarray((slots, max(raw_max_pixels, size * size) * 3), dtype=np.uint8, buffer=shm.buf)
+    else:
+        _W["ring"] = np.ndarray((slots, size, size, 3), dtype=np.uint8, buffer=shm.buf)
     _W["size"] = size
     _W["mode"] = mode
+    _W["raw"] = raw_max_pixels
 
 
-def _worker_decode(task: Tuple[int, str]) -> bool:
+def _worker_decode(task: Tuple[int, str]):
+    """-> False (decode failed), True (model-input image in the slot) or (h, w) (raw mode: the composited image at its own size)."""
     slot, path = task
-    a = decode_image(path, _W["size"], _W["mode"])
+    a = decode_image(path, _W["size"], _W["mode"], _W["raw"])
     if a is None:
         return False
+    if _W["raw"] > 0:
+        _W["ring"][slot, :a.size] = a.reshape(-1)
+        return (int(a.shape[0]), int(a.shape[1]))
     _W["ring"][slot] = a
     return True
 
@@ -87,18 +106,48 @@ class DecodePool:
 
     Files that fail to decode are dropped from `paths` (message printed by the worker), like the reference."""
 
-    def __init__(self, workers: Optional[int] = None, size: int = 448, batch: int = 64, mode: str = TAGGER):
+    def __init__(self, workers: Optional[int] = None, size: int = 448, batch: int = 64, mode: str = TAGGER,
+                 device_resize: bool = False, device: int = 0, max_pixels: int = 1600 * 1600):
         self.workers = max(1, workers or (os.cpu_count() or 1))
         self.size, self.batch, self.mode = size, batch, mode
         self.slots = 2 * batch
-        self._shm = shared_memory.SharedMemory(create=True, size=self.slots * size * size * 3)
-        self._ring = np.ndarray((self.slots, size, size, 3), dtype=np.uint8, buffer=self._shm.buf)
+        self.raw = max(int(max_pixels), size * size) if device_resize else 0
+        self.device = device
+        self._pinned = False
+        self._events = [None, None]
+        slot_bytes = self.raw * 3 if self.raw else size * size * 3
+        self._shm = shared_memory.SharedMemory(create=True, size=self.slots * slot_bytes)
+        if self.raw:
+            self._ring = np.ndarray((self.slots, slot_bytes), dtype=np.uint8, buffer=self._shm.buf)
+            import torch
+            try:    # pinned ring: the per-image copies become asynchronous DMA (without it they are staged copies -- slower, still correct)
+                self._pinned = int(torch.cuda.cudart().cudaHostRegister(self._ring.ctypes.data, self._ring.nbytes, 0)) == 0
+            except Exception:
+                self._pinned = False
+        else:
+            self._ring = np.ndarray((self.slots, size, size, 3), dtype=np.uint8, buffer=self._shm.buf)
         ctx = mp.get_context("forkserver")
-        self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self._shm.name, self.slots, size, mode))
+        self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self._shm.name, self.slots, size, mode, self.raw))
+
+    def _to_device(self, base: int, results, stream) -> "object":
+        """Raw mode: the ring slots base .. of one decoded batch -> uint8 [n,S,S,3] CUDA tensor on `stream`: copied, padded (tagger: white,
+        centred -- prepare_image, tagging.py:100-120) and resized (bicubic for the tagger's transform, bilinear for gen_cfeatures.py:101) by
+        one library call (hipts_resize_batch_u8); nothing waits for the device."""
+        import torch
+        from . import _lib
+        S = self.size
+        out = torch.empty((len(results), S, S, 3), dtype=torch.uint8, device="cuda:%d" % self.device)
+        hw = np.ascontiguousarray(np.asarray(results, dtype=np.int32).reshape(-1, 2))
+        _lib.call("hipts_resize_batch_u8", self._ring[base].ctypes.data, _lib.HOST, self._ring.shape[1], _lib.ptr(hw), len(results),
+                  1 if self.mode == TAGGER else 0, _lib.ptr(out), S, 3 if self.mode == TAGGER else 2, self.device, stream.cuda_stream)
+        return out
 
     def batches(self, paths: Sequence[str]) -> Iterator[Tuple[List[str], np.ndarray]]:
         chunks = [list(paths[i:i + self.batch]) for i in range(0, len(paths), self.batch)]
         if not chunks:
+            return
+        if self.raw:
+            yield from self._batches_raw(chunks)
             return
 
         def submit(k: int):
@@ -119,7 +168,82 @@ class DecodePool:
                 if keep:
                     yield [chunk[i] for i in keep], np.ascontiguousarray(view[keep])
 
+    def _batches_raw(self, chunks):
+        """decode (worker processes, batch k + 2)  ||  copy + pad + resize (this producer thread, its own stream, batch k + 1)  ||  the
+        consumer's forward (caller's stream, batch k).  The hand-over is a queue of (paths, tensor, event)."""
+        import queue
+        import threading
+        import torch
+        q: "queue.Queue" = queue.Queue(maxsize=2)
+        stop = threading.Event()
+
+        def submit(k: int):
+            base = (k & 1) * self.batch
+            if self._events[k & 1] is not None:
+                self._events[k & 1].synchronize()       # the copies out of this half of the ring (batch k - 2) are done
+            return self._pool.map_async(_worker_decode, [(base + i, p) for i, p in enumerate(chunks[k])],
+                                        chunksize=max(1, len(chunks[k]) // (4 * self.workers)))
+
+        def produce():
+            try:
+                with torch.cuda.device(self.device):
+                    side = torch.cuda.Stream()
+                    pending = submit(0)
+                    for k, chunk in enumerate(chunks):
+                        res = pending.get()
+                        if k + 1 < len(chunks):
+                            pending = submit(k + 1)
+                        if stop.is_set():
+                            return
+                        keep = [i for i, r in enumerate(res) if r is not False]
+                        if not keep:
+                            continue
+                        base = (k & 1) * self.batch
+                        with torch.cuda.stream(side):
+                            if len(keep) == len(chunk):
+                                out = self._to_device(base, res, side)
+                            else:       # failed decodes leave holes: slot by slot
+                                out = torch.cat([self._to_device(base + i, [res[i]], side) for i in keep])
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                        self._events[k & 1] = ev
+                        q.put(([chunk[i] for i in keep], out, ev))
+                q.put(None)
+            except BaseException as e:      # hand the error to the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="hipts-decode-producer", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                kept, out, ev = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                out.record_stream(cur)
+                yield kept, out
+        finally:
+            stop.set()
+            while th.is_alive():            # unblock a producer that waits on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
+
     def close(self) -> None:
+        if getattr(self, "_pinned", False):
+            try:
+                import torch
+                torch.cuda.synchronize()
+                torch.cuda.cudart().cudaHostUnregister(self._ring.ctypes.data)
+            except Exception:
+                pass
+            self._pinned = False
         if self._pool is not None:
             self._pool.terminate()
             self._pool.join()

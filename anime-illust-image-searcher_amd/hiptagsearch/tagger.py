@@ -314,7 +314,7 @@ class Predictor:
         packed = isinstance(tensors, np.ndarray) and tensors.dtype == np.uint8 and tensors.ndim == 4      # [B,S,S,3] from the decode pool / shards
         for s in range(0, len(tensors), self.max_batch):
             chunk = tensors[s:s + self.max_batch]
-            if packed:
+            if packed or (hasattr(tensors, "is_cuda") and tensors.is_cuda and tensors.dim() == 4):      # ... or [B,S,S,3] on the device (decode pool with device resize)
                 _, probs = self.tagger_model.forward_u8(chunk, want="probs")
             elif hasattr(first, "is_cuda") and first.is_cuda:                     # uint8 [S,S,3] device tensors (gpu_resize)
                 import torch
@@ -421,7 +421,7 @@ class Predictor:
             from . import pipeline
             mine = file_list[lo:hi]
             where = {p: i for i, p in enumerate(mine)}
-            pool = pipeline.DecodePool(workers, size, bs, pipeline.TAGGER)
+            pool = pipeline.DecodePool(workers, size, bs, pipeline.TAGGER, device_resize=self.gpu_resize, device=self.device)
             def batches():
                 for kept, images in pool.batches(mine):
                     yield [where[p] for p in kept], images
@@ -522,7 +522,8 @@ class Predictor:
             if shards:
                 source = pipeline.iter_shards(shards, min(batch_size, self.max_batch))
             else:
-                pool = pipeline.DecodePool(workers, size, min(batch_size, self.max_batch), pipeline.TAGGER)
+                pool = pipeline.DecodePool(workers, size, min(batch_size, self.max_batch), pipeline.TAGGER, device_resize=self.gpu_resize,
+                                           device=self.device)
                 source = pool.batches(file_list)
             try:
                 for kept, images in source:

@@ -33,7 +33,8 @@ def main(arg_str: list) -> None:
     parser.add_argument('--write-shards', default=None, help='decode --dir once into packed uint8 shards in this directory and exit')
     parser.add_argument('--shards', default=None, help='tag the pre-decoded shards in this directory (written by --write-shards)')
     parser.add_argument('--gpu-resize', action='store_true',
-                        help='decode threads only decode and pad; the Resize(bicubic) of the transform runs on the device (Pillow-exact kernel)')
+                        help='decode threads (or the --workers processes) only decode; padding and the Resize(bicubic) of the transform run on the '
+                             'device (Pillow-exact kernel)')
     parser.add_argument('--synthetic', type=int, default=0, metavar='N',
                         help='tag N images of the synthetic benchmark corpus generated on the device (BASELINE.json configs[3]; --dir is ignored)')
     parser.add_argument('--device', type=int, default=0)

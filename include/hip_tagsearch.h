@@ -209,6 +209,15 @@ int hipts_ccip_flops_per_image(const hipts_ccip_t* h, double* flops);
 int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, int src_w, uint8_t* dst_device, int dst_h, int dst_w, int filter,
                     int device, void* stream);
 
+/* A batch of decoded images of different sizes -> uint8 [n][size][size][3] on the device: image i is hw[2 i] x hw[2 i + 1] x 3 at
+ * src_base + i * slot_stride (host or device memory: the ring slots of the decode-only worker processes, hiptagsearch/pipeline.py).
+ * pad_square != 0: centred on a white max(h, w) square first -- Predictor.prepare_image, reference tagging.py:100-120 -- then the
+ * Resize of hipts_resize_u8 (filter 3: tagging.py:241's transform; filter 2, pad_square 0: gen_cfeatures.py:101).  Host images are
+ * copied with hipMemcpyAsync (register the ring as pinned memory for asynchronous DMA); all work is ordered on `stream`, the call does
+ * not synchronise: keep the source bytes unchanged until the stream has passed this point. */
+int hipts_resize_batch_u8(const uint8_t* src_base, int src_memspace, int64_t slot_stride, const int32_t* hw, int n, int pad_square,
+                          uint8_t* dst_device, int size, int filter, int device, void* stream);
+
 /* The synthetic image corpus of the benchmark configurations (BASELINE.json configs[3]: "1M synthetic images sharded
  * 8xMI355X"), generated on the device with no host I/O: images first_index .. first_index + count - 1 of the corpus `seed`, uint8
  * [count][image_size][image_size][3], every byte a counter-hash of (seed, GLOBAL image index, byte offset) -- so a rank produces its own

@@ -74,10 +74,45 @@ def test_tagging_cli_gpu_resize_writes_the_same_file(tmp_path):
     for i in range(13):
         Image.fromarray(rng.integers(0, 256, (120 + 17 * i, 200 - 9 * i, 3), dtype=np.uint8)).save(str(tmp_path / "imgs" / ("p%02d.png" % i)))
     outs = []
-    for extra in ([], ["--gpu-resize"]):
+    for extra in ([], ["--gpu-resize"], ["--gpu-resize", "--workers", "2"]):
         if os.path.exists(tmp_path / "tags-wd-tagger.txt"):
             os.remove(tmp_path / "tags-wd-tagger.txt")
         r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--model", "vit-tiny", "--batch", "8"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read())
-    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 13
+    assert outs[0] == outs[1] == outs[2] and len(outs[0].splitlines()) == 13
+
+
+@pytest.mark.parametrize("mode", ["tagger", "ccip"])
+def test_decode_pool_with_device_resize_yields_the_host_images(tmp_path, mode):
+    """pipeline.DecodePool(device_resize=True): the workers only decode and composite, the consumer pads and resizes on the device --
+    the same uint8 images as decode_image on the host, for RGB / RGBA / L / palette inputs, tall and wide and already-square ones, an
+    image larger than a ring slot (resized by the worker) and a file that does not decode (dropped)."""
+    from PIL import Image
+    from hiptagsearch import pipeline
+    rng = np.random.default_rng(11)
+    size = 448 if mode == "tagger" else 384
+    paths = []
+    def save(name, img):
+        p = str(tmp_path / name)
+        img.save(p)
+        paths.append(p)
+    save("a.png", Image.fromarray(rng.integers(0, 256, (300, 500, 3), dtype=np.uint8)))
+    save("b.png", Image.fromarray(rng.integers(0, 256, (520, 333, 4), dtype=np.uint8), "RGBA"))
+    save("c.png", Image.fromarray(rng.integers(0, 256, (size, size), dtype=np.uint8), "L"))
+    save("d.jpg", Image.fromarray(rng.integers(0, 256, (600, 800, 3), dtype=np.uint8)))
+    open(tmp_path / "e.png", "wb").write(b"not an image")
+    paths.append(str(tmp_path / "e.png"))
+    save("f.png", Image.fromarray(rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)).convert("P"))
+    save("g.png", Image.fromarray(rng.integers(0, 256, (900, 700, 3), dtype=np.uint8)))        # 630 000 pixels > max_pixels below
+    save("h.png", Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)))
+    want = {p: pipeline.decode_image(p, size, mode) for p in paths}
+    got = {}
+    with pipeline.DecodePool(workers=2, size=size, batch=3, mode=mode, device_resize=True, max_pixels=500_000) as pool:
+        for kept, images in pool.batches(paths):
+            assert images.is_cuda and tuple(images.shape[1:]) == (size, size, 3) and len(kept) == images.shape[0]
+            for p, img in zip(kept, images.cpu().numpy()):
+                got[p] = img
+    assert sorted(got) == sorted(p for p in paths if want[p] is not None) and len(got) == len(paths) - 1
+    for p in got:
+        np.testing.assert_array_equal(got[p], want[p], err_msg=p)
