@@ -3,6 +3,7 @@
 #include <cstdio>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int OP>
 __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* cyc) {
     float a[24];
@@ -18,6 +19,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
             if (OP == 3) p[i] = __builtin_elementwise_fma(p[i], f32x2{1.0001f, 1.0001f}, f32x2{0.5f, 0.5f});
             if (OP == 4) a[i] = fmaxf(fmaxf(a[i], a[i]), 0.25f);
             if (OP == 5) a[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p[i][0]), __builtin_bit_cast(bf16x2, p[(i + 1) % 24][1]), a[i], false);
+            if (OP == 7) a[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, p[i][0]), __builtin_bit_cast(f16x2, p[(i + 1) % 24][1]), a[i], false);
+            if (OP == 8) a[i] = __builtin_fmaf((float)__builtin_bit_cast(f16x2, p[i][0])[0], p[(i + 1) % 24][1], a[i]);      // v_fma_mix_f32
+            if (OP == 9) p[i][0] = __builtin_bit_cast(float, __builtin_elementwise_fma(__builtin_bit_cast(f16x2, p[i][0]), __builtin_bit_cast(f16x2, p[(i + 1) % 24][1]), __builtin_bit_cast(f16x2, p[i][1])));   // v_pk_fma_f16
             if (OP == 6) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, a[i]), __builtin_bit_cast(unsigned, a[(i + 1) % 24]), 0x05040100u));
         }
     }
@@ -29,15 +33,16 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
 }
 int main() {
     float* out; unsigned long long* cyc;
-    hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 64);
+    hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 128);
     const int iters = 4096;
-    const char* names[] = {"v_exp_f32", "v_rcp_f32", "v_fma_f32", "v_pk_fma_f32", "v_max3_f32", "v_dot2c_f32_bf16", "v_perm_b32"};
+    const char* names[] = {"v_exp_f32", "v_rcp_f32", "v_fma_f32", "v_pk_fma_f32", "v_max3_f32", "v_dot2c_f32_bf16", "v_perm_b32", "v_dot2_f32_f16", "v_fma_mix_f32", "v_pk_fma_f16"};
     for (int rep = 0; rep < 2; ++rep) {
         k<0><<<256, 256>>>(out, iters, cyc); k<1><<<256, 256>>>(out, iters, cyc); k<2><<<256, 256>>>(out, iters, cyc);
         k<3><<<256, 256>>>(out, iters, cyc); k<4><<<256, 256>>>(out, iters, cyc); k<5><<<256, 256>>>(out, iters, cyc); k<6><<<256, 256>>>(out, iters, cyc);
+        k<7><<<256, 256>>>(out, iters, cyc); k<8><<<256, 256>>>(out, iters, cyc); k<9><<<256, 256>>>(out, iters, cyc);
         hipDeviceSynchronize();
     }
-    unsigned long long h[8]; hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-    for (int i = 0; i < 7; ++i) printf("%-14s %.2f cycles per wave instruction (1 wave/SIMD)\n", names[i], (double)h[i] / (iters * 24.0));
+    unsigned long long h[16]; hipMemcpy(h, cyc, 128, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 10; ++i) printf("%-14s %.2f cycles per wave instruction (1 wave/SIMD)\n", names[i], (double)h[i] / (iters * 24.0));
     return 0;
 }
