@@ -395,6 +395,13 @@ __device__ void search1_state_debug(Search1State* st, uint32_t cnt, uint32_t fas
 constexpr int S1_BLOCK_CAP = 64;     // candidates one search1_collect_kernel workgroup (1024 documents) may hand on: at least this many (search_one sizes it)
 constexpr int S1_GATHER_BLOCKS = 1024;  // up to this many workgroups' slots are gathered through an offset table in LDS
 
+#ifdef HIPTS_X_TOPK_STAMPS          // measurement-only build (tools/gpurun/r3_topk_stamps.sh): wall-clock stamps of workgroup 0, 10 ns units
+__device__ unsigned long long g_topk_stamps[16];
+#define TOPK_STAMP(i) do { __syncthreads(); if (blockIdx.x == HIPTS_X_TOPK_STAMPS && threadIdx.x == 0) g_topk_stamps[i] = wall_clock64(); } while (0)
+#else
+#define TOPK_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
                                                     int32_t* __restrict__ ids_out, double* __restrict__ vals_out,
                                                     Search1State* __restrict__ pre = nullptr, const uint32_t* __restrict__ pre_cnt = nullptr,
@@ -470,12 +477,39 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         search1_state_clear(pre);               // the maxima slots are zero again for the next query (search1_combine_kernel has read them)
         search1_state_debug(pre, (uint32_t)c, done_fast ? 1u : 0u);
     }
+    TOPK_STAMP(0);
     if (!done_fast && n >= 8192) {
         for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
         if (tid == 0) sh_cnt = 0;
         __syncthreads();
         // the first 1024 of every 8192 scores; TOPK_U loads per thread in flight (one load per step made the sample a chain of ~13
         // dependent round trips for 100 k scores: ~25 us of the kernel's ~80 per workgroup)
+        // 16-byte loads where the row allows it (even length, 16-byte aligned): 8-byte loads reach about 0.6 of the 16-byte rate on this
+        // part (MI355X_MICROARCH.md, "8-B accesses 0.54-0.70x the 16-B rate"), and both passes of the fast path are pure streams
+        const bool wide = (n & 1) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+        constexpr int UW = TOPK_U / 2;
+        uint32_t smax = 0u;
+        bool shave = false;
+        if (wide) {
+            // the first 2048 of every 16384 scores (the same 1/8 sample)
+            for (int64_t base0 = 0; base0 < n; base0 += (int64_t)UW * 16384) {
+                double2 sx[UW];
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int64_t i = base0 + (int64_t)u * 16384 + 2 * tid;
+                    sx[u] = i < n ? *reinterpret_cast<const double2*>(v + i) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int64_t i = base0 + (int64_t)u * 16384 + 2 * tid;
+                    if (i < n) {
+                        const uint32_t d0 = value_digit(sx[u].x), d1 = value_digit(sx[u].y);
+                        smax = max(smax, max(d0, d1));
+                        shave = true;
+                    }
+                }
+            }
+        } else
         for (int64_t base0 = 0; base0 < n; base0 += (int64_t)TOPK_U * 8192) {
             double sx[TOPK_U];
 #pragma unroll
@@ -486,10 +520,20 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
                 const int64_t i = base0 + (int64_t)u * 8192 + tid;
-                hist_add(hist, i < n ? value_digit(sx[u]) : 0u, i < n);
+                if (i < n) {
+                    smax = max(smax, value_digit(sx[u]));
+                    shave = true;
+                }
             }
         }
+        // ONE histogram entry per thread: the largest digit among its ~12 samples.  The number of samples at or above a digit is at least
+        // the number of thread maxima there, so the digit chosen below still leaves >= `want` samples above it (a few more when two of a
+        // thread's samples qualify: 0.6 expected at k = 100, +9 % at k = 1024) -- and the histogram takes 1 k LDS atomics instead of 12.5 k
+        // spread over 4096 bins (12 us of the kernel's 77 at k = 100: tools/topk_k.py, tools/topk_cases.py).
+        TOPK_STAMP(1);
+        hist_add(hist, smax, shave);
         __syncthreads();
+        TOPK_STAMP(2);
         const int want = k / 8 + 3 * (int)ceilf(sqrtf((float)k / 8.0f)) + 4;
         int own[4], ssum = 0;
 #pragma unroll
@@ -515,6 +559,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         // passes, 130-200 us for a row with fewer than ~300 finite scores, and the slowest row sets the launch time (measured:
         // tools/topk_cases.py).  Now: collect everything ABOVE digit 0 and look at what the bin holds; if nothing but -inf (the common case),
         // the candidates are all results and the rest are -inf ties in index order (the ordered fill at the end of the kernel).
+        TOPK_STAMP(3);
         const bool dip = sh_digit == 0;
         const uint32_t dmin = dip ? 1u : (uint32_t)sh_digit;
         if (tid == 0) sh_z0 = 0ull;
@@ -522,6 +567,63 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         unsigned long long z0 = 0ull;
         // the next step's TOPK_U loads are requested before this step's values are examined (two register sets): the pass was a chain of
         // load round trips, one per 16 k scores
+        // Candidates go into the wave's OWN 128 slots of ckey / cid, placed by ballot and a wave-uniform count -- no atomics: ~250 adds on
+        // one LDS counter were 14 us of the kernel at k = 100.  A wave whose slots are full (skewed rows, k = 1024) appends to an overflow
+        // list that lives in the histogram's memory (free now) through a shared counter; the lists are packed below.
+        constexpr int WSLOTS = TOPK_CAP / 16, OVCAP = 1024;
+        uint64_t* ovk = reinterpret_cast<uint64_t*>(hist);                  // 8 KB
+        uint32_t* ovi = hist + 2 * OVCAP;                                   // 4 KB behind it
+        const int wv = tid >> 6, ln = tid & 63;
+        int wcnt = 0;
+        __syncthreads();                                                    // every thread has read its bins of the histogram
+        auto examine = [&](double xv, int64_t i) {
+            const bool c = i < n && value_digit(xv) >= dmin;
+            const unsigned long long m = __ballot(c);
+            if (m) {
+                if (c) {
+                    const int pos = wcnt + __popcll(m & ((1ull << ln) - 1ull));
+                    if (pos < WSLOTS) {
+                        ckey[wv * WSLOTS + pos] = order_key(xv);
+                        cid[wv * WSLOTS + pos] = (uint32_t)i;
+                    } else {
+                        const int slot = atomicAdd(&sh_cnt, 1);
+                        if (slot < OVCAP) {
+                            ovk[slot] = order_key(xv);
+                            ovi[slot] = (uint32_t)i;
+                        }
+                    }
+                }
+                wcnt += __popcll(m);
+            }
+            if (!c && dip && i < n) {
+                const unsigned long long kx = order_key(xv);
+                z0 = kx > z0 ? kx : z0;
+            }
+        };
+        if (wide) {
+            double2 x[UW], xn[UW];
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const int64_t i = (int64_t)u * 2048 + 2 * tid;
+                x[u] = i < n ? *reinterpret_cast<const double2*>(v + i) : make_double2(-INFINITY, -INFINITY);
+            }
+            for (int64_t i0 = 0; i0 < n; i0 += UW * 2048) {
+                const int64_t i1 = i0 + UW * 2048;
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int64_t i = i1 + u * 2048 + 2 * tid;
+                    xn[u] = i < n ? *reinterpret_cast<const double2*>(v + i) : make_double2(-INFINITY, -INFINITY);
+                }
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int64_t i = i0 + u * 2048 + 2 * tid;
+                    examine(x[u].x, i);
+                    examine(x[u].y, i + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < UW; ++u) x[u] = xn[u];
+            }
+        } else {
         double x[TOPK_U], xn[TOPK_U];
 #pragma unroll
         for (int u = 0; u < TOPK_U; ++u) {
@@ -536,23 +638,10 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
                 xn[u] = i < n ? v[i] : -INFINITY;
             }
 #pragma unroll
-            for (int u = 0; u < TOPK_U; ++u) {
-                const int64_t i = i0 + u * 1024 + tid;
-                if (i < n) {
-                    if (value_digit(x[u]) >= dmin) {
-                        const int slot = atomicAdd(&sh_cnt, 1);
-                        if (slot < TOPK_CAP) {
-                            ckey[slot] = order_key(x[u]);
-                            cid[slot] = (uint32_t)i;
-                        }
-                    } else if (dip) {
-                        const unsigned long long kx = order_key(x[u]);
-                        z0 = kx > z0 ? kx : z0;
-                    }
-                }
-            }
+            for (int u = 0; u < TOPK_U; ++u) examine(x[u], i0 + u * 1024 + tid);
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) x[u] = xn[u];
+        }
         }
         if (dip) {
 #pragma unroll
@@ -561,6 +650,40 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
                 z0 = other > z0 ? other : z0;
             }
             if ((tid & 63) == 0) atomicMax(&sh_z0, z0);
+        }
+        TOPK_STAMP(4);
+        // pack the sixteen wave lists and the overflow list into ckey / cid [0, total): through registers (source and destination overlap)
+        if (ln == 0) scratch[wv] = wcnt < WSLOTS ? wcnt : WSLOTS;
+        __syncthreads();
+        {
+            const int nov = sh_cnt;                                         // entries the waves tried to append to the overflow list
+            int off[17];
+            off[0] = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) off[w + 1] = off[w] + scratch[w];
+            const int total = off[16] + (nov < OVCAP ? nov : OVCAP);
+            uint64_t mk[3];
+            uint32_t mi[3];
+            int md[3];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                                    // wave-list slots tid and tid + 1024
+                const int sl = tid + e * 1024, w = sl / WSLOTS, j = sl - w * WSLOTS;
+                md[e] = j < scratch[w] ? off[w] + j : -1;
+                mk[e] = ckey[sl];
+                mi[e] = cid[sl];
+            }
+            md[2] = tid < nov && tid < OVCAP ? off[16] + tid : -1;           // overflow slot tid
+            mk[2] = ovk[tid];
+            mi[2] = ovi[tid];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (md[e] >= 0 && md[e] < TOPK_CAP) {
+                    ckey[md[e]] = mk[e];
+                    cid[md[e]] = mi[e];
+                }
+            __syncthreads();
+            if (tid == 0) sh_cnt = nov > OVCAP ? TOPK_CAP + 1 : total;      // an overflowing overflow list: not a fast-path row
         }
         __syncthreads();
         if (dip) {
@@ -572,6 +695,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         }
         __syncthreads();
     }
+    TOPK_STAMP(5);
     uint64_t prefix = 0;
     int pbits = 0;
     int need = k;            // how many of the keys matching `prefix` are still wanted
@@ -718,22 +842,31 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     }
     const int cnt = sh_cnt;
     const int kout = cnt < k ? cnt : k;
+    TOPK_STAMP(6);
     if (cnt <= 640) {
         // few candidates: rank by counting -- rank(i) = #{j : j before i in (key desc, id asc)} -- no barriers, LDS broadcasts
+        // P adjacent lanes share a candidate, each counting over every P-th entry (one thread per candidate walked the whole list as a
+        // chain of LDS round trips: 26 us of the workgroup's 67 at k = 100 -- tools/topk_stamps.py); partial ranks meet by lane swaps
         __syncthreads();
-        if (tid < cnt) {
-            const uint64_t ki = ckey[tid];
-            const uint32_t ii = cid[tid];
-            int rank = 0;
-            for (int j = 0; j < cnt; ++j) {
+        const int P = cnt <= 256 ? 4 : (cnt <= 512 ? 2 : 1);
+        const int c = tid / P, part = tid - c * P;
+        const bool live = c < cnt;
+        const uint64_t ki = live ? ckey[c] : 0ull;
+        const uint32_t ii = live ? cid[c] : 0u;
+        int rank = 0;
+        if (live) {
+#pragma unroll 4
+            for (int j = part; j < cnt; j += P) {
                 const uint64_t kj = ckey[j];
                 const uint32_t ij = cid[j];
                 rank += (kj > ki || (kj == ki && ij < ii)) ? 1 : 0;
             }
-            if (rank < kout) {
-                ids_out[(int64_t)blockIdx.x * k + rank] = (int32_t)ii;
-                vals_out[(int64_t)blockIdx.x * k + rank] = key_value(ki);
-            }
+        }
+        if (P >= 2) rank += __shfl_xor(rank, 1);
+        if (P == 4) rank += __shfl_xor(rank, 2);
+        if (live && part == 0 && rank < kout) {
+            ids_out[(int64_t)blockIdx.x * k + rank] = (int32_t)ii;
+            vals_out[(int64_t)blockIdx.x * k + rank] = key_value(ki);
         }
     } else {
         int np2 = 64;
@@ -766,6 +899,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
             vals_out[(int64_t)blockIdx.x * k + i] = key_value(ckey[i]);
         }
     }
+    TOPK_STAMP(7);
     if (fill_need > 0) {
         // the remaining results are -inf scores in ascending index order (ordered compaction; stops as soon as enough are found)
         const uint64_t ninf = order_key(-INFINITY);
@@ -1470,6 +1604,16 @@ int hipts_query_profile_read(hipts_bm25_t* h, int category, double* total_ms, in
     if (launches) *launches = h->prof_n[category];
     if (total_bytes) *total_bytes = h->prof_bytes[category];
     return HIPTS_OK;
+}
+
+int hiptsdbg_topk_stamps(unsigned long long* host16) {
+#ifdef HIPTS_X_TOPK_STAMPS
+    HIPTS_HIP(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_topk_stamps), 16 * 8));
+    return HIPTS_OK;
+#else
+    (void)host16;
+    return set_error(HIPTS_ERR_STATE, "built without HIPTS_X_TOPK_STAMPS");
+#endif
 }
 
 int hiptsdbg_search1_last(hipts_bm25_t* h, uint32_t* candidates, uint32_t* took_candidate_path) {

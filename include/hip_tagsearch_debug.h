@@ -51,6 +51,8 @@ int hiptsdbg_attention2_stamps(unsigned long long* host, int n);
 /* One-query search path (hipts_search with nq == 1): how many candidates its threshold step collected for the last query and
  * whether the ranking used them (1) or fell through to the exact radix select (0). */
 int hiptsdbg_search1_last(hipts_bm25_t* h, uint32_t* candidates, uint32_t* took_candidate_path);
+/* measurement-only builds (-DHIPTS_X_TOPK_STAMPS=<workgroup>): the 16 wall-clock stamps (10 ns units) of the last batched hipts_topk launch */
+int hiptsdbg_topk_stamps(unsigned long long* host16);
 
 #ifdef __cplusplus
 }
