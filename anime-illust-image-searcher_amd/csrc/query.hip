@@ -845,10 +845,10 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     TOPK_STAMP(6);
     if (cnt <= 640) {
         // few candidates: rank by counting -- rank(i) = #{j : j before i in (key desc, id asc)} -- no barriers, LDS broadcasts
-        // P adjacent lanes share a candidate, each counting over every P-th entry (one thread per candidate walked the whole list as a
+        // P adjacent lanes (as many as 1024 threads allow) share a candidate, each counting over every P-th entry (one thread per candidate walked the whole list as a
         // chain of LDS round trips: 26 us of the workgroup's 67 at k = 100 -- tools/topk_stamps.py); partial ranks meet by lane swaps
         __syncthreads();
-        const int P = cnt <= 256 ? 4 : (cnt <= 512 ? 2 : 1);
+        const int P = cnt <= 64 ? 16 : cnt <= 128 ? 8 : cnt <= 256 ? 4 : cnt <= 512 ? 2 : 1;
         const int c = tid / P, part = tid - c * P;
         const bool live = c < cnt;
         const uint64_t ki = live ? ckey[c] : 0ull;
@@ -863,7 +863,9 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
             }
         }
         if (P >= 2) rank += __shfl_xor(rank, 1);
-        if (P == 4) rank += __shfl_xor(rank, 2);
+        if (P >= 4) rank += __shfl_xor(rank, 2);
+        if (P >= 8) rank += __shfl_xor(rank, 4);
+        if (P >= 16) rank += __shfl_xor(rank, 8);
         if (live && part == 0 && rank < kout) {
             ids_out[(int64_t)blockIdx.x * k + rank] = (int32_t)ii;
             vals_out[(int64_t)blockIdx.x * k + rank] = key_value(ki);
