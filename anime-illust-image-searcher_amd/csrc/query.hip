@@ -301,6 +301,110 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_mfma_kernel(const float* __re
     }
 }
 
+// Up to 256 queries per pass over the index (round 3).  The kernel above streams the whole index once per 32 queries -- 8 passes of
+// 120 MB for the bench's 256-query batch, HBM-bound at 41 us each -- although a 32-document tile already in registers can be multiplied
+// against every query block for the price of the (exact-f32) MFMAs alone.  Here a workgroup of 8 waves takes 8 document tiles and walks K
+// in chunks of 8: the chunk of the query matrix ([8 k][256 queries], 9 KB) is staged in LDS by all threads (double-buffered, one barrier
+// per chunk), each wave multiplies its documents' 8 k-values against NQB query blocks (4 NQB MFMAs) and keeps NQB accumulator tiles.
+// Per (query, document) the MFMA sequence -- operands and order -- is the one of the kernel above: the same bits.
+constexpr int SIMW_QS = 288;       // floats per k-row of the LDS chunk: 256 queries + 32, so that the two half-waves (k, k + 1) use different banks
+template <int NQB>
+__global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __restrict__ tiled, int64_t D, int K, const float* __restrict__ q, int nq,
+                                                            float* __restrict__ out, int64_t out_ld) {
+    __shared__ float qs[2][8][SIMW_QS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t ntiles = (D + 31) / 32;
+    const int KQ = K >> 2;                       // float4 per document row
+    const int nchunks = (KQ + 1) >> 1;           // 8 k per chunk; the last one holds 4 when K % 8 == 4
+    const int sj = tid >> 1, sh = tid & 1;       // staging role: query sj, k-half sh of the chunk
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_q = [&](int c) {
+        const int kq = 2 * c + sh;
+        return (sj < nq && kq < KQ) ? *reinterpret_cast<const float4*>(q + (int64_t)sj * K + 4 * kq) : zero4;
+    };
+    auto store_q = [&](int buf, float4 v) {
+        qs[buf][4 * sh + 0][sj] = v.x;
+        qs[buf][4 * sh + 1][sj] = v.y;
+        qs[buf][4 * sh + 2][sj] = v.z;
+        qs[buf][4 * sh + 3][sj] = v.w;
+    };
+    for (int64_t st = blockIdx.x; st * 8 < ntiles; st += gridDim.x) {
+        const int64_t tile = st * 8 + wave;
+        const bool tv = tile < ntiles;           // wave-uniform; a wave without a tile still stages and meets the barriers
+        const float4* __restrict__ trow = tiled + (tv ? tile : ntiles - 1) * KQ * 32 + r;
+        f32x16 acc[NQB];
+#pragma unroll
+        for (int b = 0; b < NQB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.0f;
+        float4 d0 = trow[0], d1 = 1 < KQ ? trow[32] : zero4;
+        store_q(0, load_q(0));                   // buffer 0 was last read before the final barrier of the previous super-tile
+        __syncthreads();
+        const int nfull = KQ >> 1;               // chunks of 8 k; K % 8 == 4 leaves a chunk of 4 behind them
+        for (int c = 0; c < nfull; ++c) {
+            const bool more = c + 1 < nchunks;
+            float4 qn = zero4, e0 = zero4, e1 = zero4;
+            if (more) {                          // the next chunk's loads are in flight under this chunk's MFMAs
+                qn = load_q(c + 1);
+                e0 = trow[(2 * c + 2) * 32];
+                e1 = 2 * c + 3 < KQ ? trow[(2 * c + 3) * 32] : zero4;
+            }
+            const float b0 = h ? d0.y : d0.x, b1 = h ? d0.w : d0.z, b2 = h ? d1.y : d1.x, b3 = h ? d1.w : d1.z;
+            const float* qrow = &qs[c & 1][h][r];
+            // k-pair by k-pair across the blocks: consecutive MFMAs are independent (per block the k order is unchanged)
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32], b0, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 2 * SIMW_QS], b1, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 4 * SIMW_QS], b2, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 6 * SIMW_QS], b3, acc[b], 0, 0, 0);
+            if (more) {
+                store_q((c + 1) & 1, qn);
+                d0 = e0;
+                d1 = e1;
+            }
+            __syncthreads();
+        }
+        if (KQ & 1) {                            // the chunk of 4 (staged by the last iteration above, or by the prologue when K == 4)
+            const float b0 = h ? d0.y : d0.x, b1 = h ? d0.w : d0.z;
+            const float* qrow = &qs[nfull & 1][h][r];
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) {
+                const float* qk = qrow + b * 32;
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[0], b0, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[2 * SIMW_QS], b1, acc[b], 0, 0, 0);
+            }
+            __syncthreads();                     // the next super-tile's prologue writes buffer 0 again
+        }
+        const int64_t doc = tile * 32 + r;
+        if (tv && doc < D) {
+            // D layout: column = lane & 31 = document, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = query of the block.  One per-lane
+            // pointer, the row offsets as scalar products of a stride the compiler may not hoist (left to itself it keeps 16 NQB 64-bit
+            // offsets and as many lane masks alive across the whole tile loop: 256 VGPRs and 190 spilled for NQB = 8)
+            int64_t old = out_ld;
+            int nqv = nq;
+            asm volatile("" : "+s"(old), "+s"(nqv));
+            float* __restrict__ base = out + (int64_t)(4 * h) * old + doc;
+#pragma unroll
+            for (int b = 0; b < NQB; ++b) {
+                if (b * 32 + 32 <= nqv) {                      // uniform: a whole block of queries, no per-lane test
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) base[(int64_t)(b * 32 + (reg & 3) + 8 * (reg >> 2)) * old] = acc[b][reg];
+                } else if (b * 32 < nqv) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int cqi = b * 32 + (reg & 3) + 8 * (reg >> 2);
+                        if (cqi + 4 * h < nqv) base[(int64_t)cqi * old] = acc[b][reg];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // (re)build tiles [t0, t1) of the tile-major copy from the row-major rows; rows >= len read as zero
 __global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ rows, float4* __restrict__ tl, int64_t len, int K,
                                                      int64_t t0, int64_t t1) {
@@ -1378,6 +1482,21 @@ struct hipts_index {
 
 namespace {
 
+bool sim_wide_enabled() {
+    static const bool on = !(getenv("HIPTS_SIM_WIDE") && atoi(getenv("HIPTS_SIM_WIDE")) == 0) && !(getenv("HIPTS_SIM") && strcmp(getenv("HIPTS_SIM"), "rows") == 0);
+    return on;
+}
+// passes over the index that launch_sim makes for nq queries (the profile's algorithmic bytes)
+int sim_index_passes(bool tiled, int K, int nq) {
+    if (!(tiled && sim_wide_enabled() && K % 4 == 0)) return (nq + 31) / 32;
+    int passes = 0, done = 0;
+    while (nq - done > 32) {
+        done += std::min(256, nq - done);
+        ++passes;
+    }
+    return passes + (done < nq ? 1 : 0);
+}
+
 int launch_sim(const float* index, const float* tiled, int64_t D, int K, const float* q_dev, int nq, float* out_dev, int64_t out_ld,
                hipStream_t s) {
     const size_t lds = (size_t)K * 32 * sizeof(float);
@@ -1398,7 +1517,24 @@ int launch_sim(const float* index, const float* tiled, int64_t D, int K, const f
     constexpr int WPB = SIM_THREADS / 64;
     int grid = (int)std::min<int64_t>((ntiles + WPB - 1) / WPB, 256 * 4);
     if (grid < 1) grid = 1;
-    for (int q0 = 0; q0 < nq; q0 += 32) {
+    // more than 32 queries over the tile-major copy: one pass per 256 queries (HIPTS_SIM_WIDE=0: the 32-query passes, for A/B)
+    const bool use_wide = sim_wide_enabled();
+    int q_done = 0;
+    if (tiled && use_tiled && use_wide && K % 4 == 0) {
+        const int wgrid = (int)std::min<int64_t>((ntiles + 7) / 8, 256);
+        while (nq - q_done > 32) {
+            const int n = std::min(256, nq - q_done);
+            const float4* t4 = reinterpret_cast<const float4*>(tiled);
+            const float* qp = q_dev + (int64_t)q_done * K;
+            float* op = out_dev + (int64_t)q_done * out_ld;
+            if (n <= 64) sim_mfma_wide_kernel<2><<<wgrid, 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            else if (n <= 128) sim_mfma_wide_kernel<4><<<wgrid, 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            else sim_mfma_wide_kernel<8><<<wgrid, 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            HIPTS_LAUNCH_CHECK();
+            q_done += n;
+        }
+    }
+    for (int q0 = q_done; q0 < nq; q0 += 32) {
         const int n = std::min(32, nq - q0);
         if (tiled && use_tiled) sim_mfma_kernel<true><<<grid, SIM_THREADS, lds, s>>>(tiled, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
         else sim_mfma_kernel<false><<<grid, SIM_THREADS, lds, s>>>(index, D, K, K, q_dev + (int64_t)q0 * K, n, out_dev + (int64_t)q0 * out_ld, out_ld);
@@ -2059,7 +2195,7 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
         HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
     }
     {
-        QueryProfScope ps(bm25, s, QP_SIM, (double)((nq + 31) / 32) * D * index->dim * 4.0 + (double)nq * D * 4.0);
+        QueryProfScope ps(bm25, s, QP_SIM, (double)sim_index_passes(index->tiled.p != nullptr, index->dim, nq) * D * index->dim * 4.0 + (double)nq * D * 4.0);
         HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s));
     }
     {

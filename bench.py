@@ -210,11 +210,17 @@ def query_section(device):
     def dominant(prof):
         return max(prof, key=lambda c: c["avg_us"] * c["launches"]) if prof else None
     roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "note": "achieved = algorithmic bytes per launch / HIP-event time of that launch, on the launch stream. Batched: a launch of "
-                    "sim_mfma_kernel serves 32 queries with ONE pass over the index (its unit is bytes per 32-query pass, %d of them per "
-                    "batch of %d), bm25_postings_kernel / topk_kernel / rowmax / combine one launch per batch. Single: the one-query path's "
-                    "four launches per query" % (chunk // 32, chunk),
+            "note": "achieved = algorithmic bytes per launch / HIP-event time of that launch, on the launch stream. Batched: the index product "
+                    "(sim_mfma_wide_kernel, round 3) serves up to 256 queries with ONE pass over the index -- its bytes are the index once plus "
+                    "the %d x D score rows, and at that many queries per pass it is bound by the exact-f32 MFMA rate (2 D K nq flop against "
+                    "157 TFLOP/s: see 'sim_mfma'), not by HBM; bm25_postings_kernel / topk_kernel / rowmax / combine one launch per batch. "
+                    "Single: the one-query path's four launches per query" % chunk,
             "batched": {"kernels": prof_batched}, "single": {"kernels": prof_single}}
+    for c in prof_batched:
+        if c["kernel"] == "sim_mfma_kernel":
+            fl = 2.0 * D * K * chunk
+            roof["sim_mfma"] = {"bound": "mfma (exact f32, v_mfma_f32_32x32x2_f32)", "flops_per_launch": fl, "avg_launch_us": c["avg_us"],
+                                "achieved": fl / (c["avg_us"] * 1e6), "peak": 157.0, "unit": "TFLOP/s", "frac": fl / (c["avg_us"] * 1e6) / 157.0}
     for tag, prof in (("batched", prof_batched), ("single", prof_single)):
         d = dominant(prof)
         if d:
