@@ -506,12 +506,25 @@ __device__ unsigned long long g_topk_stamps[16];
 #define TOPK_STAMP(i) do { } while (0)
 #endif
 
+// The score rows as the two addends of webui.py:377-383 instead of their sum: with `a` set the kernel computes
+// wa * (a / max_a) + (double)(wb * (b / max_b)) -- combine_kernel's expression, operation for operation -- wherever it reads a score,
+// and the batched search neither writes nor re-reads the combined rows (round 3: 20 B per score of traffic less, one launch less).
+struct TopkFused {
+    const double* a = nullptr;       // [nq][n] BM25 scores
+    const float* b = nullptr;        // [nq][n] index products
+    double wa = 0.0;
+    float wb = 0.f;
+    const double* max_a = nullptr;   // [nq] row maxima (normalise when > 0)
+    const float* max_b = nullptr;
+};
+
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
                                                     int32_t* __restrict__ ids_out, double* __restrict__ vals_out,
                                                     Search1State* __restrict__ pre = nullptr, const uint32_t* __restrict__ pre_cnt = nullptr,
                                                     const uint32_t* __restrict__ pre_flag = nullptr, const unsigned long long* __restrict__ pre_key = nullptr,
                                                     const uint32_t* __restrict__ pre_id = nullptr, int pre_blocks = 0,
-                                                    uint32_t* __restrict__ done_flag = nullptr, uint32_t done_seq = 0, int pre_cap = S1_BLOCK_CAP) {
+                                                    uint32_t* __restrict__ done_flag = nullptr, uint32_t done_seq = 0, int pre_cap = S1_BLOCK_CAP,
+                                                    const TopkFused fz = TopkFused()) {
     __shared__ uint32_t hist[4096];
     __shared__ uint64_t ckey[TOPK_CAP];
     __shared__ uint32_t cid[TOPK_CAP];
@@ -520,7 +533,27 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     __shared__ unsigned long long sh_z0;       // largest order key among the scores of digit 0 (fast path that has to dip into that bin)
     __shared__ int soff[S1_GATHER_BLOCKS];
     const int tid = threadIdx.x;
-    const double* __restrict__ v = vals + (int64_t)blockIdx.x * n;
+    const bool fused = fz.a != nullptr;
+    const double* __restrict__ v = fused ? nullptr : vals + (int64_t)blockIdx.x * n;
+    const double* __restrict__ fa = fused ? fz.a + (int64_t)blockIdx.x * n : nullptr;
+    const float* __restrict__ fb = fused ? fz.b + (int64_t)blockIdx.x * n : nullptr;
+    const double f_ma = fused ? fz.max_a[blockIdx.x] : 0.0;
+    const float f_mb = fused ? fz.max_b[blockIdx.x] : 0.f;
+    auto comb = [&](double A, float B) -> double {       // combine_kernel, operation for operation (the file is built with -ffp-contract=off)
+        if (f_ma > 0.0) A = A / f_ma;
+        if (f_mb > 0.0f) B = B / f_mb;
+        const float wB = fz.wb * B;
+        return fz.wa * A + (double)wB;
+    };
+    auto val = [&](int64_t i) -> double { return fused ? comb(fa[i], fb[i]) : v[i]; };
+    auto val2 = [&](int64_t i) -> double2 {              // scores i, i + 1 (i even, rows 16-byte aligned: `wide`)
+        if (fused) {
+            const double2 A = *reinterpret_cast<const double2*>(fa + i);
+            const float2 B = *reinterpret_cast<const float2*>(fb + i);
+            return make_double2(comb(A.x, B.x), comb(A.y, B.y));
+        }
+        return *reinterpret_cast<const double2*>(v + i);
+    };
     if ((int64_t)k > n) k = (int)n;
     // ---- fast path (measured: the exact radix select below spends ~200 us of a 233 us single-query call in the
     // LDS atomics of its first histogram, 100 k of them).  Estimate the threshold from a 1/8 sample instead:
@@ -590,7 +623,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         // dependent round trips for 100 k scores: ~25 us of the kernel's ~80 per workgroup)
         // 16-byte loads where the row allows it (even length, 16-byte aligned): 8-byte loads reach about 0.6 of the 16-byte rate on this
         // part (MI355X_MICROARCH.md, "8-B accesses 0.54-0.70x the 16-B rate"), and both passes of the fast path are pure streams
-        const bool wide = (n & 1) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+        const bool wide = (n & 1) == 0 && (fused ? ((reinterpret_cast<uintptr_t>(fa) & 15) == 0 && (reinterpret_cast<uintptr_t>(fb) & 7) == 0)
+                                                 : (reinterpret_cast<uintptr_t>(v) & 15) == 0);
         constexpr int UW = TOPK_U / 2;
         uint32_t smax = 0u;
         bool shave = false;
@@ -601,7 +635,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
                 for (int u = 0; u < UW; ++u) {
                     const int64_t i = base0 + (int64_t)u * 16384 + 2 * tid;
-                    sx[u] = i < n ? *reinterpret_cast<const double2*>(v + i) : make_double2(0.0, 0.0);
+                    sx[u] = i < n ? val2(i) : make_double2(0.0, 0.0);
                 }
 #pragma unroll
                 for (int u = 0; u < UW; ++u) {
@@ -619,7 +653,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
                 const int64_t i = base0 + (int64_t)u * 8192 + tid;
-                sx[u] = i < n ? v[i] : 0.0;
+                sx[u] = i < n ? val(i) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
@@ -709,14 +743,14 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
             for (int u = 0; u < UW; ++u) {
                 const int64_t i = (int64_t)u * 2048 + 2 * tid;
-                x[u] = i < n ? *reinterpret_cast<const double2*>(v + i) : make_double2(-INFINITY, -INFINITY);
+                x[u] = i < n ? val2(i) : make_double2(-INFINITY, -INFINITY);
             }
             for (int64_t i0 = 0; i0 < n; i0 += UW * 2048) {
                 const int64_t i1 = i0 + UW * 2048;
 #pragma unroll
                 for (int u = 0; u < UW; ++u) {
                     const int64_t i = i1 + u * 2048 + 2 * tid;
-                    xn[u] = i < n ? *reinterpret_cast<const double2*>(v + i) : make_double2(-INFINITY, -INFINITY);
+                    xn[u] = i < n ? val2(i) : make_double2(-INFINITY, -INFINITY);
                 }
 #pragma unroll
                 for (int u = 0; u < UW; ++u) {
@@ -732,14 +766,14 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
         for (int u = 0; u < TOPK_U; ++u) {
             const int64_t i = (int64_t)u * 1024 + tid;
-            x[u] = i < n ? v[i] : -INFINITY;
+            x[u] = i < n ? val(i) : -INFINITY;
         }
         for (int64_t i0 = 0; i0 < n; i0 += TOPK_U * 1024) {
             const int64_t i1 = i0 + TOPK_U * 1024;
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
                 const int64_t i = i1 + u * 1024 + tid;
-                xn[u] = i < n ? v[i] : -INFINITY;
+                xn[u] = i < n ? val(i) : -INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) examine(x[u], i0 + u * 1024 + tid);
@@ -815,7 +849,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
                 const int64_t i = i0 + u * 1024 + tid;
-                key[u] = i < n ? order_key(v[i]) : 0;
+                key[u] = i < n ? order_key(val(i)) : 0;
             }
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
@@ -861,7 +895,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
             // in the bin agree, the remaining five digit passes are known in advance.
             uint64_t mn = ~0ull, mx = 0ull;
             for (int64_t i = tid; i < n; i += 1024) {
-                const uint64_t key = order_key(v[i]);
+                const uint64_t key = order_key(val(i));
                 if ((key >> (64 - pbits)) == prefix) {
                     mn = key < mn ? key : mn;
                     mx = key > mx ? key : mx;
@@ -902,7 +936,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
                 const int64_t i = i0 + u * 1024 + tid;
-                key[u] = i < n ? order_key(v[i]) : 0;
+                key[u] = i < n ? order_key(val(i)) : 0;
             }
 #pragma unroll
             for (int u = 0; u < TOPK_U; ++u) {
@@ -919,7 +953,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         // pbits == 64 and more than CAP exact ties at the threshold: everything above it, then the
         // `need` lowest indices among the ties (ordered compaction).
         for (int64_t i = tid; i < n; i += 1024) {
-            const uint64_t key = order_key(v[i]);
+            const uint64_t key = order_key(val(i));
             if (key > low) {
                 const int slot = atomicAdd(&sh_cnt, 1);
                 ckey[slot] = key;
@@ -930,7 +964,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         int base = sh_cnt, taken = 0;
         for (int64_t i0 = 0; i0 < n && taken < need; i0 += 1024) {
             const int64_t i = i0 + tid;
-            const int flag = (i < n && order_key(v[i]) == low) ? 1 : 0;
+            const int flag = (i < n && order_key(val(i)) == low) ? 1 : 0;
             int total;
             const int excl = block_excl_scan(flag, scratch, &total);
             if (flag && taken + excl < need) {
@@ -1012,7 +1046,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         int taken = 0;
         for (int64_t i0 = 0; i0 < n && taken < fill_need; i0 += 1024) {
             const int64_t i = i0 + tid;
-            const int flag = (i < n && order_key(v[i]) == ninf) ? 1 : 0;
+            const int flag = (i < n && order_key(val(i)) == ninf) ? 1 : 0;
             int total;
             const int excl = block_excl_scan(flag, scratch, &total);
             if (flag && taken + excl < fill_need) {
@@ -2174,8 +2208,12 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     const float* qvec = reinterpret_cast<const float*>(bm25->ws_q.as<char>() + off_v);
     HIPTS_TRY(bm25->ws_scores.reserve((size_t)nq * D * 8));
     HIPTS_TRY(bm25->ws_sims.reserve((size_t)nq * D * 4));
+    // Without a caller who wants the combined rows they are never written: the top-k kernel combines on the fly (TopkFused;
+    // HIPTS_SEARCH_FUSED_TOPK=0 restores combine_kernel + top-k over the stored rows, for A/B).
+    static const bool fuse_topk = !(getenv("HIPTS_SEARCH_FUSED_TOPK") && atoi(getenv("HIPTS_SEARCH_FUSED_TOPK")) == 0);
+    const bool fused = fuse_topk && final_out_device == nullptr;
     double* final_dev = final_out_device;
-    if (!final_dev) {
+    if (!final_dev && !fused) {
         HIPTS_TRY(bm25->ws_final.reserve((size_t)nq * D * 8));
         final_dev = bm25->ws_final.as<double>();
     }
@@ -2203,7 +2241,7 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
         rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
         HIPTS_LAUNCH_CHECK();
     }
-    {
+    if (!fused) {
         QueryProfScope ps(bm25, s, QP_COMBINE, (double)nq * D * 20.0);
         dim3 grid(ceil_div(D, 256), nq);
         combine_kernel<<<grid, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, ma,
@@ -2217,8 +2255,19 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     double* ov = bm25->ws_out.as<double>();
     int32_t* oi = reinterpret_cast<int32_t*>(ov + (size_t)nq * kk);
     {
-        QueryProfScope ps(bm25, s, QP_TOPK, (double)nq * D * 8.0);
-        topk_kernel<<<nq, 1024, 0, s>>>(final_dev, D, kk, oi, ov);
+        QueryProfScope ps(bm25, s, QP_TOPK, (double)nq * D * (fused ? 12.0 : 8.0));
+        if (fused) {
+            TopkFused fz;
+            fz.a = bm25->ws_scores.as<double>();
+            fz.b = bm25->ws_sims.as<float>();
+            fz.wa = w_bm25;
+            fz.wb = (float)w_sim;
+            fz.max_a = ma;
+            fz.max_b = mb;
+            topk_kernel<<<nq, 1024, 0, s>>>(nullptr, D, kk, oi, ov, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0u, S1_BLOCK_CAP, fz);
+        } else {
+            topk_kernel<<<nq, 1024, 0, s>>>(final_dev, D, kk, oi, ov);
+        }
         HIPTS_LAUNCH_CHECK();
     }
     HIPTS_HIP(hipMemcpyAsync(bm25->pin_out.p, ov, out_bytes, hipMemcpyDeviceToHost, s));
