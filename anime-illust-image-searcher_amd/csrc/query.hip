@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(const int64_t* __restri
 // idf * (0 / denom) = +0.0, which leaves a non-negative score unchanged, so skipping them is exact.
 // Reads sum(df) * 8 B + a few passes over D instead of the whole corpus per query.
 // mark[d]: bit 7 = an excluded term is present, low bits = number of required terms present.
+#ifdef HIPTS_X_TOPK_STAMPS
+__device__ unsigned long long g_bm25_stamps[8];
+#define BM25_STAMP(i) do { __syncthreads(); if (blockIdx.x == HIPTS_X_TOPK_STAMPS && threadIdx.x == 0) g_bm25_stamps[i] = wall_clock64(); } while (0)
+#else
+#define BM25_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __restrict__ tptr, const int32_t* __restrict__ tdoc,
                                                              const int32_t* __restrict__ ttf, const int32_t* __restrict__ dl,
                                                              const double* __restrict__ idf, int32_t V, double avgdl, int64_t D,
@@ -122,40 +128,122 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
         if (w > REQUIRE_MAGIC) ++n_required;
         if (w > REQUIRE_MAGIC || w < 0.0) masking = true;
     }
+    BM25_STAMP(0);
+    // the query's term metadata (posting range, idf) is requested before the row is cleared: per term the dependent chain is then
+    // posting -> {document length, score} instead of term -> range -> posting -> ... (~2 us per term of a workgroup's 60-135 us)
+    constexpr int TPRE = 8;
+    int64_t t_b[TPRE], t_e[TPRE];
+    double t_idf[TPRE];
+#pragma unroll
+    for (int u = 0; u < TPRE; ++u) {
+        const int j = qb + u;
+        const int32_t t = j < qe ? q_terms[j] : -1;
+        const bool ok = t >= 0 && t < V;
+        t_b[u] = ok ? tptr[t] : 0;
+        t_e[u] = ok ? tptr[t + 1] : 0;
+        t_idf[u] = ok ? idf[t] : 0.0;
+    }
+    // 8 documents per thread and step where the row allows it (64 B of scores, 8 B of marks per thread: the byte-wide mark accesses
+    // made the masked rows' last pass 65-72 us against 15-29 us for unmasked ones -- tools/bm25_stamps.py)
+    const bool vec8 = (D & 7) == 0;
+    if (vec8) {
+        // lane-contiguous 16-byte stores (1 KB per wave instruction; 64 B per lane at a 64 B stride wrote every line in four pieces: 59 us)
+        const double2 z2 = make_double2(0.0, 0.0);
+        for (int64_t g = tid; g < (D >> 1); g += 1024) reinterpret_cast<double2*>(scores)[g] = z2;
+        if (masking)
+            for (int64_t g = tid; g < (D >> 3); g += 1024) reinterpret_cast<uint64_t*>(mark)[g] = 0ull;
+    } else {
 #pragma unroll 8
-    for (int64_t d = tid; d < D; d += 1024) {
-        scores[d] = 0.0;
-        if (masking) mark[d] = 0;
+        for (int64_t d = tid; d < D; d += 1024) {
+            scores[d] = 0.0;
+            if (masking) mark[d] = 0;
+        }
     }
     __syncthreads();
+    BM25_STAMP(1);
     for (int j = qb; j < qe; ++j) {
         const int32_t t = q_terms[j];
         const double w = q_weights[j];
         if (t >= 0 && t < V) {
-            const double idf_t = idf[t];
-            const int64_t b = tptr[t], e = tptr[t + 1];
-#pragma unroll 4
-            for (int64_t i = b + tid; i < e; i += 1024) {      // (distinct documents within a term: iterations are independent)
-                const int32_t d = tdoc[i];
+            double idf_t;
+            int64_t b, e;
+            const int u = j - qb;
+            if (u < TPRE) {                       // uniform
+                idf_t = t_idf[0]; b = t_b[0]; e = t_e[0];
+#pragma unroll
+                for (int x = 1; x < TPRE; ++x)
+                    if (u == x) { idf_t = t_idf[x]; b = t_b[x]; e = t_e[x]; }
+            } else {
+                idf_t = idf[t]; b = tptr[t]; e = tptr[t + 1];
+            }
+            // Eight postings per thread in flight: the documents of one term are distinct, but the compiler cannot know that a
+            // load of scores[d'] may pass the store to scores[d], so an unrolled loop still ran its read-modify-writes one after
+            // the other (~6 us per 1024 x 4 postings); here the gathers of a batch are all issued before the first store.
+            constexpr int PU = 8;
+            const bool req = w > REQUIRE_MAGIC;
+            const double ww = req ? (w - REQUIRE_MAGIC) : w;
+            for (int64_t i0 = b + tid; i0 < e; i0 += (int64_t)PU * 1024) {
+                int32_t dd[PU];
+                double tfd[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int64_t i = i0 + (int64_t)u * 1024;
+                    dd[u] = i < e ? tdoc[i] : -1;
+                    tfd[u] = i < e ? (double)ttf[i] : 0.0;
+                }
                 if (w < 0.0) {
-                    mark[d] |= 0x80;
+#pragma unroll
+                    for (int u = 0; u < PU; ++u)
+                        if (dd[u] >= 0) mark[dd[u]] |= 0x80;
                 } else {
-                    const double tfd = (double)ttf[i];
-                    const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * ((double)dl[d] / avgdl));
-                    const double sc = idf_t * ((tfd * (BM25_K1 + 1.0)) / (tfd + nrm));
-                    if (w > REQUIRE_MAGIC) {
-                        scores[d] += (w - REQUIRE_MAGIC) * sc;
-                        mark[d] += 1;
-                    } else {
-                        scores[d] += w * sc;
+                    double dlv[PU], sv[PU];
+                    uint8_t mk[PU];
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        dlv[u] = dd[u] >= 0 ? (double)dl[dd[u]] : 0.0;
+                        sv[u] = dd[u] >= 0 ? scores[dd[u]] : 0.0;
+                        mk[u] = (req && dd[u] >= 0) ? mark[dd[u]] : (uint8_t)0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        if (dd[u] < 0) continue;
+                        const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv[u] / avgdl));
+                        const double sc = idf_t * ((tfd[u] * (BM25_K1 + 1.0)) / (tfd[u] + nrm));
+                        scores[dd[u]] = sv[u] + ww * sc;
+                        if (req) mark[dd[u]] = (uint8_t)(mk[u] + 1);
                     }
                 }
             }
         }
         __syncthreads();
     }
+    BM25_STAMP(2);
     double mx = -INFINITY;
-    if (masking) {
+    if (masking && vec8) {
+        // two documents per lane and access (16 B of scores, 2 B of marks), four accesses in flight; every wave instruction covers a contiguous KB
+        const int64_t pairs = D >> 1;
+        for (int64_t g0 = tid; g0 < pairs; g0 += 4 * 1024) {
+            double2 v[4];
+            uint32_t m2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * 1024;
+                v[u] = g < pairs ? reinterpret_cast<const double2*>(scores)[g] : make_double2(-INFINITY, -INFINITY);
+                m2[u] = g < pairs ? reinterpret_cast<const uint16_t*>(mark)[g] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * 1024;
+                if (g >= pairs) continue;
+                const uint32_t ma = m2[u] & 0xffu, mb_ = m2[u] >> 8;
+                const bool ka = (ma & 0x80u) || (int)(ma & 0x7fu) != n_required, kb = (mb_ & 0x80u) || (int)(mb_ & 0x7fu) != n_required;
+                if (ka) v[u].x = -INFINITY;
+                if (kb) v[u].y = -INFINITY;
+                if (ka || kb) reinterpret_cast<double2*>(scores)[g] = v[u];
+                mx = fmax(mx, fmax(v[u].x, v[u].y));
+            }
+        }
+    } else if (masking) {
 #pragma unroll 8
         for (int64_t d = tid; d < D; d += 1024) {
             const uint8_t m = mark[d];
@@ -163,10 +251,18 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
             if ((m & 0x80) || (m & 0x7f) != n_required) scores[d] = v = -INFINITY;
             mx = fmax(mx, v);
         }
+    } else if (max_out && vec8) {
+        const int64_t pairs = D >> 1;
+#pragma unroll 4
+        for (int64_t g = tid; g < pairs; g += 1024) {
+            const double2 a0 = reinterpret_cast<const double2*>(scores)[g];
+            mx = fmax(mx, fmax(a0.x, a0.y));
+        }
     } else if (max_out) {
 #pragma unroll 8
         for (int64_t d = tid; d < D; d += 1024) mx = fmax(mx, scores[d]);
     }
+    BM25_STAMP(3);
     if (max_out) {      // row maximum for the normalisation of webui.py:379-380, fused here
         __shared__ double part[16];
         for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
@@ -1781,6 +1877,7 @@ int hipts_query_profile_read(hipts_bm25_t* h, int category, double* total_ms, in
 int hiptsdbg_topk_stamps(unsigned long long* host16) {
 #ifdef HIPTS_X_TOPK_STAMPS
     HIPTS_HIP(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_topk_stamps), 16 * 8));
+    HIPTS_HIP(hipMemcpyFromSymbol(host16 + 8, HIP_SYMBOL(g_bm25_stamps), 8 * 8));      // slots 8..11: the BM25 kernel's clear / postings / mask+max
     return HIPTS_OK;
 #else
     (void)host16;

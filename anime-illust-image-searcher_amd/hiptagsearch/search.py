@@ -12,6 +12,7 @@ Scoring (BM25, index product, normalise, combine, top-k) runs in libhip_tagsearc
 the 10-document pseudo-relevance bookkeeping and the gap filter are host logic.
 """
 import ctypes
+import itertools
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -129,16 +130,16 @@ class SearchEngine:
             _lib.check(self._search_fn(self.bm25._h, self.index._h, qt_a.ctypes.data, qw_a.ctypes.data, qp.ctypes.data, qv.ctypes.data, 1,
                                        self._w_bm25, self._w_sim, k, ids.ctypes.data, vals.ctypes.data, None, _lib.current_stream_ptr()))
             return ids, vals
+        # the CSR of the batch without a Python-level loop over terms (that loop was ~1/5 of a 256-query call)
         qp = np.zeros(nq + 1, dtype=np.int32)
-        qt: List[int] = []
-        qw: List[float] = []
-        for i, q in enumerate(query_weights):
-            for t, w in q.items():
-                qt.append(int(t))
-                qw.append(float(w))
-            qp[i + 1] = len(qt)
-        qt_a = np.asarray(qt if qt else [0], dtype=np.int32)
-        qw_a = np.asarray(qw if qw else [0.0], dtype=np.float64)
+        np.cumsum(np.fromiter(map(len, query_weights), dtype=np.int32, count=nq), out=qp[1:])
+        nt = int(qp[nq])
+        if nt:
+            qt_a = np.fromiter(itertools.chain.from_iterable(query_weights), dtype=np.int32, count=nt)                   # dict iteration = keys
+            qw_a = np.fromiter(itertools.chain.from_iterable(map(dict.values, query_weights)), dtype=np.float64, count=nt)
+        else:
+            qt_a = np.zeros(1, dtype=np.int32)
+            qw_a = np.zeros(1, dtype=np.float64)
         qv = np.ascontiguousarray(np.atleast_2d(query_vectors), dtype=np.float32)
         ids = np.empty((nq, k), dtype=np.int32)
         vals = np.empty((nq, k), dtype=np.float64)
