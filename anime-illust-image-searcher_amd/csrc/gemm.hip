@@ -1889,7 +1889,11 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
     {   // A/B: HIPTS_GEMM_DW_MASK = bit mask over epilogue numbers whose launches take the two-workgroups-per-CU 256 x 128 kernel (its
         // residents run out of phase, so one's epilogue overlaps the other's main loop; it pays only where the epilogue is long and K short)
         static const unsigned dw_mask = getenv("HIPTS_GEMM_DW_MASK") ? (unsigned)strtoul(getenv("HIPTS_GEMM_DW_MASK"), nullptr, 0) : 0u;
+#ifdef HIPTS_X_DW_STAT      // timing probe only (the statistics come out wrong): lets the masked epilogues take the dw kernel even with stat_part
+        if (variant == 1 && ((dw_mask >> (int)EPI) & 1u) && a.M > BM) variant = 4;
+#else
         if (variant == 1 && ((dw_mask >> (int)EPI) & 1u) && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && a.stat_part)) variant = 4;
+#endif
     }
     HIPTS_REQUIRE(!a.f16 || variant == 1 || variant == 4, "half-precision operands are only built for the pp and dw GEMM loops");
     if (variant == 4) {
