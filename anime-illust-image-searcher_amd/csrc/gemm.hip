@@ -1884,7 +1884,9 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         // = 90 tiles) leaves most of the chip idle; the 256 x 128 two-per-CU kernel has 2 x the tiles and
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
         const int cus0 = cus_dev;
-        if ((long)tiles_m * ((a.N + BN - 1) / BN) < cus0 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_SWIGLU) && a.stat_part)) variant = 4;
+        static const bool auto_dw = !(getenv("HIPTS_GEMM_AUTO_DW") && atoi(getenv("HIPTS_GEMM_AUTO_DW")) == 0);      // A/B
+        // (round 3: only below 3/4 of the CUs -- EVA02-L's q|k|v at batch 10 is 252 tiles on 256 CUs and runs 1 % faster on the persistent kernel)
+        if (auto_dw && (long)tiles_m * ((a.N + BN - 1) / BN) * 4 < (long)cus0 * 3 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_SWIGLU) && a.stat_part)) variant = 4;
     }
     {   // A/B: HIPTS_GEMM_DW_MASK = bit mask over epilogue numbers whose launches take the two-workgroups-per-CU 256 x 128 kernel (its
         // residents run out of phase, so one's epilogue overlaps the other's main loop; it pays only where the epilogue is long and K short)
