@@ -84,7 +84,10 @@ def test_bm25_libm_idf_within_one_ulp(corpus20k):
 
 
 # --------------------------------------------------------------------------------- similarity
-@pytest.mark.parametrize("D,K,nq", [(1000, 300, 1), (4099, 300, 5), (3000, 768, 33), (64, 8, 2), (31, 12, 1)])
+# more than 32 queries take sim_mfma_wide_kernel (up to 256 queries per pass over the index, 2 / 4 / 8 query blocks per wave): ragged
+# document and query counts, K % 8 == 4 and == 0, one and two wide passes, a 32-query remainder on the narrow kernel
+@pytest.mark.parametrize("D,K,nq", [(1000, 300, 1), (4099, 300, 5), (3000, 768, 33), (64, 8, 2), (31, 12, 1),
+                                    (5, 300, 40), (40, 4, 64), (1000, 300, 100), (4099, 300, 256), (777, 12, 300), (100, 8, 289), (100, 8, 288)])
 def test_similarity_bit_exact(D, K, nq):
     from hiptagsearch.index import Similarity
     from oracle import search as osearch
