@@ -6,9 +6,10 @@ synthetic checkpoint (unit-variance LayerNorm outputs after every SwiGLU, 24 blo
 residual branches O(1), so 16-bit operand rounding reaches the logits at full size.  Measured (round 2, LayerNorms and RoPE
 folded into the GEMM epilogues): IEEE-half operands -- the DEFAULT of EvaTagger -- max |dlogit| 2.9e-4 (tiny) / 2.1e-3
 (EVA02-L, logit rms 0.65); bf16 operands 2.3e-3 / 1.7e-2: the 8x ratio of the two mantissas, i.e. rounding only.
-Bounds = measured + 20 %: half 5e-4 / 2.5e-3, bf16 4e-3 / 2.1e-2, and cosine(logits, oracle) >= 0.9995 (bf16) / 0.99999 (half)."""
+Bounds = measured + 20 %: half 5e-4 / 3e-3 (2.1e-3 on the default schedule, 2.6e-3 with HIPTS_EVA_ROWSTAT_KERNEL=1 and one stream: the
+order in which the LayerNorm partial sums are added), bf16 4e-3 / 2.1e-2, and cosine(logits, oracle) >= 0.9995 (bf16) / 0.99999 (half)."""
 
-TOL = {"tiny": {0: 4e-3, 1: 5e-4}, "large": {0: 2.1e-2, 1: 2.5e-3}}
+TOL = {"tiny": {0: 4e-3, 1: 5e-4}, "large": {0: 2.1e-2, 1: 3e-3}}
 COS = {0: 0.9995, 1: 0.99999}
 
 
