@@ -792,7 +792,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
         for (int i = 0; i < ns; ++i)
             if (!h->sub[i]) {
                 HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking));
-                HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+                if (!h->ev_join[i]) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
             }
         HIPTS_HIP(hipEventRecord(h->ev_fork, s));
         for (int i = 0; i < ns; ++i) {
@@ -808,6 +808,13 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     } else {
         HIPTS_TRY(vit_run_images(h, in_dev, is_u8, 0, batch, lg, pr, s, false));
         h->last_ns = 0;
+        if (h->deferred_join && dev_out) {
+            // one stream (small batch, HIPTS_VIT_STREAMS=1): the work sits on the caller's stream, but hipts_vit_join's contract is that
+            // ANY consuming stream may join -- give it an event to wait for
+            if (!h->ev_join[0]) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));
+            HIPTS_HIP(hipEventRecord(h->ev_join[0], s));
+            h->last_ns = 1;
+        }
     }
     if (!dev_out) {
         const size_t bytes = (size_t)batch * c.num_classes * 4;
