@@ -425,17 +425,17 @@ __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __rest
         qs[buf][4 * sh + 2][sj] = v.z;
         qs[buf][4 * sh + 3][sj] = v.w;
     };
-    for (int64_t st = blockIdx.x; st * 8 < ntiles; st += gridDim.x) {
-        const int64_t tile = st * 8 + wave;
-        const bool tv = tile < ntiles;           // wave-uniform; a wave without a tile still stages and meets the barriers
+    // One walk over K for this wave: document tile `tile` (tv: the wave has one) against NB query blocks starting at block qb0.
+    auto walk = [&](auto nb_c, int64_t tile, bool tv, int qb0) __attribute__((always_inline)) {
+        constexpr int NB = decltype(nb_c)::value;
         const float4* __restrict__ trow = tiled + (tv ? tile : ntiles - 1) * KQ * 32 + r;
-        f32x16 acc[NQB];
+        f32x16 acc[NB];
 #pragma unroll
-        for (int b = 0; b < NQB; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[b][i] = 0.0f;
         float4 d0 = trow[0], d1 = 1 < KQ ? trow[32] : zero4;
-        store_q(0, load_q(0));                   // buffer 0 was last read before the final barrier of the previous super-tile
+        store_q(0, load_q(0));                   // buffer 0 was last read before the final barrier of the previous walk
         __syncthreads();
         const int nfull = KQ >> 1;               // chunks of 8 k; K % 8 == 4 leaves a chunk of 4 behind them
         for (int c = 0; c < nfull; ++c) {
@@ -447,16 +447,16 @@ __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __rest
                 e1 = 2 * c + 3 < KQ ? trow[(2 * c + 3) * 32] : zero4;
             }
             const float b0 = h ? d0.y : d0.x, b1 = h ? d0.w : d0.z, b2 = h ? d1.y : d1.x, b3 = h ? d1.w : d1.z;
-            const float* qrow = &qs[c & 1][h][r];
+            const float* qrow = &qs[c & 1][h][qb0 * 32 + r];
             // k-pair by k-pair across the blocks: consecutive MFMAs are independent (per block the k order is unchanged)
 #pragma unroll
-            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32], b0, acc[b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32], b0, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 2 * SIMW_QS], b1, acc[b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 2 * SIMW_QS], b1, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 4 * SIMW_QS], b2, acc[b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 4 * SIMW_QS], b2, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NQB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 6 * SIMW_QS], b3, acc[b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[b * 32 + 6 * SIMW_QS], b3, acc[b], 0, 0, 0);
             if (more) {
                 store_q((c + 1) & 1, qn);
                 d0 = e0;
@@ -466,14 +466,14 @@ __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __rest
         }
         if (KQ & 1) {                            // the chunk of 4 (staged by the last iteration above, or by the prologue when K == 4)
             const float b0 = h ? d0.y : d0.x, b1 = h ? d0.w : d0.z;
-            const float* qrow = &qs[nfull & 1][h][r];
+            const float* qrow = &qs[nfull & 1][h][qb0 * 32 + r];
 #pragma unroll
-            for (int b = 0; b < NQB; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const float* qk = qrow + b * 32;
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[0], b0, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(qk[2 * SIMW_QS], b1, acc[b], 0, 0, 0);
             }
-            __syncthreads();                     // the next super-tile's prologue writes buffer 0 again
+            __syncthreads();                     // the next walk's prologue writes buffer 0 again
         }
         const int64_t doc = tile * 32 + r;
         if (tv && doc < D) {
@@ -483,20 +483,53 @@ __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __rest
             int64_t old = out_ld;
             int nqv = nq;
             asm volatile("" : "+s"(old), "+s"(nqv));
-            float* __restrict__ base = out + (int64_t)(4 * h) * old + doc;
+            float* __restrict__ base = out + (int64_t)(qb0 * 32 + 4 * h) * old + doc;
+            const int nleft = nqv - qb0 * 32;    // queries from this wave's first block on
 #pragma unroll
-            for (int b = 0; b < NQB; ++b) {
-                if (b * 32 + 32 <= nqv) {                      // uniform: a whole block of queries, no per-lane test
+            for (int b = 0; b < NB; ++b) {
+                if (b * 32 + 32 <= nleft) {                     // uniform: a whole block of queries, no per-lane test
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) base[(int64_t)(b * 32 + (reg & 3) + 8 * (reg >> 2)) * old] = acc[b][reg];
-                } else if (b * 32 < nqv) {
+                } else if (b * 32 < nleft) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int cqi = b * 32 + (reg & 3) + 8 * (reg >> 2);
-                        if (cqi + 4 * h < nqv) base[(int64_t)cqi * old] = acc[b][reg];
+                        if (cqi + 4 * h < nleft) base[(int64_t)cqi * old] = acc[b][reg];
                     }
                 }
             }
+        }
+    };
+    // Full rounds: every wave of every workgroup one tile against all NQB blocks.  What is left over (fewer tiles than wave slots) may be
+    // split f ways across the query blocks (f waves per tile, NQB / f blocks each) when that shortens the tail.  A walk costs about
+    // a + b NB with a = 2.5 b (measured at 100 k x 300, 256 queries: 114 us for NB = 8, 38 us for NB = 1 -- the per-chunk load -> LDS ->
+    // barrier chain does not shrink with the MFMAs), so the split pays for small indices that would leave most workgroups without a tile
+    // (32 tiles: one walk of 1 block on 32 workgroups instead of 8 blocks on 4), not for 3125 tiles on 2048 slots (measured: 302 us with
+    // f = 8 against 228 us unsplit).
+    const int64_t G = gridDim.x, slots = 8 * G;
+    const int64_t full_rounds = ntiles / slots;
+    for (int64_t rd = 0; rd < full_rounds; ++rd) walk(std::integral_constant<int, NQB>{}, (rd * G + blockIdx.x) * 8 + wave, true, 0);
+    const int64_t base_tile = full_rounds * slots, rem = ntiles - base_tile;
+    if (rem > 0) {
+        int f = 1;
+        int64_t best = (rem + slots - 1) / slots * (5 + 2 * NQB);        // walks x (a + b NB), a : b = 5 : 2
+        for (int c = 2; c <= NQB; c *= 2) {
+            const int64_t len = (rem * c + slots - 1) / slots * (5 + 2 * (NQB / c));
+            if (len < best) {
+                best = len;
+                f = c;
+            }
+        }
+        const int64_t jobs = rem * f, walks = (jobs + slots - 1) / slots;
+        for (int64_t w = 0; w < walks; ++w) {
+            const int64_t J = (w * G + blockIdx.x) * 8 + wave;
+            const bool tv = J < jobs;
+            const int64_t tile = base_tile + (tv ? J / f : 0);
+            const int grp = (int)(J % f);
+            if (f == 1) walk(std::integral_constant<int, NQB>{}, tile, tv, 0);
+            if constexpr (NQB >= 2) { if (f == 2) walk(std::integral_constant<int, NQB / 2>{}, tile, tv, grp * (NQB / 2)); }
+            if constexpr (NQB >= 4) { if (f == 4) walk(std::integral_constant<int, NQB / 4>{}, tile, tv, grp * (NQB / 4)); }
+            if constexpr (NQB >= 8) { if (f == 8) walk(std::integral_constant<int, NQB / 8>{}, tile, tv, grp * (NQB / 8)); }
         }
     }
 }
@@ -1651,15 +1684,16 @@ int launch_sim(const float* index, const float* tiled, int64_t D, int K, const f
     const bool use_wide = sim_wide_enabled();
     int q_done = 0;
     if (tiled && use_tiled && use_wide && K % 4 == 0) {
-        const int wgrid = (int)std::min<int64_t>((ntiles + 7) / 8, 256);
+        // up to one workgroup per CU; a small index still fills them: the kernel splits the tiles it has across the query blocks
+        auto grid_for = [&](int nqb) { return (int)std::max<int64_t>(1, std::min<int64_t>((ntiles * nqb + 7) / 8, 256)); };
         while (nq - q_done > 32) {
             const int n = std::min(256, nq - q_done);
             const float4* t4 = reinterpret_cast<const float4*>(tiled);
             const float* qp = q_dev + (int64_t)q_done * K;
             float* op = out_dev + (int64_t)q_done * out_ld;
-            if (n <= 64) sim_mfma_wide_kernel<2><<<wgrid, 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
-            else if (n <= 128) sim_mfma_wide_kernel<4><<<wgrid, 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
-            else sim_mfma_wide_kernel<8><<<wgrid, 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            if (n <= 64) sim_mfma_wide_kernel<2><<<grid_for(2), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            else if (n <= 128) sim_mfma_wide_kernel<4><<<grid_for(4), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            else sim_mfma_wide_kernel<8><<<grid_for(8), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
             HIPTS_LAUNCH_CHECK();
             q_done += n;
         }
