@@ -95,6 +95,10 @@ def test_tagging_cli_vit_b16_shards_two_ranks(tmp_path):
     os.remove(tmp_path / "tags-wd-tagger.txt")
     _torchrun(2, "tagging.py", ["--dir", "imgs", "--workers", "2", "--batch", "8"], tmp_path)
     assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
+    # ... and with decode-only workers, the pad + resize on each rank's device
+    os.remove(tmp_path / "tags-wd-tagger.txt")
+    _torchrun(2, "tagging.py", ["--dir", "imgs", "--workers", "2", "--batch", "8", "--gpu-resize"], tmp_path)
+    assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
 
 
 def test_tagging_cli_synthetic_corpus_and_wide_rows(tmp_path):
