@@ -693,6 +693,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     // members it contains the top k and the sort below finishes the job; otherwise the exact path runs.
     bool done_fast = false;
     int fill_need = 0;        // results still missing after the candidates: the lowest-index -inf scores (candidate path only)
+    TOPK_STAMP(12);
     if (pre) {
         // Candidates handed on by search1_collect_kernel (per-workgroup slots): every score whose digit is at or above a threshold
         // digit, i.e. all scores >= a pivot.  With at least k and at most CAP of them the top k are among them.  With fewer than
@@ -740,6 +741,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
             if (c < k) fill_need = k - c;
         }
         __syncthreads();
+        TOPK_STAMP(13);
         search1_state_clear(pre);               // the maxima slots are zero again for the next query (search1_combine_kernel has read them)
         search1_state_debug(pre, (uint32_t)c, done_fast ? 1u : 0u);
     }
@@ -1185,6 +1187,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
             taken += total;
         }
     }
+    TOPK_STAMP(14);
     if (done_flag) {
         // The results above went to pinned host memory.  Publish them to the HOST without waiting for the runtime's completion
         // signal (a hipStreamSynchronize wake-up costs ~10 us): every storing thread fences at system scope, the workgroup meets,
@@ -1193,6 +1196,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
         __syncthreads();
         if (tid == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    TOPK_STAMP(15);
 }
 
 // =============================================================================================
@@ -1911,7 +1915,8 @@ int hipts_query_profile_read(hipts_bm25_t* h, int category, double* total_ms, in
 int hiptsdbg_topk_stamps(unsigned long long* host16) {
 #ifdef HIPTS_X_TOPK_STAMPS
     HIPTS_HIP(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_topk_stamps), 16 * 8));
-    HIPTS_HIP(hipMemcpyFromSymbol(host16 + 8, HIP_SYMBOL(g_bm25_stamps), 8 * 8));      // slots 8..11: the BM25 kernel's clear / postings / mask+max
+    if (getenv("HIPTS_DBG_BM25_STAMPS"))      // slots 8..11 <- the BM25 kernel's clear / postings / mask+max (tools/bm25_stamps.py)
+        HIPTS_HIP(hipMemcpyFromSymbol(host16 + 8, HIP_SYMBOL(g_bm25_stamps), 4 * 8));
     return HIPTS_OK;
 #else
     (void)host16;

@@ -2,6 +2,7 @@
 """Development aid (gpurun only, -DHIPTS_X_TOPK_STAMPS=<workgroup> build): phases of one workgroup (= one query) of bm25_postings_kernel in a
 256-query batch of the bench corpus."""
 import ctypes, os, sys
+os.environ["HIPTS_DBG_BM25_STAMPS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
 import numpy as np, torch
