@@ -198,6 +198,32 @@ def test_search_rank_equal(corpus20k):
         assert vals[i].tobytes() == wv.tobytes()
 
 
+@pytest.mark.parametrize("D,V", [(300, 60), (9000, 800), (20000, 2000)])
+def test_search_without_stored_rows_equals_search_with_them(D, V):
+    """hipts_search for a batch, final_out absent: the top-k kernel combines BM25 and index scores where it reads them (no combine launch,
+    no stored rows).  Same ids and bit-identical scores as the call that stores the combined rows -- the form test_search_rank_equal pins to
+    the oracle -- for k below / above the candidate capacity, plain / required / excluded terms, indexes below and above the fast path's
+    8192-document floor (the exact radix select reads its scores through the same expression)."""
+    import torch
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    ptr, terms = synth.tag_corpus(D, V, seed=7)
+    bm = BM25Index(ptr, terms, V)
+    index = Similarity("idx", None, 300, capacity=D)
+    index.add_matrix(synth.index_vectors(D, 300, seed=8))
+    eng = SearchEngine(None, index, {}, bm, [])
+    qs = [dict(q) for q in synth.queries(70, V, seed=9, head=min(V, 300))]
+    qv = np.random.default_rng(3).standard_normal((len(qs), 300)).astype(np.float32)
+    for k in (5, 100, min(1024, D)):
+        final_dev = torch.empty((len(qs), D), dtype=torch.float64, device="cuda")
+        ids_a, vals_a = eng.score_topk(qs, qv, k, final_out=final_dev)
+        ids_b, vals_b = eng.score_topk(qs, qv, k)
+        np.testing.assert_array_equal(ids_b, ids_a, err_msg="D %d k %d" % (D, k))
+        assert vals_b.tobytes() == vals_a.tobytes(), (D, k)
+
+
 def test_search_one_query_path_is_bit_equal_to_the_batched_path(corpus20k):
     """hipts_search with nq == 1 takes the one-query path (thread-per-document BM25 in the reference's document-major form,
     fmaf-chain index product, sampled threshold + candidate ranking): ids, scores and the combined score row must equal the
