@@ -79,10 +79,42 @@ __device__ __forceinline__ void wait_vm() {
 
 // One workgroup's pass over its query blocks with the fixed-reference softmax.  Returns true when a row sum left its window
 // (nothing is stored then; the workgroup repeats the blocks with attn2_classic).
+// The low halves of four values whose high halves are `hi`: value - (float)hi, rounded once (the hi | lo operand split: two 16-bit
+// halves carry 22 significant bits of an IEEE-half operand, 16 of a bf16 one; the consumer multiplies them against [W | W]).
+template <bool F16>
+__device__ __forceinline__ bf16x4 pack4_lo(float a, float b, float c, float d, bf16x4 hi) {
+    return pack4<F16>(a - from_op<F16>(hi[0]), b - from_op<F16>(hi[1]), c - from_op<F16>(hi[2]), d - from_op<F16>(hi[3]));
+}
+
+// Output quads 2 kp (even) and 2 kp + 1 (odd) of one query row, normalised, as one 16 B store per lane (attn2_body's comment); with
+// lo_off != 0 the low halves follow at op + lo_off (hipts_vit_config_t.operand_f16 bit 4: the attention output as a hi | lo pair).
+template <bool F16>
+__device__ __forceinline__ void store_o_pair(const f32x16& oe, const f32x16& oo, int kp, float inv, int h, bool valid, bf16_t* op, int lo_off) {
+    const int ke = 2 * kp, ko = 2 * kp + 1;
+    const int ie = 4 * (ke & 3), io = 4 * (ko & 3);
+    const float e0 = oe[ie] * inv, e1 = oe[ie + 1] * inv, e2 = oe[ie + 2] * inv, e3 = oe[ie + 3] * inv;
+    const float f0 = oo[io] * inv, f1 = oo[io + 1] * inv, f2 = oo[io + 2] * inv, f3 = oo[io + 3] * inv;
+    const bf16x4 we = pack4<F16>(e0, e1, e2, e3), wo = pack4<F16>(f0, f1, f2, f3);
+    const int kq = h ? ko : ke;              // the chunk this lane owns after the swap: d = 32 (kq >> 2) + 8 (kq & 3) .. + 7
+    bf16_t* dst = op + 32 * (kq >> 2) + 8 * (kq & 3);
+    {
+        const uint2 ue = __builtin_bit_cast(uint2, we), uo = __builtin_bit_cast(uint2, wo);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
+        if (valid) *reinterpret_cast<uint4*>(dst) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+    if (lo_off) {                            // uniform over the launch
+        const uint2 ue = __builtin_bit_cast(uint2, pack4_lo<F16>(e0, e1, e2, e3, we)), uo = __builtin_bit_cast(uint2, pack4_lo<F16>(f0, f1, f2, f3, wo));
+        const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
+        if (valid) *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+
 template <bool F16, int QB, int NW>
 __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
-                                           int bh, int blk0, int nblk, int out_stride) {
+                                           int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off) {
     constexpr int PCS = 8 / NW;                      // 1 KiB pieces of a K (and of a V) tile per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -281,32 +313,15 @@ __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t
     for (int qb = 0; qb < QB; ++qb) {
         const float inv = l_run[qb];
         const int qi = q0 + 32 * qb + r;
-        bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+        bf16_t* op = out + ((size_t)b * out_stride + qi) * out_ld + head * HD;
         // quad kq (0 .. 7) of this lane = registers 4 (kq & 3) .. + 3 of blk = kq >> 2 -> d = 32 blk + 8 (kq & 3) + 4 h + (0 .. 3): the two
         // halves of a query's 16 B chunk sit in lanes r and r + 32.  Swap so that lane h = 0 holds whole chunks of the even quads and
         // lane h = 1 of the odd ones (cdna_hip_programming.md T21), then 4 stores of 16 B per lane instead of 8 of 8 B.
+        // v_permlane32_swap a, b: a.lanes[32..63] <-> b.lanes[0..31].  With a = the even quad's word and b = the odd quad's:
+        // afterwards lane h = 0 holds (a = its own even word, b = its partner's even word) = d + 0..3 | d + 4..7 of the even chunk,
+        // lane h = 1 holds (a = its partner's odd word, b = its own odd word) = the odd chunk, in that order as well.
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) {
-            const int ke = 2 * kp, ko = 2 * kp + 1;
-            const f32x16& oe = o[qb][ke >> 2];
-            const f32x16& oo = o[qb][ko >> 2];
-            const int ie = 4 * (ke & 3), io = 4 * (ko & 3);
-            const bf16x4 we = pack4<F16>(oe[ie] * inv, oe[ie + 1] * inv, oe[ie + 2] * inv, oe[ie + 3] * inv);
-            const bf16x4 wo = pack4<F16>(oo[io] * inv, oo[io + 1] * inv, oo[io + 2] * inv, oo[io + 3] * inv);
-            const uint2 ue = __builtin_bit_cast(uint2, we), uo = __builtin_bit_cast(uint2, wo);
-            // v_permlane32_swap a, b: a.lanes[32..63] <-> b.lanes[0..31].  With a = the even quad's word and b = the odd quad's:
-            // afterwards lane h = 0 holds (a = its own even word, b = its partner's even word) = d + 0..3 | d + 4..7 of the even chunk,
-            // lane h = 1 holds (a = its partner's odd word, b = its own odd word) = the odd chunk, in that order as well.
-            uint32_t a0 = ue.x, b0 = uo.x, a1 = ue.y, b1 = uo.y;
-            {
-                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                a0 = r0[0]; b0 = r0[1];
-                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                a1 = r1[0]; b1 = r1[1];
-            }
-            const int kq = h ? ko : ke;              // the chunk this lane now owns: d = 32 (kq >> 2) + 8 (kq & 3) .. + 7
-            if (qi < tokens) *reinterpret_cast<uint4*>(op + 32 * (kq >> 2) + 8 * (kq & 3)) = make_uint4(a0, a1, b0, b1);
-        }
+        for (int kp = 0; kp < 4; ++kp) store_o_pair<F16>(o[qb][(2 * kp) >> 2], o[qb][(2 * kp + 1) >> 2], kp, inv, h, qi < tokens, op, lo_off);
     }
     return false;
 }
@@ -317,7 +332,7 @@ __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t
 template <bool F16, int NW>
 __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
-                                               int bh, int blk0, int nblk, int out_stride) {
+                                               int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off) {
     constexpr int PCS = 8 / NW;
     constexpr int SNS = HIPTS_ATTN2_SEQ_SLOTS;       // ring slots per operand: 2 = one tile in flight, 3 = two
     constexpr int VB = SNS * TILE;                   // V slots behind the K slots
@@ -520,20 +535,9 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 #endif
     const float inv = 1.0f / l_tot;
     const int qi = q0 + r;
-    bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+    bf16_t* op = out + ((size_t)b * out_stride + qi) * out_ld + head * HD;
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) {                 // see attn2_body
-        const int ke = 2 * kp, ko = 2 * kp + 1;
-        const f32x16& oe = o[ke >> 2];
-        const f32x16& oo = o[ko >> 2];
-        const int ie = 4 * (ke & 3), io = 4 * (ko & 3);
-        const uint2 ue = __builtin_bit_cast(uint2, pack4<F16>(oe[ie] * inv, oe[ie + 1] * inv, oe[ie + 2] * inv, oe[ie + 3] * inv));
-        const uint2 uo = __builtin_bit_cast(uint2, pack4<F16>(oo[io] * inv, oo[io + 1] * inv, oo[io + 2] * inv, oo[io + 3] * inv));
-        const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
-        const int kq = h ? ko : ke;
-        if (qi < tokens) *reinterpret_cast<uint4*>(op + 32 * (kq >> 2) + 8 * (kq & 3)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-    }
+    for (int kp = 0; kp < 4; ++kp) store_o_pair<F16>(o[(2 * kp) >> 2], o[(2 * kp + 1) >> 2], kp, inv, h, qi < tokens, op, lo_off);      // see attn2_body
     return false;
 }
 
@@ -544,7 +548,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 template <bool F16, int QB, int NW>
 __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int bh,
-                                           int blk0, int nblk, int out_stride) {
+                                           int blk0, int nblk, int out_stride, int out_ld, int lo_off) {
     constexpr int PCS = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -638,14 +642,17 @@ __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf1
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
         const int qi = q0 + r;
-        bf16_t* op = out + ((size_t)b * out_stride + qi) * (heads * HD) + head * HD;
+        bf16_t* op = out + ((size_t)b * out_stride + qi) * out_ld + head * HD;
         if (qi < tokens) {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) =
-                        pack4<F16>(o[blk][4 * g4] * inv, o[blk][4 * g4 + 1] * inv, o[blk][4 * g4 + 2] * inv, o[blk][4 * g4 + 3] * inv);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float x0 = o[blk][4 * g4] * inv, x1 = o[blk][4 * g4 + 1] * inv, x2 = o[blk][4 * g4 + 2] * inv, x3 = o[blk][4 * g4 + 3] * inv;
+                    const bf16x4 hi = pack4<F16>(x0, x1, x2, x3);
+                    *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) = hi;
+                    if (lo_off) *reinterpret_cast<bf16x4*>(op + lo_off + blk * 32 + 8 * g4 + 4 * h) = pack4_lo<F16>(x0, x1, x2, x3, hi);
+                }
         }
     }
 }
@@ -653,7 +660,7 @@ __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf1
 template <bool F16, int QB, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) void attn2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                         bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int chunks, int out_stride,
-                                                        int classic) {
+                                                        int classic, int out_ld, int lo_off) {
     // ALL of the kernel's LDS is this one array (ring + the fallback flag word): with a second LDS object in the kernel -- __syncthreads_or()
     // brings one -- hipcc puts an s_waitcnt vmcnt(0) in front of the first ds_read of every tile step and the DMA ring never runs ahead
     // (cdna_hip_programming.md section 5, "three .s-level traps" (a); seen in this kernel's .s).
@@ -673,21 +680,21 @@ __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) voi
     // classic != 0 (HIPTS_ATTN_CLASSIC=1): the fallback everywhere (A/B runs, its own test)
     if (!classic) {
         bool bad;
-        if constexpr (MODE == 1) bad = attn2_seq_body<F16, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride);
-        else bad = attn2_body<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride);
+        if constexpr (MODE == 1) bad = attn2_seq_body<F16, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off);
+        else bad = attn2_body<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off);
         if (bad) *redo = 1;
     }
     __syncthreads();
     // a wave whose row sum left the window stored nothing; the workgroup (its waves stage K / V together) repeats its blocks classically
-    if (*redo) attn2_classic<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride);
+    if (*redo) attn2_classic<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off);
 }
 
 template <bool F16, int QB, int NW, int MODE>
 int launch_cfg(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, int ost,
-               int classic, hipStream_t s) {
+               int classic, int out_ld, int lo_off, hipStream_t s) {
     const int nb = (tokens + 32 * QB - 1) / (32 * QB);
     const int chunks = (nb + NW - 1) / NW;
-    attn2_kernel<F16, QB, NW, MODE><<<batch * heads * chunks, NW * 64, 0, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic);
+    attn2_kernel<F16, QB, NW, MODE><<<batch * heads * chunks, NW * 64, 0, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic, out_ld, lo_off);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
@@ -697,15 +704,17 @@ int launch_cfg(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, i
 // q, k, v: [batch * heads][tokens_pad][64] 16-bit (q pre-scaled by head_dim^-0.5 log2 e; rows past `tokens` zero), out [batch * out_stride][heads * 64].
 // variant: 0 = default; 1: 4 waves x 64 rows, 2: 8 waves x 32 rows, 3: 4 waves x 32 rows (A/B, hiptsdbg_attention2_*).
 int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, bool f16,
-                      hipStream_t s, int out_tokens_stride, int variant) {
+                      hipStream_t s, int out_tokens_stride, int variant, int split_lo) {
     const int ost = out_tokens_stride > 0 ? out_tokens_stride : tokens;
+    // split_lo: rows of `out` are [hi (heads * 64) | lo (heads * 64)] -- the output as a hi | lo pair of 16-bit halves
+    const int out_ld = split_lo ? 2 * heads * HD : heads * HD, lo_off = split_lo ? heads * HD : 0;
     HIPTS_REQUIRE(tokens_pad % KV == 0 && tokens_pad >= tokens && tokens >= 1, "attention: tokens_pad must be a multiple of %d", KV);
     static const int classic = (getenv("HIPTS_ATTN_CLASSIC") && atoi(getenv("HIPTS_ATTN_CLASSIC"))) ? 1 : 0;
     static const int env_variant = getenv("HIPTS_ATTN2") ? atoi(getenv("HIPTS_ATTN2")) : 0;
     if (variant == 0) variant = env_variant ? env_variant : 5;
 #define HIPTS_ATTN2_CASE(QB_, NW_, MODE_)                                                                                        \
-    return f16 ? launch_cfg<true, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, s)                      \
-               : launch_cfg<false, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, s)
+    return f16 ? launch_cfg<true, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, s)                      \
+               : launch_cfg<false, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, s)
     switch (variant) {
         case 1: HIPTS_ATTN2_CASE(2, 4, 0);
         case 2: HIPTS_ATTN2_CASE(1, 8, 0);

@@ -49,6 +49,7 @@ struct hipts_eva {
     std::vector<std::string> missing;
     DevBuf img_in, a0, tmp, x, xn, q, k, v, att, g1, stat_part, rowstat, xstat, pool_part, pooled2, logits, probs;
     bool fold_ln = false, fold_dirty = true;      // as in the ViT forward (vit.hip)
+    bool split_att = false;                       // cfg.operand_f16 bit 4 (HIPTS_OPERAND_SPLIT_ATT), as in the ViT forward
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
 };
@@ -215,7 +216,7 @@ int alloc_zero(DevBuf& buf, size_t bytes) {
 int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int batch, float* lg, float* pr, hipStream_t s, bool shared_chip) {
     const auto& c = h->cfg;
     const int S = c.image_size, D = c.dim, P = c.patch, H = c.heads, T = h->T, TS = h->TS, Tp = h->Tp, np = h->np;
-    const bool f16 = c.operand_f16 != 0;
+    const bool f16 = (c.operand_f16 & 1) != 0;
     const int M = batch * TS;
     in_dev = (const char*)in_dev + (size_t)i0 * S * S * 3 * (is_u8 ? 1 : 4);
     const size_t r0 = (size_t)i0 * TS, qo = (size_t)i0 * H * Tp * 64;
@@ -226,7 +227,8 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     bf16_t* q_p = h->q.as<bf16_t>() + qo;
     bf16_t* k_p = h->k.as<bf16_t>() + qo;
     bf16_t* v_p = h->v.as<bf16_t>() + qo;
-    bf16_t* att_p = h->att.as<bf16_t>() + r0 * D;
+    const int att_k = h->split_att ? 2 * D : D;
+    bf16_t* att_p = h->att.as<bf16_t>() + r0 * att_k;
     bf16_t* g1_p = h->g1.as<bf16_t>() + r0 * h->HK;
     const int sblocks = (2 * h->HK + 255) / 256;                               // 256-column tiles of the fc1 launch: one partial (sum, sum of squares) pair per tile and row
     float* stat_p = h->stat_part.as<float>() + 2 * (size_t)sblocks * r0;      // [sblocks][M] float2, this sub-batch's region
@@ -279,11 +281,11 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.rope = h->rope.as<float>(); g.rope_tokens = np;  // 2-D rotary embedding on the fp32 result, in the epilogue
         if (ln1_folded) folded(g, L.qkv_u.as<float>(), L.qkv_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_QK_ROPE, g, s));
-        HIPTS_TRY(launch_attention2(q_p, k_p, v_p, att_p, batch, H, T, Tp, f16, s, TS));
+        HIPTS_TRY(launch_attention2(q_p, k_p, v_p, att_p, batch, H, T, Tp, f16, s, TS, 0, h->split_att ? 1 : 0));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
-        g.A = att_p; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = D; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
+        g.A = att_p; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = att_k; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
         if (fold) {
             g.out_bf16 = xn; g.ln_gamma = L.ln2_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
             HIPTS_TRY(launch_gemm(EPI_RESID_XG, g, s));
@@ -357,7 +359,7 @@ int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
     float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
     if (h->fold_ln && h->fold_dirty) {
-        const bool f16w = c.operand_f16 != 0;
+        const bool f16w = (c.operand_f16 & 1) != 0;
         for (auto& L : h->layers) {
             HIPTS_TRY(launch_fold_ln(L.qkv_w.as<bf16_t>(), f16w, L.ln1_g.as<float>(), L.ln1_b.as<float>(), L.qkv_b.as<float>(), L.qkv_u.as<float>(),
                                      L.qkv_c.as<float>(), 3 * c.dim, c.dim, s));
@@ -412,6 +414,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     auto* h = new hipts_eva();
     h->device = device;
     h->cfg = *cfg;
+    h->split_att = (cfg->operand_f16 & HIPTS_OPERAND_SPLIT_ATT) != 0;
     const int D = cfg->dim, B = cfg->max_batch;
     h->grid = cfg->image_size / cfg->patch;
     h->np = h->grid * h->grid;
@@ -428,7 +431,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     int st = 0;
     if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->v, qk)) ||
-        (st = alloc_zero(h->att, M * D * 2)) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
+        (st = alloc_zero(h->att, M * D * 2 * (h->split_att ? 2 : 1))) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
         (st = h->stat_part.alloc((size_t)((2 * h->HK + 255) / 256) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
         (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
         delete h;
@@ -509,7 +512,7 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
     HIPTS_TRY(use_device(h->device));
     const std::string key(key_c);
     const auto& c = h->cfg;
-    const bool f16 = c.operand_f16 != 0;
+    const bool f16 = (c.operand_f16 & 1) != 0;
     const int D = c.dim, P = c.patch, Hd = c.mlp_hidden, C = c.num_classes;
     int st = HIPTS_OK;
 #define EXPECT(n)                                                                                                         \
@@ -558,7 +561,19 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
         else if (t == "attn.v_proj.weight") { EXPECT((int64_t)D * D); st = put_rows16(L.qkv_w, data, D, D, 2 * D, D, f16); }
         else if (t == "attn.q_proj.bias") { EXPECT(D); st = upload(L.qkv_b.as<float>(), data, (size_t)D * 4); }
         else if (t == "attn.v_proj.bias") { EXPECT(D); st = upload(L.qkv_b.as<float>() + 2 * D, data, (size_t)D * 4); }
-        else if (t == "attn.proj.weight") { EXPECT((int64_t)D * D); st = upload_matrix16(L.proj_w, data, D, D, round_up(D, 256), f16); }
+        else if (t == "attn.proj.weight") {
+            EXPECT((int64_t)D * D);
+            if (h->split_att) {      // [W | W] against the (hi | lo) halves of the attention output
+                std::vector<float> dup((size_t)D * 2 * D);
+                for (int n = 0; n < D; ++n) {
+                    memcpy(&dup[(size_t)n * 2 * D], &data[(size_t)n * D], (size_t)D * 4);
+                    memcpy(&dup[(size_t)n * 2 * D + D], &data[(size_t)n * D], (size_t)D * 4);
+                }
+                st = upload_matrix16(L.proj_w, dup.data(), D, 2 * D, round_up(D, 256), f16);
+            } else {
+                st = upload_matrix16(L.proj_w, data, D, D, round_up(D, 256), f16);
+            }
+        }
         else if (t == "attn.proj.bias") { EXPECT(D); st = up_f32(L.proj_b, data, D); }
         else if (t == "mlp.fc1_g.weight" || t == "mlp.fc1_x.weight") {
             // hidden unit u -> physical row 64 (u / 32) + (u % 32), + 32 for the value half (EPI_SWIGLU)

@@ -65,6 +65,7 @@ struct hipts_vit {
     DevBuf img_in, a0, x, xn, q, k, v, att, hmid, pool_part, pooled2, logits, probs, stat_part;
     bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default; HIPTS_LN_FOLD=0 turns it off)
     bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
+    bool split_att = false;                       // cfg.operand_f16 bit 4: the attention output travels as a hi | lo pair, proj runs K = 2 dim against [W | W]
     int pool_splits = 1;
     static constexpr int kMaxSub = 4;
     int want_sub = 0;                             // hipts_vit_set_sub_batches; 0 = default
@@ -349,6 +350,7 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     h->tokens = grid * grid;
     h->tokens_pad = round_up(h->tokens, 64);
     h->patch_k = cfg->patch * cfg->patch * 3;
+    h->split_att = (cfg->operand_f16 & HIPTS_OPERAND_SPLIT_ATT) != 0;
     h->layers.resize(cfg->depth);
     h->missing = {"patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed", "norm.weight", "norm.bias",
                   "head.weight", "head.bias"};
@@ -365,7 +367,7 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     int st = HIPTS_OK;
     if ((st = h->a0.alloc(M * h->patch_k * 2 * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
         (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->v.alloc(qkv_elems * 2)) ||
-        (st = h->att.alloc(M * D * 2)) || (st = h->hmid.alloc(M * (size_t)cfg->mlp_dim * 2)) ||
+        (st = h->att.alloc(M * D * 2 * (h->split_att ? 2 : 1))) || (st = h->hmid.alloc(M * (size_t)cfg->mlp_dim * 2)) ||
         (st = h->pool_part.alloc(B * h->pool_splits * D * 4)) || (st = h->pooled2.alloc(B * 2 * D * 2)) ||
         (st = h->logits.alloc(B * (size_t)cfg->num_classes * 4)) || (st = h->probs.alloc(B * (size_t)cfg->num_classes * 4))) {
         delete h;
@@ -416,7 +418,7 @@ int hipts_vit_destroy(hipts_vit_t* h) {
 int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, int64_t numel) {
     HIPTS_REQUIRE(h && key_c && data, "hipts_vit_set_tensor: null argument");
     HIPTS_TRY(use_device(h->device));
-    g_upload_f16 = h->cfg.operand_f16 != 0;
+    g_upload_f16 = (h->cfg.operand_f16 & 1) != 0;
     const std::string key(key_c);
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, Mlp = c.mlp_dim, C = c.num_classes;
@@ -493,7 +495,19 @@ int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, i
         else if (sub == "norm2.bias") { EXPECT(D); st = set_f32(L.ln2_b, data, D); }
         else if (sub == "attn.qkv.weight") { EXPECT((int64_t)3 * D * D); st = set_bf16_matrix(L.qkv_w, data, 3 * D, D, round_up(2 * D, 256) + round_up(D, 256) + 256); }
         else if (sub == "attn.qkv.bias") { EXPECT(3 * D); st = set_f32(L.qkv_b, data, 3 * D); }
-        else if (sub == "attn.proj.weight") { EXPECT((int64_t)D * D); st = set_bf16_matrix(L.proj_w, data, D, D, round_up(D, 256)); }
+        else if (sub == "attn.proj.weight") {
+            EXPECT((int64_t)D * D);
+            if (h->split_att) {      // [D][2D] = [W | W]: multiplies the (hi | lo) halves of the attention output
+                std::vector<float> dup((size_t)D * 2 * D);
+                for (int n = 0; n < D; ++n) {
+                    memcpy(&dup[(size_t)n * 2 * D], &data[(size_t)n * D], (size_t)D * 4);
+                    memcpy(&dup[(size_t)n * 2 * D + D], &data[(size_t)n * D], (size_t)D * 4);
+                }
+                st = set_bf16_matrix(L.proj_w, dup.data(), D, 2 * D, round_up(D, 256));
+            } else {
+                st = set_bf16_matrix(L.proj_w, data, D, D, round_up(D, 256));
+            }
+        }
         else if (sub == "attn.proj.bias") { EXPECT(D); st = set_f32(L.proj_b, data, D); }
         else if (sub == "mlp.fc1.weight") { EXPECT((int64_t)Mlp * D); st = set_bf16_matrix(L.fc1_w, data, Mlp, D, round_up(Mlp, 256)); }
         else if (sub == "mlp.fc1.bias") { EXPECT(Mlp); st = set_f32(L.fc1_b, data, Mlp); }
@@ -589,13 +603,14 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
     const int M = nb * T;
-    const bool f16 = c.operand_f16 != 0;
+    const bool f16 = (c.operand_f16 & 1) != 0;
     const size_t r0 = (size_t)i0 * T;                                   // first token row
     const int a0_ld = is_u8 ? h->patch_k : 2 * h->patch_k;
     bf16_t* a0 = h->a0.as<bf16_t>() + r0 * a0_ld;
     float* x = h->x.as<float>() + r0 * D;
     bf16_t* xn = h->xn.as<bf16_t>() + r0 * D;
-    bf16_t* att = h->att.as<bf16_t>() + r0 * D;
+    const int att_k = h->split_att ? 2 * D : D;                          // row width of the attention output: [hi | lo] when split
+    bf16_t* att = h->att.as<bf16_t>() + r0 * att_k;
     bf16_t* hmid = h->hmid.as<bf16_t>() + r0 * c.mlp_dim;
     const size_t qoff = (size_t)i0 * H * Tp * 64;
     bf16_t* q = h->q.as<bf16_t>() + qoff;
@@ -695,11 +710,11 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         }
         {
             ProfScope ps(h, s, PC_ATTENTION, 4.0 * nb * H * dT * dT * 64, dM * dD * 2 * 4);
-            HIPTS_TRY(launch_attention2(q, k, v, att, nb, H, T, Tp, f16, s));
+            HIPTS_TRY(launch_attention2(q, k, v, att, nb, H, T, Tp, f16, s, 0, 0, h->split_att ? 1 : 0));
         }
         // x += att Wp^T + b  (+ norm2 prepared)
-        HIPTS_TRY(residual(att, L.proj_w.as<bf16_t>(), L.proj_b.as<float>(), D, fold ? L.ln2_g.as<float>() : nullptr, 2.0 * dM * dD * dD,
-                           dM * dD * 2 + dM * dD * 8));
+        HIPTS_TRY(residual(att, L.proj_w.as<bf16_t>(), L.proj_b.as<float>(), att_k, fold ? L.ln2_g.as<float>() : nullptr, 2.0 * dM * dD * att_k,
+                           dM * att_k * 2 + dM * dD * 8));
         if (!fold) HIPTS_TRY(layernorm(L.ln2_g.as<float>(), L.ln2_b.as<float>()));
         g = GemmArgs{};
         g.f16 = f16;
@@ -777,7 +792,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
     float* lg = (dev_out && logits_out) ? logits_out : h->logits.as<float>();
     float* pr = (probs_out || !dev_out) ? ((dev_out && probs_out) ? probs_out : h->probs.as<float>()) : nullptr;
     if (h->fold_ln && h->fold_dirty) {
-        const bool f16w = c.operand_f16 != 0;
+        const bool f16w = (c.operand_f16 & 1) != 0;
         for (auto& L : h->layers) {
             HIPTS_TRY(launch_fold_ln(L.qkv_w.as<bf16_t>(), f16w, L.ln1_g.as<float>(), L.ln1_b.as<float>(), L.qkv_b.as<float>(), L.qkv_u.as<float>(),
                                      L.qkv_c.as<float>(), 3 * c.dim, c.dim, s));

@@ -275,8 +275,10 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
 
 // The same for head_dim 64 with V in its natural layout: q, k, v [B*H][tokens_pad][64] (attn2.hip: LDS-DMA ring, transposed LDS reads of V).
 // variant 0 = default geometry (HIPTS_ATTN2 overrides): 1: 4 waves x 64 query rows, 2: 8 waves x 32, 3: 4 waves x 32.
+// split_lo != 0: rows of out are [hi | lo], 2 * heads * 64 wide -- each output value as two 16-bit halves (the consumer GEMM runs K = 2 * dim
+// against [W | W]).
 int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, bool f16,
-                      hipStream_t s, int out_tokens_stride = 0, int variant = 0);
+                      hipStream_t s, int out_tokens_stride = 0, int variant = 0, int split_lo = 0);
 
 int attention2_read_stamps(unsigned long long* host, int n);      // measurement-only builds (HIPTS_X_STAMPS)
 

@@ -71,10 +71,16 @@ typedef struct hipts_vit_config {
     int32_t gelu_tanh;       /* 1: tanh approximation, 0: erf         */
     int32_t pool_then_norm;  /* 0: LN(tokens) then mean (fc_norm=False); 1: mean then LN */
     int32_t max_batch;       /* workspace is sized for this many images per forward call */
-    int32_t operand_f16;     /* 0: bf16 MFMA operands (default, BASELINE.json configs[1]); 1: IEEE half operands --
+    int32_t operand_f16;     /* bit 0 -- 0: bf16 MFMA operands (BASELINE.json configs[1]); 1: IEEE half operands --
                                 same MFMA rate, 8x smaller activation rounding: keeps |dlogit| <= 1e-3 also on flat
-                                images, where bf16 rounding is identical on every token and does not average out */
+                                images, where bf16 rounding is identical on every token and does not average out.
+                                bit 4 (HIPTS_OPERAND_SPLIT_ATT) -- the attention output is handed to the output
+                                projection as a hi | lo pair of 16-bit halves (22 significant bits with half operands):
+                                removes the error class "one colour everywhere" (every token's attention output carries
+                                the SAME rounding) for 2 dim^2 more flops per token and layer */
 } hipts_vit_config_t;
+#define HIPTS_OPERAND_F16 1
+#define HIPTS_OPERAND_SPLIT_ATT 16
 
 int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** out);
 int hipts_vit_destroy(hipts_vit_t* h);

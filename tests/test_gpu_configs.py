@@ -153,6 +153,46 @@ def test_config2_100k_docs_top100_rank_equal(corpus100k):
             np.testing.assert_array_equal(single_ids[i], wi)
 
 
+def test_config2_benched_shape_256_queries_fused_topk(corpus100k):
+    """The shape bench.py times -- 256 queries x 100k documents through ONE call without `final_out`: the one-pass index product
+    (sim_mfma_wide_kernel<8>) and the top-k that combines the scores where it reads them (TopkFused, no stored rows) -- checked
+    DIRECTLY against the oracle (webui.py:345-383,191-192 restated), not through the stored-row form: ids and values of the top 100
+    for 12 of the queries spread over the batch (the first, the last, one per query block of 32 and three more), byte-equal;
+    and the whole batch against the stored-row form of the same call."""
+    import torch
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    from oracle import bm25 as obm25
+    from oracle import search as osearch
+    ptr, terms, V = corpus100k
+    D, K, NQ, TOPK = len(ptr) - 1, 300, 256, 100
+    rows = synth.index_vectors(D, K, seed=46)
+    bm = BM25Index(ptr, terms, V)
+    idx = Similarity("cfg2b", None, K, capacity=D)
+    idx.add_matrix(rows)
+    eng = SearchEngine(None, idx, {}, bm, [])
+    qs = synth.queries(NQ, V, seed=143)
+    qv = np.random.default_rng(15).standard_normal((NQ, K))
+    qv = (qv / np.linalg.norm(qv, axis=1, keepdims=True)).astype(np.float32)
+    ids, vals = eng.score_topk([dict(q) for q in qs], qv, TOPK)                     # the benched call: no final_out
+    assert ids.shape == (NQ, TOPK)
+    e = bm.export()
+    check = [0, 31, 32, 64, 77, 96, 128, 160, 191, 192, 224, 255]
+    for i in check:
+        q = qs[i]
+        b = obm25.bm25_score_csr(e["csr_ptr"], e["csr_term"], e["csr_tf"], e["idf"], bm.avgdl, e["doc_len"], [t for t, _ in q], [w for _, w in q])
+        f = osearch.combine(b, osearch.similarity(rows, qv[i]))
+        wi, wv = osearch.topk(f, TOPK)
+        np.testing.assert_array_equal(ids[i], wi, err_msg="query %d ids" % i)
+        assert vals[i].tobytes() == wv.tobytes(), "query %d values" % i
+    final_dev = torch.empty((NQ, D), dtype=torch.float64, device="cuda")
+    ids2, vals2 = eng.score_topk([dict(q) for q in qs], qv, TOPK, final_out=final_dev)     # stored rows: combine_kernel + top-k over them
+    np.testing.assert_array_equal(ids, ids2)
+    assert vals.tobytes() == vals2.tobytes()
+
+
 def test_config4_rerank_cosine_100k_x_768():
     """configs[4] rerank at its stated size: 100k unit feature rows x 768, the difference 1 - cosine against the k-ordered
     float32 chain of the oracle (orc_sim_chain), bit for bit, single query and a batch."""
