@@ -81,15 +81,19 @@ __device__ __forceinline__ void wait_vm() {
 // (nothing is stored then; the workgroup repeats the blocks with attn2_classic).
 // The low halves of four values whose high halves are `hi`: value - (float)hi, rounded once (the hi | lo operand split: two 16-bit
 // halves carry 22 significant bits of an IEEE-half operand, 16 of a bf16 one; the consumer multiplies them against [W | W]).
+// lo_scale (a power of two; the consumer's weights for the low half carry its inverse): keeps the low halves of IEEE-half operands out
+// of the subnormal range -- value 2^-11 is below 2^-14 for every |value| < 1/8.
 template <bool F16>
-__device__ __forceinline__ bf16x4 pack4_lo(float a, float b, float c, float d, bf16x4 hi) {
-    return pack4<F16>(a - from_op<F16>(hi[0]), b - from_op<F16>(hi[1]), c - from_op<F16>(hi[2]), d - from_op<F16>(hi[3]));
+__device__ __forceinline__ bf16x4 pack4_lo(float a, float b, float c, float d, bf16x4 hi, float lo_scale) {
+    return pack4<F16>((a - from_op<F16>(hi[0])) * lo_scale, (b - from_op<F16>(hi[1])) * lo_scale, (c - from_op<F16>(hi[2])) * lo_scale,
+                      (d - from_op<F16>(hi[3])) * lo_scale);
 }
 
 // Output quads 2 kp (even) and 2 kp + 1 (odd) of one query row, normalised, as one 16 B store per lane (attn2_body's comment); with
 // lo_off != 0 the low halves follow at op + lo_off (hipts_vit_config_t.operand_f16 bit 4: the attention output as a hi | lo pair).
 template <bool F16>
-__device__ __forceinline__ void store_o_pair(const f32x16& oe, const f32x16& oo, int kp, float inv, int h, bool valid, bf16_t* op, int lo_off) {
+__device__ __forceinline__ void store_o_pair(const f32x16& oe, const f32x16& oo, int kp, float inv, int h, bool valid, bf16_t* op, int lo_off,
+                                             float lo_scale) {
     const int ke = 2 * kp, ko = 2 * kp + 1;
     const int ie = 4 * (ke & 3), io = 4 * (ko & 3);
     const float e0 = oe[ie] * inv, e1 = oe[ie + 1] * inv, e2 = oe[ie + 2] * inv, e3 = oe[ie + 3] * inv;
@@ -104,7 +108,8 @@ __device__ __forceinline__ void store_o_pair(const f32x16& oe, const f32x16& oo,
         if (valid) *reinterpret_cast<uint4*>(dst) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
     if (lo_off) {                            // uniform over the launch
-        const uint2 ue = __builtin_bit_cast(uint2, pack4_lo<F16>(e0, e1, e2, e3, we)), uo = __builtin_bit_cast(uint2, pack4_lo<F16>(f0, f1, f2, f3, wo));
+        const uint2 ue = __builtin_bit_cast(uint2, pack4_lo<F16>(e0, e1, e2, e3, we, lo_scale)),
+                    uo = __builtin_bit_cast(uint2, pack4_lo<F16>(f0, f1, f2, f3, wo, lo_scale));
         const auto r0 = __builtin_amdgcn_permlane32_swap(ue.x, uo.x, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(ue.y, uo.y, false, false);
         if (valid) *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
@@ -114,7 +119,7 @@ __device__ __forceinline__ void store_o_pair(const f32x16& oe, const f32x16& oo,
 template <bool F16, int QB, int NW>
 __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
-                                           int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off) {
+                                           int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off, float lo_scale) {
     constexpr int PCS = 8 / NW;                      // 1 KiB pieces of a K (and of a V) tile per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -321,7 +326,7 @@ __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t
         // afterwards lane h = 0 holds (a = its own even word, b = its partner's even word) = d + 0..3 | d + 4..7 of the even chunk,
         // lane h = 1 holds (a = its partner's odd word, b = its own odd word) = the odd chunk, in that order as well.
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) store_o_pair<F16>(o[qb][(2 * kp) >> 2], o[qb][(2 * kp + 1) >> 2], kp, inv, h, qi < tokens, op, lo_off);
+        for (int kp = 0; kp < 4; ++kp) store_o_pair<F16>(o[qb][(2 * kp) >> 2], o[qb][(2 * kp + 1) >> 2], kp, inv, h, qi < tokens, op, lo_off, lo_scale);
     }
     return false;
 }
@@ -332,7 +337,7 @@ __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t
 template <bool F16, int NW>
 __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad,
-                                               int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off) {
+                                               int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off, float lo_scale) {
     constexpr int PCS = 8 / NW;
     constexpr int SNS = HIPTS_ATTN2_SEQ_SLOTS;       // ring slots per operand: 2 = one tile in flight, 3 = two
     constexpr int VB = SNS * TILE;                   // V slots behind the K slots
@@ -537,7 +542,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     const int qi = q0 + r;
     bf16_t* op = out + ((size_t)b * out_stride + qi) * out_ld + head * HD;
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) store_o_pair<F16>(o[(2 * kp) >> 2], o[(2 * kp + 1) >> 2], kp, inv, h, qi < tokens, op, lo_off);      // see attn2_body
+    for (int kp = 0; kp < 4; ++kp) store_o_pair<F16>(o[(2 * kp) >> 2], o[(2 * kp + 1) >> 2], kp, inv, h, qi < tokens, op, lo_off, lo_scale);      // see attn2_body
     return false;
 }
 
@@ -548,7 +553,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 template <bool F16, int QB, int NW>
 __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int bh,
-                                           int blk0, int nblk, int out_stride, int out_ld, int lo_off) {
+                                           int blk0, int nblk, int out_stride, int out_ld, int lo_off, float lo_scale) {
     constexpr int PCS = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -651,7 +656,7 @@ __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf1
                     const float x0 = o[blk][4 * g4] * inv, x1 = o[blk][4 * g4 + 1] * inv, x2 = o[blk][4 * g4 + 2] * inv, x3 = o[blk][4 * g4 + 3] * inv;
                     const bf16x4 hi = pack4<F16>(x0, x1, x2, x3);
                     *reinterpret_cast<bf16x4*>(op + blk * 32 + 8 * g4 + 4 * h) = hi;
-                    if (lo_off) *reinterpret_cast<bf16x4*>(op + lo_off + blk * 32 + 8 * g4 + 4 * h) = pack4_lo<F16>(x0, x1, x2, x3, hi);
+                    if (lo_off) *reinterpret_cast<bf16x4*>(op + lo_off + blk * 32 + 8 * g4 + 4 * h) = pack4_lo<F16>(x0, x1, x2, x3, hi, lo_scale);
                 }
         }
     }
@@ -660,7 +665,7 @@ __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf1
 template <bool F16, int QB, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) void attn2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                         bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int chunks, int out_stride,
-                                                        int classic, int out_ld, int lo_off) {
+                                                        int classic, int out_ld, int lo_off, float lo_scale) {
     // ALL of the kernel's LDS is this one array (ring + the fallback flag word): with a second LDS object in the kernel -- __syncthreads_or()
     // brings one -- hipcc puts an s_waitcnt vmcnt(0) in front of the first ds_read of every tile step and the DMA ring never runs ahead
     // (cdna_hip_programming.md section 5, "three .s-level traps" (a); seen in this kernel's .s).
@@ -680,21 +685,21 @@ __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) voi
     // classic != 0 (HIPTS_ATTN_CLASSIC=1): the fallback everywhere (A/B runs, its own test)
     if (!classic) {
         bool bad;
-        if constexpr (MODE == 1) bad = attn2_seq_body<F16, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off);
-        else bad = attn2_body<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off);
+        if constexpr (MODE == 1) bad = attn2_seq_body<F16, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale);
+        else bad = attn2_body<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale);
         if (bad) *redo = 1;
     }
     __syncthreads();
     // a wave whose row sum left the window stored nothing; the workgroup (its waves stage K / V together) repeats its blocks classically
-    if (*redo) attn2_classic<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off);
+    if (*redo) attn2_classic<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale);
 }
 
 template <bool F16, int QB, int NW, int MODE>
 int launch_cfg(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, int ost,
-               int classic, int out_ld, int lo_off, hipStream_t s) {
+               int classic, int out_ld, int lo_off, float lo_scale, hipStream_t s) {
     const int nb = (tokens + 32 * QB - 1) / (32 * QB);
     const int chunks = (nb + NW - 1) / NW;
-    attn2_kernel<F16, QB, NW, MODE><<<batch * heads * chunks, NW * 64, 0, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic, out_ld, lo_off);
+    attn2_kernel<F16, QB, NW, MODE><<<batch * heads * chunks, NW * 64, 0, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic, out_ld, lo_off, lo_scale);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
@@ -704,7 +709,7 @@ int launch_cfg(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, i
 // q, k, v: [batch * heads][tokens_pad][64] 16-bit (q pre-scaled by head_dim^-0.5 log2 e; rows past `tokens` zero), out [batch * out_stride][heads * 64].
 // variant: 0 = default; 1: 4 waves x 64 rows, 2: 8 waves x 32 rows, 3: 4 waves x 32 rows (A/B, hiptsdbg_attention2_*).
 int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, bool f16,
-                      hipStream_t s, int out_tokens_stride, int variant, int split_lo) {
+                      hipStream_t s, int out_tokens_stride, int variant, int split_lo, float lo_scale) {
     const int ost = out_tokens_stride > 0 ? out_tokens_stride : tokens;
     // split_lo: rows of `out` are [hi (heads * 64) | lo (heads * 64)] -- the output as a hi | lo pair of 16-bit halves
     const int out_ld = split_lo ? 2 * heads * HD : heads * HD, lo_off = split_lo ? heads * HD : 0;
@@ -713,8 +718,8 @@ int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
     static const int env_variant = getenv("HIPTS_ATTN2") ? atoi(getenv("HIPTS_ATTN2")) : 0;
     if (variant == 0) variant = env_variant ? env_variant : 5;
 #define HIPTS_ATTN2_CASE(QB_, NW_, MODE_)                                                                                        \
-    return f16 ? launch_cfg<true, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, s)                      \
-               : launch_cfg<false, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, s)
+    return f16 ? launch_cfg<true, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, lo_scale, s)                      \
+               : launch_cfg<false, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, lo_scale, s)
     switch (variant) {
         case 1: HIPTS_ATTN2_CASE(2, 4, 0);
         case 2: HIPTS_ATTN2_CASE(1, 8, 0);

@@ -28,7 +28,8 @@ struct hipts_d2v {
     int dim = 0, negative = 5;
     double exp_scale = 83.0;
     bool has_sample = false;
-    DevBuf syn1neg, syn_lane, cum_table, sample_int, exp_table;      // syn_lane: the lane-major copy the planned kernel gathers (below)
+    DevBuf syn1neg, syn_lane, cum_table, sample_int, exp_table, word_vectors;      // word_vectors: PV-DM inference only (hipts_d2v_set_word_vectors)
+    // syn_lane: the lane-major copy the planned kernel gathers (below)
     DevBuf ws_ptr, ws_words, ws_v0, ws_seeds, ws_out;
 };
 
@@ -173,6 +174,140 @@ __global__ __launch_bounds__(256) void d2v_infer_kernel(const float* __restrict_
 #pragma unroll
             for (int c = 0; c < EPL; ++c) v[c] = v[c] + work[c];
         }
+        alpha -= alpha_delta;
+    }
+#pragma unroll
+    for (int c = 0; c < EPL; ++c)
+        if (lane + 64 * c < dim) out[doc * dim + lane + 64 * c] = v[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// PV-DM inference (dm = 1, sum or mean; BASELINE.json's north_star names it, the reference runs dm = 0): gensim's
+// train_document_dm with frozen word vectors and hidden layer -- oracle/csrc/oracle.c::orc_d2v_infer_dm is the restatement this
+// follows operation for operation.  A wave per document as d2v_infer_kernel; per epoch the kept words (in vocabulary, surviving
+// sub-sampling) and their reduced windows go into the wave's LDS lists (written by lane 0 from the scalar LCG walk), then every
+// kept position builds l1 = (context word vectors, ascending position, + the document vector) [* 1 / count] and runs the
+// (1 + negative) targets against it.  The same lane owns element lane + 64 c of every vector, so sums and the dot product have
+// the oracle's order.
+// ---------------------------------------------------------------------------------------------
+constexpr int DM_CAP = 512;        // kept words of one document (host-checked against the raw length)
+
+template <int EPL>
+__global__ __launch_bounds__(256) void d2v_infer_dm_kernel(const float* __restrict__ syn1neg, const float* __restrict__ wv,
+                                                           const uint32_t* __restrict__ cum_table, const uint32_t* __restrict__ sample_int,
+                                                           int64_t V, int dim, const int64_t* __restrict__ doc_ptr,
+                                                           const int32_t* __restrict__ words, int64_t ndocs, const float* __restrict__ v0,
+                                                           const uint64_t* __restrict__ seeds, int epochs, float alpha0, float min_alpha,
+                                                           int negative, double exp_scale, const float* __restrict__ exp_table_g, int window,
+                                                           int dm_mean, float* __restrict__ out) {
+    __shared__ float exp_table[EXP_TABLE_SIZE];
+    __shared__ int32_t s_kept[4][DM_CAP];
+    __shared__ int32_t s_red[4][DM_CAP];
+    for (int i = threadIdx.x; i < EXP_TABLE_SIZE; i += 256) exp_table[i] = exp_table_g[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t doc = (int64_t)blockIdx.x * 4 + wid;
+    if (doc >= ndocs) return;                       // whole wave exits together
+    int32_t* kept = s_kept[wid];
+    int32_t* red = s_red[wid];
+    float v[EPL], work[EPL], rw[EPL], l1[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) v[c] = (lane + 64 * c < dim) ? v0[doc * dim + lane + 64 * c] : 0.0f;
+    const int64_t wb = doc_ptr[doc], we = doc_ptr[doc + 1];
+    const uint64_t seed = seeds[doc];
+    const uint32_t cum_last = cum_table[V - 1];
+    double alpha = (double)alpha0;
+    const double alpha_delta = ((double)alpha0 - (double)min_alpha) / (double)(epochs - 1 > 1 ? epochs - 1 : 1);
+    for (int e = 0; e < epochs; ++e) {
+        uint64_t next_random = uniform64(splitmix64(seed + (uint64_t)e) & LCG_MOD);
+        const float a = (float)alpha;
+        int n = 0;
+        for (int64_t i = wb; i < we; ++i) {
+            const int32_t w = __builtin_amdgcn_readfirstlane(words[i]);
+            if (w < 0 || w >= V) continue;
+            if (sample_int) {
+                const uint64_t r = next_random >> 16;
+                next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                if ((uint64_t)sample_int[w] < r) continue;
+            }
+            if (lane == 0) kept[n] = w;
+            ++n;
+        }
+        for (int i = 0; i < n; ++i) {
+            if (lane == 0) red[i] = (int32_t)((uint32_t)(next_random >> 16) % (uint32_t)window);
+            next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+        }
+        // lane 0's LDS writes are read by every lane of this wave below: LDS operations of one wave execute in order, the fence
+        // only keeps the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = 0; i < n; ++i) {
+            const int b = __builtin_amdgcn_readfirstlane(red[i]);
+            int j = i - window + b, k = i + window + 1 - b;
+            j = j < 0 ? 0 : j;
+            k = k > n ? n : k;
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) l1[c] = 0.0f;
+            float count = 0.0f;
+            for (int m = j; m < k; ++m) {
+                if (m == i) continue;
+                count += 1.0f;
+                const int32_t wm = __builtin_amdgcn_readfirstlane(kept[m]);
+                const float* __restrict__ row = wv + (int64_t)wm * dim;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) l1[c] = l1[c] + ((lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f);
+            }
+            count += 1.0f;                                  // the document tag
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) l1[c] = l1[c] + v[c];
+            const float inv_count = 1.0f / count;
+            if (dm_mean) {
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) l1[c] = l1[c] * inv_count;
+            }
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) work[c] = 0.0f;
+            const int32_t w = __builtin_amdgcn_readfirstlane(kept[i]);
+            for (int d = 0; d < negative + 1; ++d) {
+                uint32_t target;
+                float label;
+                if (d == 0) {
+                    target = (uint32_t)w;
+                    label = 1.0f;
+                } else {
+                    const uint32_t x = (uint32_t)(next_random >> 16) % cum_last;
+                    target = __builtin_amdgcn_readfirstlane(bisect_left_wave(cum_table, x, (uint32_t)V, lane));
+                    next_random = (next_random * 25214903917ULL + 11) & LCG_MOD;
+                    if (target == (uint32_t)w) continue;
+                    label = 0.0f;
+                }
+                const float* __restrict__ row = syn1neg + (int64_t)target * dim;
+                float p = 0.0f;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) {
+                    rw[c] = (lane + 64 * c < dim) ? row[lane + 64 * c] : 0.0f;
+                    p = fmaf(l1[c], rw[c], p);
+                }
+                p = wave_sum_butterfly(p);
+                float f = p;
+                if (f <= -(float)MAX_EXP || f >= (float)MAX_EXP) continue;
+                f = exp_table[(int)((double)(f + (float)MAX_EXP) * exp_scale)];
+                const float g = (label - f) * a;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) work[c] = fmaf(g, rw[c], work[c]);
+            }
+            if (!dm_mean) {
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) work[c] = work[c] * inv_count;
+            }
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) v[c] = v[c] + work[c];
+        }
+        // the next epoch's list writes must not overtake this epoch's list reads (same wave, in order; compiler fence only)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         alpha -= alpha_delta;
     }
 #pragma unroll
@@ -664,6 +799,66 @@ int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words
     if (out_memspace != HIPTS_DEVICE) {
         HIPTS_HIP(hipMemcpyAsync(out, out_dev, (size_t)ndocs * h->dim * 4, hipMemcpyDeviceToHost, s));
     }
+    HIPTS_HIP(hipStreamSynchronize(s));   // staging buffers are reused by the next call
+    return HIPTS_OK;
+}
+
+int hipts_d2v_set_word_vectors(hipts_d2v_t* h, const float* word_vectors) {
+    HIPTS_REQUIRE(h && word_vectors, "hipts_d2v_set_word_vectors: null argument");
+    HIPTS_TRY(use_device(h->device));
+    HIPTS_TRY(h->word_vectors.alloc((size_t)h->V * h->dim * 4));
+    return upload(h->word_vectors.p, word_vectors, (size_t)h->V * h->dim * 4);
+}
+
+int hipts_d2v_infer_dm(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words, int64_t ndocs, const float* v0,
+                       const uint64_t* seeds, int epochs, float alpha, float min_alpha, int window, int dm_mean, float* out,
+                       int out_memspace, void* stream) {
+    HIPTS_REQUIRE(h && doc_ptr && v0 && seeds && out && ndocs >= 1 && epochs >= 1, "hipts_d2v_infer_dm: bad arguments");
+    HIPTS_REQUIRE(window >= 1, "hipts_d2v_infer_dm: window must be >= 1");
+    if (!h->word_vectors.p)
+        return set_error(HIPTS_ERR_STATE, "hipts_d2v_infer_dm: the model has no word vectors (hipts_d2v_set_word_vectors)");
+    HIPTS_TRY(use_device(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nw = doc_ptr[ndocs];
+    HIPTS_REQUIRE(doc_ptr[0] == 0 && nw >= 0 && (words || nw == 0), "hipts_d2v_infer_dm: bad CSR");
+    for (int64_t d = 0; d < ndocs; ++d)
+        HIPTS_REQUIRE(doc_ptr[d + 1] >= doc_ptr[d] && doc_ptr[d + 1] - doc_ptr[d] <= DM_CAP,
+                      "hipts_d2v_infer_dm: document %lld has %lld words, at most %d are supported", (long long)d,
+                      (long long)(doc_ptr[d + 1] - doc_ptr[d]), DM_CAP);
+    HIPTS_TRY(h->ws_ptr.reserve((size_t)(ndocs + 1) * 8));
+    HIPTS_TRY(h->ws_words.reserve((size_t)(nw ? nw : 1) * 4));
+    HIPTS_TRY(h->ws_v0.reserve((size_t)ndocs * h->dim * 4));
+    HIPTS_TRY(h->ws_seeds.reserve((size_t)ndocs * 8));
+    HIPTS_HIP(hipMemcpyAsync(h->ws_ptr.p, doc_ptr, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s));
+    if (nw) HIPTS_HIP(hipMemcpyAsync(h->ws_words.p, words, (size_t)nw * 4, hipMemcpyHostToDevice, s));
+    HIPTS_HIP(hipMemcpyAsync(h->ws_v0.p, v0, (size_t)ndocs * h->dim * 4, hipMemcpyHostToDevice, s));
+    HIPTS_HIP(hipMemcpyAsync(h->ws_seeds.p, seeds, (size_t)ndocs * 8, hipMemcpyHostToDevice, s));
+    float* out_dev = out;
+    if (out_memspace != HIPTS_DEVICE) {
+        HIPTS_TRY(h->ws_out.reserve((size_t)ndocs * h->dim * 4));
+        out_dev = h->ws_out.as<float>();
+    }
+    const int grid = ceil_div(ndocs, 4);
+    const int epl = (h->dim + 63) / 64;
+#define D2V_DM_LAUNCH(E)                                                                                                              \
+    d2v_infer_dm_kernel<E><<<grid, 256, 0, s>>>(h->syn1neg.as<float>(), h->word_vectors.as<float>(), h->cum_table.as<uint32_t>(),         \
+                                                h->has_sample ? h->sample_int.as<uint32_t>() : nullptr, h->V, h->dim,                 \
+                                                h->ws_ptr.as<int64_t>(), h->ws_words.as<int32_t>(), ndocs, h->ws_v0.as<float>(),       \
+                                                h->ws_seeds.as<uint64_t>(), epochs, alpha, min_alpha, h->negative, h->exp_scale,      \
+                                                h->exp_table.as<float>(), window, dm_mean ? 1 : 0, out_dev)
+    switch (epl) {
+        case 1: D2V_DM_LAUNCH(1); break;
+        case 2: D2V_DM_LAUNCH(2); break;
+        case 3: D2V_DM_LAUNCH(3); break;
+        case 4: D2V_DM_LAUNCH(4); break;
+        case 5: D2V_DM_LAUNCH(5); break;
+        case 6: D2V_DM_LAUNCH(6); break;
+        case 7: D2V_DM_LAUNCH(7); break;
+        default: D2V_DM_LAUNCH(8); break;
+    }
+#undef D2V_DM_LAUNCH
+    HIPTS_LAUNCH_CHECK();
+    if (out_memspace != HIPTS_DEVICE) HIPTS_HIP(hipMemcpyAsync(out, out_dev, (size_t)ndocs * h->dim * 4, hipMemcpyDeviceToHost, s));
     HIPTS_HIP(hipStreamSynchronize(s));   // staging buffers are reused by the next call
     return HIPTS_OK;
 }

@@ -281,7 +281,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.rope = h->rope.as<float>(); g.rope_tokens = np;  // 2-D rotary embedding on the fp32 result, in the epilogue
         if (ln1_folded) folded(g, L.qkv_u.as<float>(), L.qkv_c.as<float>());
         HIPTS_TRY(launch_gemm(EPI_QK_ROPE, g, s));
-        HIPTS_TRY(launch_attention2(q_p, k_p, v_p, att_p, batch, H, T, Tp, f16, s, TS, 0, h->split_att ? 1 : 0));
+        HIPTS_TRY(launch_attention2(q_p, k_p, v_p, att_p, batch, H, T, Tp, f16, s, TS, 0, h->split_att ? 1 : 0, split_lo_scale(f16)));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
@@ -565,9 +565,10 @@ int hipts_eva_set_tensor(hipts_eva_t* h, const char* key_c, const float* data, i
             EXPECT((int64_t)D * D);
             if (h->split_att) {      // [W | W] against the (hi | lo) halves of the attention output
                 std::vector<float> dup((size_t)D * 2 * D);
+                const float inv = 1.0f / split_lo_scale(f16);      // the low halves arrive multiplied by the scale
                 for (int n = 0; n < D; ++n) {
                     memcpy(&dup[(size_t)n * 2 * D], &data[(size_t)n * D], (size_t)D * 4);
-                    memcpy(&dup[(size_t)n * 2 * D + D], &data[(size_t)n * D], (size_t)D * 4);
+                    for (int kk = 0; kk < D; ++kk) dup[(size_t)n * 2 * D + D + kk] = data[(size_t)n * D + kk] * inv;
                 }
                 st = upload_matrix16(L.proj_w, dup.data(), D, 2 * D, round_up(D, 256), f16);
             } else {

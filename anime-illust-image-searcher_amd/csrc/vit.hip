@@ -499,9 +499,10 @@ int hipts_vit_set_tensor(hipts_vit_t* h, const char* key_c, const float* data, i
             EXPECT((int64_t)D * D);
             if (h->split_att) {      // [D][2D] = [W | W]: multiplies the (hi | lo) halves of the attention output
                 std::vector<float> dup((size_t)D * 2 * D);
+                const float inv = 1.0f / split_lo_scale(g_upload_f16);      // the low halves arrive multiplied by the scale
                 for (int n = 0; n < D; ++n) {
                     memcpy(&dup[(size_t)n * 2 * D], &data[(size_t)n * D], (size_t)D * 4);
-                    memcpy(&dup[(size_t)n * 2 * D + D], &data[(size_t)n * D], (size_t)D * 4);
+                    for (int kk = 0; kk < D; ++kk) dup[(size_t)n * 2 * D + D + kk] = data[(size_t)n * D + kk] * inv;
                 }
                 st = set_bf16_matrix(L.proj_w, dup.data(), D, 2 * D, round_up(D, 256));
             } else {
@@ -710,7 +711,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         }
         {
             ProfScope ps(h, s, PC_ATTENTION, 4.0 * nb * H * dT * dT * 64, dM * dD * 2 * 4);
-            HIPTS_TRY(launch_attention2(q, k, v, att, nb, H, T, Tp, f16, s, 0, 0, h->split_att ? 1 : 0));
+            HIPTS_TRY(launch_attention2(q, k, v, att, nb, H, T, Tp, f16, s, 0, 0, h->split_att ? 1 : 0, split_lo_scale(f16)));
         }
         // x += att Wp^T + b  (+ norm2 prepared)
         HIPTS_TRY(residual(att, L.proj_w.as<bf16_t>(), L.proj_b.as<float>(), att_k, fold ? L.ln2_g.as<float>() : nullptr, 2.0 * dM * dD * att_k,

@@ -275,10 +275,20 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
 
 // The same for head_dim 64 with V in its natural layout: q, k, v [B*H][tokens_pad][64] (attn2.hip: LDS-DMA ring, transposed LDS reads of V).
 // variant 0 = default geometry (HIPTS_ATTN2 overrides): 1: 4 waves x 64 query rows, 2: 8 waves x 32, 3: 4 waves x 32.
-// split_lo != 0: rows of out are [hi | lo], 2 * heads * 64 wide -- each output value as two 16-bit halves (the consumer GEMM runs K = 2 * dim
-// against [W | W]).
+// split_lo != 0: rows of out are [hi | lo * lo_scale], 2 * heads * 64 wide -- each output value as two 16-bit halves (the consumer GEMM runs
+// K = 2 * dim against [W | W / lo_scale]; split_lo_scale(f16) is the scale both sides use).
 int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, bool f16,
-                      hipStream_t s, int out_tokens_stride = 0, int variant = 0, int split_lo = 0);
+                      hipStream_t s, int out_tokens_stride = 0, int variant = 0, int split_lo = 0, float lo_scale = 1.0f);
+// The power of two that the low half of a hi | lo operand pair is multiplied by (and the matching weight copy divided by).  IEEE half: the
+// low half of a value v is about v * 2^-11, subnormal (< 2^-14) for every |v| < 1/8 -- which covers most activations; 64 moves it back into
+// the normal range while W / 64 stays normal for |W| >= 2^-8 and exact (a power of two) otherwise down to 2^-18.  Measured, ViT-B/16 batch
+// 64: with scale 1 the forward ran 26 % slower than without the split (5295 -> 3919 images/s; bf16 operands, whose low halves are normal
+// numbers: 6 %) -- subnormal half operands slow the matrix pipe down.  HIPTS_SPLIT_LO_SCALE overrides (A/B).
+inline float split_lo_scale(bool f16) {
+    static const float env = getenv("HIPTS_SPLIT_LO_SCALE") ? (float)atof(getenv("HIPTS_SPLIT_LO_SCALE")) : 0.0f;
+    if (env > 0.0f) return env;
+    return f16 ? 64.0f : 1.0f;
+}
 
 int attention2_read_stamps(unsigned long long* host, int n);      // measurement-only builds (HIPTS_X_STAMPS)
 

@@ -113,6 +113,9 @@ _SIGNATURES = {
                         c_float, c_float, ctypes.c_uint64, c_int, c_int, c_int, c_void_p],
     "hipts_d2v_infer": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p,
                         c_int, c_void_p],
+    "hipts_d2v_set_word_vectors": [c_void_p, c_void_p],
+    "hipts_d2v_infer_dm": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_int, c_void_p,
+                           c_int, c_void_p],
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 

@@ -1,4 +1,4 @@
-"""Doc2Vec PV-DBOW inference: host-side mirror of `gensim.models.Doc2Vec.infer_vector` as the
+"""Doc2Vec PV-DBOW (and, as a flag, PV-DM) inference: host-side mirror of `gensim.models.Doc2Vec.infer_vector` as the
 reference uses it (genmodel.py:169; webui.py:106,185) over libhip_tagsearch's wave-per-document
 kernel (csrc/d2v.hip), and of `Doc2Vec(...)` / `build_vocab` / `train` (genmodel.py:159-162) over
 hipts_d2v_train.  A trained model is the arrays inference consumes: syn1neg, cum_table, sample_int
@@ -25,11 +25,15 @@ def pseudorandom_weak_vector(size: int, seed_string: str) -> np.ndarray:
 
 
 class Doc2VecInference:
-    """Frozen PV-DBOW model on the device."""
+    """Frozen Doc2Vec model on the device: PV-DBOW (dm=0, the reference's configuration, genmodel.py:159) or -- with
+    `word_vectors` -- PV-DM (dm=1, non-concatenative; dm_mean 0: sum, 1: mean), the form BASELINE.json's north_star names.
+    A dm=1 model is gensim's {wv.vectors, syn1neg, cum_table, sample_int, window}; this package trains DBOW only, so such a model
+    comes from outside (or from synthetic arrays in the tests)."""
 
     def __init__(self, syn1neg: np.ndarray, cum_table: np.ndarray, sample_int: Optional[np.ndarray],
                  key_to_index: Dict[str, int], epochs: int = 100, alpha: float = 0.025, min_alpha: float = 1e-4,
-                 negative: int = 5, exp_scale: float = 83.0, seed: int = 1, device: int = 0):
+                 negative: int = 5, exp_scale: float = 83.0, seed: int = 1, device: int = 0,
+                 dm: int = 0, word_vectors: Optional[np.ndarray] = None, window: int = 5, dm_mean: int = 0):
         self.syn1neg = np.ascontiguousarray(syn1neg, dtype=np.float32)
         self.cum_table = np.ascontiguousarray(cum_table, dtype=np.uint32)
         self.sample_int = None if sample_int is None else np.ascontiguousarray(sample_int, dtype=np.uint32)
@@ -43,6 +47,15 @@ class Doc2VecInference:
                   _lib.ptr(self.sample_int) if self.sample_int is not None else None,
                   c_int64(self.syn1neg.shape[0]), self.vector_size, self.negative, c_double(self.exp_scale), device,
                   ctypes.byref(self._h))
+        self.dm, self.window, self.dm_mean = int(dm), int(window), int(dm_mean)
+        self.word_vectors = None
+        if self.dm:
+            if word_vectors is None:
+                raise ValueError("dm=1 needs the model's word vectors (wv.vectors)")
+            self.word_vectors = np.ascontiguousarray(word_vectors, dtype=np.float32)
+            if self.word_vectors.shape != self.syn1neg.shape:
+                raise ValueError("word_vectors must be [vocab][vector_size] like syn1neg")
+            _lib.call("hipts_d2v_set_word_vectors", self._h, _lib.ptr(self.word_vectors))
 
     # -- raw batch interface (explicit start vectors and seeds) ------------------------------
     def infer_batch(self, doc_ptr: np.ndarray, words: np.ndarray, v0: np.ndarray, seeds: np.ndarray,
@@ -54,6 +67,11 @@ class Doc2VecInference:
         n = len(doc_ptr) - 1
         if out is None:
             out = np.empty((n, self.vector_size), dtype=np.float32)
+        if self.dm:
+            _lib.call("hipts_d2v_infer_dm", self._h, _lib.ptr(doc_ptr), _lib.ptr(words if len(words) else np.zeros(1, np.int32)),
+                      c_int64(n), _lib.ptr(v0), _lib.ptr(seeds), int(epochs or self.epochs), c_float(self.alpha),
+                      c_float(self.min_alpha), self.window, self.dm_mean, _lib.ptr(out), _lib.memspace_of(out), _lib.current_stream_ptr())
+            return out
         _lib.call("hipts_d2v_infer", self._h, _lib.ptr(doc_ptr), _lib.ptr(words if len(words) else np.zeros(1, np.int32)),
                   c_int64(n), _lib.ptr(v0), _lib.ptr(seeds), int(epochs or self.epochs), c_float(self.alpha),
                   c_float(self.min_alpha), _lib.ptr(out), _lib.memspace_of(out), _lib.current_stream_ptr())
@@ -127,7 +145,8 @@ class Doc2Vec:
                  sample: float = 1e-3, alpha: float = 0.025, min_alpha: float = 1e-4, ns_exponent: float = 0.75, seed: int = 1,
                  epochs: int = 10, batch_words: int = 10000, exp_scale: float = 83.0, device: int = 0, sequential_max_words: int = 200_000):
         if dm != 0:
-            raise NotImplementedError("only PV-DBOW (dm=0), the reference's configuration (genmodel.py:159), is built")
+            raise NotImplementedError("training is PV-DBOW only (dm=0, the reference's configuration, genmodel.py:159); PV-DM INFERENCE of a "
+                                      "model trained elsewhere: Doc2VecInference(..., dm=1, word_vectors=..., window=..., dm_mean=...)")
         self.vector_size, self.window, self.min_count, self.workers = int(vector_size), window, int(min_count), int(workers)
         self.negative, self.sample, self.alpha, self.min_alpha = int(negative), float(sample), float(alpha), float(min_alpha)
         self.ns_exponent, self.seed, self.epochs, self.batch_words = float(ns_exponent), int(seed), int(epochs), int(batch_words)

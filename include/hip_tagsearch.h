@@ -399,6 +399,17 @@ int hipts_d2v_infer(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words
                     const float* v0, const uint64_t* seeds, int epochs, float alpha, float min_alpha,
                     float* out, int out_memspace, void* stream);
 
+/* Doc2Vec PV-DM inference (dm=1, non-concatenative; dm_mean 0: sum, 1: mean of context word vectors + document vector).
+ * BASELINE.json's north_star names this form; the reference's model is dm=0 (genmodel.py:159), so no call site of the reference
+ * reaches it -- it replaces gensim Doc2Vec.infer_vector of a dm=1 model (doc2vec_inner.pyx::train_document_dm with
+ * learn_doctags only).  word_vectors: float32 [vocab][dim] = the model's wv.vectors, frozen.  window: the model's window; the
+ * reduced windows continue the document's explicit LCG stream (oracle/csrc/oracle.c::orc_d2v_infer_dm).  Documents of more
+ * than 512 words are refused (HIPTS_ERR_INVALID). */
+int hipts_d2v_set_word_vectors(hipts_d2v_t* h, const float* word_vectors);
+int hipts_d2v_infer_dm(hipts_d2v_t* h, const int64_t* doc_ptr, const int32_t* words, int64_t ndocs,
+                       const float* v0, const uint64_t* seeds, int epochs, float alpha, float min_alpha,
+                       int window, int dm_mean, float* out, int out_memspace, void* stream);
+
 /* Doc2Vec PV-DBOW TRAINING.   Replaces  Doc2Vec(vector_size=300, window=50, min_count=1, workers=1, dm=0) / build_vocab /
  * train(epochs=100)                                                                       genmodel.py:159-162.
  * The vocabulary statistics (build_vocab: cum_table with ns_exponent 0.75, sample_int for sample = 1e-3, both over the

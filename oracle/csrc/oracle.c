@@ -9,6 +9,8 @@
  *                    k-ordered fused chain acc = fmaf(a[k], q[k], acc), k = 0..K-1, which is
  *                    exactly what gfx950's v_mfma_f32_32x32x2_f32 computes.
  *
+ *   orc_d2v_infer_dm the same for dm=1 (PV-DM, sum or mean of context + document vector): see its own comment below.
+ *
  *   orc_d2v_infer    gensim Doc2Vec.infer_vector for dm=0 (PV-DBOW), negative sampling,
  *                    hs=0 (reference call sites genmodel.py:159,169; webui.py:106,185):
  *                    doc2vec.py::infer_vector -> doc2vec_inner.pyx::train_document_dbow ->
@@ -143,6 +145,116 @@ void orc_d2v_infer(const float* syn1neg, const uint32_t* cum_table, int64_t V, c
     for (int64_t d = 0; d < ndocs; ++d) {
         infer_one(syn1neg, cum_table, V, sample_int, dim, words + doc_ptr[d], (int)(doc_ptr[d + 1] - doc_ptr[d]),
                   v0 + d * dim, seeds[d], epochs, alpha, min_alpha, negative, exp_scale, table, out + d * dim);
+    }
+}
+
+
+/* ---------------------------------------------------------------------------------------------
+ * orc_d2v_infer_dm -- gensim Doc2Vec.infer_vector for dm=1 (PV-DM, non-concatenative), negative sampling, hs=0:
+ * doc2vec.py::infer_vector -> doc2vec_inner.pyx::train_document_dm (learn_doctags = 1, learn_words = learn_hidden = 0)
+ * -> fast_document_dm_neg.  BASELINE.json's north_star names this form; the reference itself runs dm=0 (genmodel.py:159).
+ * PARITY UNPINNED (gensim 4.3.3 absent; restated from the published algorithm).  Per epoch:
+ *   1. the kept words: in vocabulary and surviving sub-sampling (one LCG draw per in-vocabulary word, as orc_d2v_infer);
+ *   2. a reduced window b[i] in [0, window) per kept position (gensim draws them with ONE numpy randint call from the
+ *      model's hidden RandomState; here they continue the same explicit 48-bit LCG stream: b[i] = (state >> 16) % window,
+ *      one step per position, after the pass of 1.);
+ *   3. for every kept position i: context = kept positions [max(0, i - window + b), min(n, i + window + 1 - b)) without i;
+ *      l1 = sum of the context words' vectors (ascending position) + the document vector, count = context size + 1,
+ *      dm_mean: l1 *= 1 / count;  work = sum over the (1 + negative) targets of g * syn1neg[target] with
+ *      f = l1 . syn1neg[target] (targets, draws, EXP_TABLE and skips exactly as fast_document_dbow_neg above);
+ *      not dm_mean: work *= 1 / count;  document vector += work (lockf = 1).
+ * word_vectors: float32 [V][dim], the model's wv.vectors (frozen during inference).  The float32 operation order is the
+ * one shared with the HIP kernel: sums element-wise in the order given, dot = dot_wave64.  Documents with more than
+ * max_kept kept words are an error for the caller to rule out (the HIP kernel holds a document's kept list in LDS).
+ */
+static void infer_one_dm(const float* syn1neg, const float* wv, const uint32_t* cum_table, int64_t V, const uint32_t* sample_int,
+                         int dim, const int32_t* words, int nwords, const float* v0, uint64_t seed, int epochs, float alpha0,
+                         float min_alpha, int negative, double exp_scale, int window, int dm_mean, const float* exp_table, float* out) {
+    const uint64_t MOD = 281474976710655ULL;
+    float* v = out;
+    float* work = (float*)malloc(sizeof(float) * (size_t)dim);
+    float* l1 = (float*)malloc(sizeof(float) * (size_t)dim);
+    int32_t* kept = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nwords > 0 ? nwords : 1));
+    int32_t* red = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nwords > 0 ? nwords : 1));
+    memcpy(v, v0, sizeof(float) * (size_t)dim);
+    double alpha = (double)alpha0;
+    double alpha_delta = ((double)alpha0 - (double)min_alpha) / (double)(epochs - 1 > 1 ? epochs - 1 : 1);
+    for (int e = 0; e < epochs; ++e) {
+        uint64_t next_random = splitmix64(seed + (uint64_t)e) & MOD;
+        const float a = (float)alpha;
+        int n = 0;
+        for (int i = 0; i < nwords; ++i) {
+            int32_t w = words[i];
+            if (w < 0 || w >= V) continue;
+            if (sample_int) {
+                uint64_t r = next_random >> 16;
+                next_random = (next_random * 25214903917ULL + 11) & MOD;
+                if ((uint64_t)sample_int[w] < r) continue;
+            }
+            kept[n++] = w;
+        }
+        for (int i = 0; i < n; ++i) {
+            red[i] = (int32_t)((next_random >> 16) % (uint64_t)window);
+            next_random = (next_random * 25214903917ULL + 11) & MOD;
+        }
+        for (int i = 0; i < n; ++i) {
+            int j = i - window + red[i], k = i + window + 1 - red[i];
+            if (j < 0) j = 0;
+            if (k > n) k = n;
+            memset(l1, 0, sizeof(float) * (size_t)dim);
+            float count = 0.0f;
+            for (int m = j; m < k; ++m) {
+                if (m == i) continue;
+                count += 1.0f;
+                const float* row = wv + (int64_t)kept[m] * dim;
+                for (int c = 0; c < dim; ++c) l1[c] = l1[c] + row[c];
+            }
+            count += 1.0f;                                                   /* the one document tag */
+            for (int c = 0; c < dim; ++c) l1[c] = l1[c] + v[c];
+            const float inv_count = 1.0f / count;
+            if (dm_mean)
+                for (int c = 0; c < dim; ++c) l1[c] = l1[c] * inv_count;
+            memset(work, 0, sizeof(float) * (size_t)dim);
+            const int32_t w = kept[i];
+            for (int d = 0; d < negative + 1; ++d) {
+                uint32_t target;
+                float label;
+                if (d == 0) {
+                    target = (uint32_t)w;
+                    label = 1.0f;
+                } else {
+                    target = bisect_left_u32(cum_table, (next_random >> 16) % cum_table[V - 1], 0, (uint64_t)V);
+                    next_random = (next_random * 25214903917ULL + 11) & MOD;
+                    if (target == (uint32_t)w) continue;
+                    label = 0.0f;
+                }
+                const float* row = syn1neg + (int64_t)target * dim;
+                float f = dot_wave64(l1, row, dim);
+                if (f <= -ORC_MAX_EXP || f >= ORC_MAX_EXP) continue;
+                f = exp_table[(int)((double)(f + (float)ORC_MAX_EXP) * exp_scale)];
+                float g = (label - f) * a;
+                for (int c = 0; c < dim; ++c) work[c] = fmaf(g, row[c], work[c]);
+            }
+            if (!dm_mean)
+                for (int c = 0; c < dim; ++c) work[c] = work[c] * inv_count;
+            for (int c = 0; c < dim; ++c) v[c] = v[c] + work[c];
+        }
+        alpha -= alpha_delta;
+    }
+    free(work);
+    free(l1);
+    free(kept);
+    free(red);
+}
+
+void orc_d2v_infer_dm(const float* syn1neg, const float* word_vectors, const uint32_t* cum_table, int64_t V, const uint32_t* sample_int,
+                      int dim, const int64_t* doc_ptr, const int32_t* words, int64_t ndocs, const float* v0, const uint64_t* seeds,
+                      int epochs, float alpha, float min_alpha, int negative, double exp_scale, int window, int dm_mean, float* out) {
+    float table[ORC_EXP_TABLE_SIZE];
+    orc_exp_table(table);
+    for (int64_t d = 0; d < ndocs; ++d) {
+        infer_one_dm(syn1neg, word_vectors, cum_table, V, sample_int, dim, words + doc_ptr[d], (int)(doc_ptr[d + 1] - doc_ptr[d]),
+                     v0 + d * dim, seeds[d], epochs, alpha, min_alpha, negative, exp_scale, window, dm_mean, table, out + d * dim);
     }
 }
 

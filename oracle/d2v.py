@@ -43,6 +43,33 @@ def infer(syn1neg: np.ndarray, cum_table: np.ndarray, sample_int, doc_ptr: np.nd
     return out
 
 
+def infer_dm(syn1neg: np.ndarray, word_vectors: np.ndarray, cum_table: np.ndarray, sample_int, doc_ptr: np.ndarray, words: np.ndarray,
+             v0: np.ndarray, seeds: np.ndarray, epochs: int, alpha: float = 0.025, min_alpha: float = 1e-4, negative: int = 5,
+             exp_scale: float = 83.0, window: int = 5, dm_mean: int = 1) -> np.ndarray:
+    """PV-DM inference (orc_d2v_infer_dm: doc2vec_inner.pyx::train_document_dm with frozen word vectors and hidden layer)."""
+    syn1neg = np.ascontiguousarray(syn1neg, dtype=np.float32)
+    word_vectors = np.ascontiguousarray(word_vectors, dtype=np.float32)
+    cum_table = np.ascontiguousarray(cum_table, dtype=np.uint32)
+    V, dim = syn1neg.shape
+    assert word_vectors.shape == (V, dim)
+    doc_ptr = np.ascontiguousarray(doc_ptr, dtype=np.int64)
+    words = np.ascontiguousarray(words, dtype=np.int32)
+    v0 = np.ascontiguousarray(v0, dtype=np.float32)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    n = len(doc_ptr) - 1
+    out = np.empty((n, dim), dtype=np.float32)
+    si = None if sample_int is None else np.ascontiguousarray(sample_int, dtype=np.uint32)
+    f = lib().orc_d2v_infer_dm
+    f.restype = None
+    P = ctypes.c_void_p
+    f(syn1neg.ctypes.data_as(P), word_vectors.ctypes.data_as(P), cum_table.ctypes.data_as(P), ctypes.c_int64(V),
+      si.ctypes.data_as(P) if si is not None else None, ctypes.c_int(dim), doc_ptr.ctypes.data_as(P), words.ctypes.data_as(P),
+      ctypes.c_int64(n), v0.ctypes.data_as(P), seeds.ctypes.data_as(P), ctypes.c_int(epochs), ctypes.c_float(alpha),
+      ctypes.c_float(min_alpha), ctypes.c_int(negative), ctypes.c_double(exp_scale), ctypes.c_int(window), ctypes.c_int(dm_mean),
+      out.ctypes.data_as(P))
+    return out
+
+
 def build_vocab(docs, sample: float = 1e-3, ns_exponent: float = 0.75):
     """gensim Doc2Vec.build_vocab with min_count=1 as genmodel.py:159-160 calls it [published algorithm, PARITY UNPINNED]:
     vocabulary sorted by descending count (ties: first occurrence first), `sample_int` from the sub-sampling formula of

@@ -31,6 +31,52 @@ def test_d2v_infer_bit_exact(dim, V, ndocs, epochs, with_sample):
     assert not np.array_equal(got, v0)
 
 
+@pytest.mark.parametrize("dim,V,ndocs,epochs,window,dm_mean,with_sample", [(300, 2000, 120, 20, 50, 1, True), (300, 2000, 40, 100, 5, 0, False),
+                                                                             (64, 500, 100, 7, 3, 1, True), (100, 70, 50, 5, 50, 0, True)])
+def test_d2v_infer_dm_bit_exact(dim, V, ndocs, epochs, window, dm_mean, with_sample):
+    """PV-DM inference (dm=1: mean or sum of context word vectors + document vector; the form BASELINE.json's north_star names) against
+    the C oracle with the same explicit inputs -- document vectors bit for bit.  window 50 is the reference model's (genmodel.py:159),
+    3 and 5 cut the context inside a document so the reduced windows matter."""
+    from hiptagsearch import synth
+    from hiptagsearch.d2v import Doc2VecInference
+    from oracle import d2v as od2v
+    ptr, terms = synth.tag_corpus(D=ndocs, V=V, seed=9)
+    terms = terms.copy()
+    terms[::13] = -1
+    counts = synth.term_counts(ptr, terms, V)
+    m = synth.d2v_model(counts, dim=dim, seed=45)
+    wv = (np.random.default_rng(46).standard_normal((V, dim)) * 0.3).astype(np.float32)      # a trained model's word vectors: O(0.1 .. 1)
+    v0, seeds = synth.d2v_inputs(ndocs, dim, seed=45)
+    si = m["sample_int"] if with_sample else None
+    model = Doc2VecInference(m["syn1neg"], m["cum_table"], si, {}, epochs=epochs, dm=1, word_vectors=wv, window=window, dm_mean=dm_mean)
+    got = model.infer_batch(ptr, terms, v0, seeds)
+    want = od2v.infer_dm(m["syn1neg"], wv, m["cum_table"], si, ptr, terms, v0, seeds, epochs, window=window, dm_mean=dm_mean)
+    assert np.isfinite(got).all()
+    assert got.tobytes() == want.tobytes()
+    assert not np.array_equal(got, v0)
+    # and it is a different model from PV-DBOW on the same arrays
+    dbow = Doc2VecInference(m["syn1neg"], m["cum_table"], si, {}, epochs=epochs).infer_batch(ptr, terms, v0, seeds)
+    assert not np.array_equal(got, dbow)
+
+
+def test_d2v_infer_dm_refuses_what_it_cannot_run():
+    import hiptagsearch
+    from hiptagsearch import synth
+    from hiptagsearch.d2v import Doc2Vec, Doc2VecInference
+    V, dim = 100, 64
+    ptr, terms = synth.tag_corpus(D=4, V=V, seed=1)
+    m = synth.d2v_model(synth.term_counts(ptr, terms, V), dim=dim)
+    with pytest.raises(ValueError):
+        Doc2VecInference(m["syn1neg"], m["cum_table"], None, {}, dm=1)                      # no word vectors
+    with pytest.raises(NotImplementedError):
+        Doc2Vec(vector_size=dim, dm=1)                                                      # training stays PV-DBOW
+    wv = np.zeros((V, dim), np.float32)
+    model = Doc2VecInference(m["syn1neg"], m["cum_table"], None, {}, epochs=2, dm=1, word_vectors=wv, window=5, dm_mean=1)
+    long_ptr = np.array([0, 600], dtype=np.int64)
+    with pytest.raises(hiptagsearch.HipTagSearchError):
+        model.infer_batch(long_ptr, np.zeros(600, np.int32), np.zeros((1, dim), np.float32), np.zeros(1, np.uint64))
+
+
 def test_d2v_gensim_shaped_interface():
     from hiptagsearch import synth
     from hiptagsearch.d2v import Doc2VecInference
