@@ -74,6 +74,7 @@ struct hipts_vit {
     int pend_ns = 0, pend_batch = 0;              // an UNJOINED forward (deferred join) of pend_batch images on pend_ns streams may still run
     hipStream_t sub[kMaxSub] = {};                // internal streams of the sub-batches
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSub] = {};
+    hipEvent_t ev_stagger = nullptr;              // HIPTS_VIT_STAGGER: recorded on sub-batch stream 0 after a chosen launch, waited for by the later streams
 };
 
 namespace {
@@ -410,6 +411,7 @@ int hipts_vit_destroy(hipts_vit_t* h) {
         for (auto e : h->ev_join)
             if (e) (void)hipEventDestroy(e);
         if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_stagger) (void)hipEventDestroy(h->ev_stagger);
         delete h;
     }
     return HIPTS_OK;
@@ -600,7 +602,8 @@ int prof_resolve(hipts_vit* h) {
 // The whole kernel sequence for images [i0, i0 + nb) of the current call, on stream s.  Every workspace
 // buffer is indexed by image (rows of M = batch * tokens, or (image, head) blocks), so disjoint image
 // ranges can run on different streams at the same time.
-int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb, float* lg, float* pr, hipStream_t s, bool shared_chip) {
+int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb, float* lg, float* pr, hipStream_t s, bool shared_chip,
+                   int stagger_at = 0) {
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
     const int M = nb * T;
@@ -709,13 +712,21 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
             ProfScope ps(h, s, PC_GEMM_QK, 2.0 * dM * 3 * dD * dD, dM * dD * 2 + dM * 3 * dD * 2);
             HIPTS_TRY(launch_gemm(EPI_QK, g, s));
         }
+        // HIPTS_VIT_STAGGER (A/B): the later sub-batch streams start only when stream 0 is this far into its FIRST layer, so that the
+        // streams run out of phase -- one's attention (32 KB of LDS per workgroup) beside the other's GEMMs (128 KB) on the same CUs
+        auto stagger = [&](int pos) {
+            if (li == 0 && stagger_at == pos && h->ev_stagger) (void)hipEventRecord(h->ev_stagger, s);
+        };
+        stagger(1);
         {
             ProfScope ps(h, s, PC_ATTENTION, 4.0 * nb * H * dT * dT * 64, dM * dD * 2 * 4);
             HIPTS_TRY(launch_attention2(q, k, v, att, nb, H, T, Tp, f16, s, 0, 0, h->split_att ? 1 : 0, split_lo_scale(f16)));
         }
+        stagger(2);
         // x += att Wp^T + b  (+ norm2 prepared)
         HIPTS_TRY(residual(att, L.proj_w.as<bf16_t>(), L.proj_b.as<float>(), att_k, fold ? L.ln2_g.as<float>() : nullptr, 2.0 * dM * dD * att_k,
                            dM * att_k * 2 + dM * dD * 8));
+        stagger(3);
         if (!fold) HIPTS_TRY(layernorm(L.ln2_g.as<float>(), L.ln2_b.as<float>()));
         g = GemmArgs{};
         g.f16 = f16;
@@ -727,10 +738,12 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
             ProfScope ps(h, s, PC_GEMM_GELU, 2.0 * dM * dD * dMlp, dM * dD * 2 + dM * dMlp * 2);
             HIPTS_TRY(launch_gemm(EPI_GELU, g, s));
         }
+        stagger(4);
         // x += hmid W2^T + b  (+ the next layer's norm1 prepared)
         HIPTS_TRY(residual(hmid, L.fc2_w.as<bf16_t>(), L.fc2_b.as<float>(), c.mlp_dim,
                            (fold && li + 1 < c.depth) ? h->layers[li + 1].ln1_g.as<float>() : nullptr, 2.0 * dM * dD * dMlp,
                            dM * dMlp * 2 + dM * dD * 8));
+        stagger(5);
     }
     // final norm + mean pool (+ hi/lo split)
     {
@@ -811,10 +824,13 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
                 if (!h->ev_join[i]) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
             }
         HIPTS_HIP(hipEventRecord(h->ev_fork, s));
+        static const int stagger_at = getenv("HIPTS_VIT_STAGGER") ? atoi(getenv("HIPTS_VIT_STAGGER")) : 0;
+        if (stagger_at > 0 && !h->ev_stagger) HIPTS_HIP(hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming));
         for (int i = 0; i < ns; ++i) {
             const int i0 = (int)((int64_t)batch * i / ns), i1 = (int)((int64_t)batch * (i + 1) / ns);
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i], true));
+            if (i > 0 && stagger_at > 0) HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_stagger, 0));
+            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i], true, i == 0 ? stagger_at : 0));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
             if (!h->deferred_join || !dev_out) HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }

@@ -133,8 +133,12 @@ def test_vit_trained_like_checkpoint():
     print("trained-like checkpoint: logit rms %.2f" % np.sqrt((want ** 2).mean()))
     for i in range(len(imgs)):
         print("  %-10s max |dlogit| %.3e  rms %.3e  rms-relative %.3e" % (kinds[i], mx[i], rms[i], rel[i]))
-    assert rel.max() <= 3e-4, rel
-    assert mx.max() <= 2e-2, mx
+    # measured (round 4, profiles/r04_precision_vit.json): rms-relative <= 6.7e-5, max |dlogit| 5.2e-4 .. 3.0e-3 (half flat; flat 1.7e-3) --
+    # north_star's absolute 1e-3 is NOT met on four of the eight kinds at this logit scale; DESIGN.md section 2 has the attribution
+    # per rounded operand and what meeting it costs (operand_f16 bit 4 removes the flat-image class for 5 %; everything else > 40 %)
+    assert rel.max() <= 1.5e-4, rel
+    assert mx.max() <= 5e-3, mx
+    assert np.median(mx) <= 1.2e-3, mx
     # what the product outputs: the selected labels (MCut on both categories, tagging.py:333) equal the oracle's on every image
     names, cat = synth.label_table(cfg["num_classes"])
     sel = TagSelector(cat, max_batch=8)
