@@ -50,6 +50,7 @@ struct hipts_eva {
     DevBuf img_in, a0, tmp, x, xn, q, k, v, att, g1, stat_part, rowstat, xstat, pool_part, pooled2, logits, probs;
     bool fold_ln = false, fold_dirty = true;      // as in the ViT forward (vit.hip)
     bool split_att = false;                       // cfg.operand_f16 bit 4 (HIPTS_OPERAND_SPLIT_ATT), as in the ViT forward
+    DevBuf sk_ws;                                 // split-K workspaces of proj / fc2 (GemmArgs::sk_ws), one per sub-batch stream, zeroed once
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
 };
@@ -213,7 +214,8 @@ int alloc_zero(DevBuf& buf, size_t bytes) {
 }
 
 // The whole kernel sequence for images [i0, i0 + batch) on stream s (every buffer is indexed by image)
-int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int batch, float* lg, float* pr, hipStream_t s, bool shared_chip) {
+int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int batch, float* lg, float* pr, hipStream_t s, bool shared_chip,
+                   int sub = 0) {
     const auto& c = h->cfg;
     const int S = c.image_size, D = c.dim, P = c.patch, H = c.heads, T = h->T, TS = h->TS, Tp = h->Tp, np = h->np;
     const bool f16 = (c.operand_f16 & 1) != 0;
@@ -286,6 +288,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.f16 = f16;
         g.shared_chip = shared_chip;
         g.A = att_p; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = att_k; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
+        g.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; g.sk_ws_bytes = GEMM_SK_WS_BYTES;      // split-K when the launch under-fills the chip
         if (fold) {
             g.out_bf16 = xn; g.ln_gamma = L.ln2_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
             HIPTS_TRY(launch_gemm(EPI_RESID_XG, g, s));
@@ -309,6 +312,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.f16 = f16;
         g.shared_chip = shared_chip;
         g.A = g1_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_c.as<float>(); g.out_f32 = x;
+        g.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; g.sk_ws_bytes = GEMM_SK_WS_BYTES;
         static const bool rowstat_kernel = getenv("HIPTS_EVA_ROWSTAT_KERNEL") && atoi(getenv("HIPTS_EVA_ROWSTAT_KERNEL"));      // A/B: finish the pairs in a kernel of its own
         if (rowstat_kernel) {
             HIPTS_TRY(launch_rowstat(stat_p, rowstat_p, M, M, sblocks, c.mlp_hidden, c.ln_eps, s));
@@ -333,6 +337,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     g.f16 = f16;
     g.shared_chip = shared_chip;
     g.A = pooled2_p; g.W = h->head_w.as<bf16_t>(); g.M = batch; g.N = c.num_classes; g.K = 2 * D;
+    g.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; g.sk_ws_bytes = GEMM_SK_WS_BYTES;      // split-K: 43 tiles on 256 CUs
     g.bias = h->head_b.as<float>(); g.out_f32 = lg; g.out2_f32 = pr;
     HIPTS_TRY(launch_gemm(EPI_HEAD, g, s));
     return HIPTS_OK;
@@ -384,7 +389,7 @@ int eva_forward_impl(hipts_eva* h, const void* input, int in_memspace, bool is_u
         const int nb0 = (batch + 1) / 2;
         for (int i = 0; i < 2; ++i) {
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-            HIPTS_TRY(eva_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, lg, pr, h->sub[i], true));
+            HIPTS_TRY(eva_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, lg, pr, h->sub[i], true, i));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
             HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
@@ -433,7 +438,8 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->v, qk)) ||
         (st = alloc_zero(h->att, M * D * 2 * (h->split_att ? 2 : 1))) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
         (st = h->stat_part.alloc((size_t)((2 * h->HK + 255) / 256) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
-        (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4))) {
+        (st = h->logits.alloc((size_t)B * cfg->num_classes * 4)) || (st = h->probs.alloc((size_t)B * cfg->num_classes * 4)) ||
+        (st = alloc_zero(h->sk_ws, 2 * GEMM_SK_WS_BYTES))) {      // split-K tickets start at zero (the kernels leave them so)
         delete h;
         return st;
     }

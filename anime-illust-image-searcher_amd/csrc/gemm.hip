@@ -1036,13 +1036,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // of a (row block, column block), so the four phases split the column blocks instead of the K halves --
 // phase = (m-half, j-half): 4 x 2 MFMAs, the same 256 matrix-pipe cycles -- and barriers, staging order and counted
 // waits are unchanged.  W fragments are read in phases 0/1 and kept; A fragments in phases 0 and 2.
-template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false>
+// SK (round 4): the split-K tail of GemmArgs::sk_* -- work items past sk_first are (tile, K slice) pairs.  A separate instantiation, so
+// the default kernels' code is untouched.
+template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false, bool SK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
+    static_assert(!SK || (!OP8 && MR == 8), "split-K: 16-bit operands, full tiles");
     constexpr int TBM = 2 * MR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float2 st_table[256];        // folded LayerNorm: (rstd, rstd * mean) of the current tile's rows
     __shared__ float2 sw_red[EPI == EPI_SWIGLU ? 1024 : 1];      // SWIGLU: [256 rows][4 waves] partial row sums of the product
+    __shared__ unsigned sk_ticket[SK ? 4 : 1];                  // SK: the ticket lane 0 drew, for the whole workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
@@ -1079,8 +1083,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
         m0 = (bid / tiles_n) * TBM;
         n0 = (bid % tiles_n) * BN;
     };
-    const int K = OP8 ? a.K / 2 : a.K, nt = K / BK;      // row stride in 16-bit units
+    const int K = OP8 ? a.K / 2 : a.K, nt_all = K / BK;      // row stride in 16-bit units
     const int w_rows = tiles_n * BN;
+    // Work items: tiles [0, sk_first) whole, then (tile, slice) pairs; without SK an item is a tile.
+    const int S = SK ? a.sk_slices : 1;
+    const int n_items = SK ? a.sk_first + (nwg - a.sk_first) * S : nwg;
+    auto decode = [&](int item, int& tid_, int& slice_, int& kt0_, int& ntl_) {
+        if (!SK || item < a.sk_first) {
+            tid_ = item; slice_ = -1; kt0_ = 0; ntl_ = nt_all;
+        } else {
+            const int j = item - a.sk_first;
+            tid_ = a.sk_first + j / S;
+            slice_ = j - (j / S) * S;
+            kt0_ = slice_ * nt_all / S;
+            ntl_ = (slice_ + 1) * nt_all / S - kt0_;
+        }
+    };
     const int scale_w = (127 - a.w_exp) * 0x01010101, scale_1 = 127 * 0x01010101;
 
     int stamp_tile = 0;
@@ -1093,13 +1111,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }                                                                                                \
     } while (0)
-    int tile = blockIdx.x, m0, n0;
-    tile_origin(tile, m0, n0);
+    int tile = blockIdx.x, m0, n0;      // `tile`: the work item
+    int tix, slice, kt0, nt;             // its tile, K slice (-1: whole K), first K-tile and K-tile count
+    decode(tile, tix, slice, kt0, nt);
+    tile_origin(tix, m0, n0);
     int par = 0;        // K-tile t of the current output tile lives in LDS stage (par + t) & 1
 
     // prologue of the first tile: K-tile 0 complete
-    if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0, 0, smem, wave, lane);     // 4 MR sub-tiles of 8 rows (wave 7 idle for MR = 7)
-    stage_tile(a.W, w_rows, K, n0, 0, smem + TILE_BYTES, wave, lane);
+    if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0, kt0, smem, wave, lane);     // 4 MR sub-tiles of 8 rows (wave 7 idle for MR = 7)
+    stage_tile(a.W, w_rows, K, n0, kt0, smem + TILE_BYTES, wave, lane);
 
     for (;;) {
         f32x4 acc[MR][4];
@@ -1121,7 +1141,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
                 int grow = (isW ? n0 : m0) + rb8 * 8 + row_in;
                 const int lim = isW ? w_rows : a.M;
                 grow = grow < lim ? grow : lim - 1;
-                src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + BK + chunk * 8;
+                src[idx] = (isW ? a.W : a.A) + (size_t)grow * K + (size_t)(kt0 + 1) * BK + chunk * 8;
                 dst[idx] = (isW ? TILE_BYTES : 0) + rb8 * 1024;
             };
             // A-low = the first 64 rows of each wave group (8-row blocks g*2*MR + 0..7): 16 sub-tiles, 2 per wave.
@@ -1318,16 +1338,73 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
         float2 st_pv[4];
         if (fold_st && !fold_many && tid < TBM) row_stat_request(a, m0 + tid, st_pv);
         const int next = tile + gridDim.x;
-        const bool has_next = next < nwg;
-        int m0n = 0, n0n = 0;
+        const bool has_next = next < n_items;
+        int m0n = 0, n0n = 0, tixn = 0, slicen = -1, kt0n = 0, ntn = nt_all;
         const int par_next = (par + nt) & 1;
         if (has_next) {
-            tile_origin(next, m0n, n0n);
+            decode(next, tixn, slicen, kt0n, ntn);
+            tile_origin(tixn, m0n, n0n);
             char* st = smem + par_next * STAGE_BYTES;
-            if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0n, 0, st, wave, lane);
-            stage_tile(a.W, w_rows, K, n0n, 0, st + TILE_BYTES, wave, lane);
+            if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0n, kt0n, st, wave, lane);
+            stage_tile(a.W, w_rows, K, n0n, kt0n, st + TILE_BYTES, wave, lane);
         }
         PPSTAMP(4);
+        bool run_epilogue = true;       // uniform over the workgroup
+        if constexpr (SK) {
+            if (slice >= 0) {
+                constexpr size_t SLAB = (size_t)TBM * BN * 4;
+                const int tl = tix - a.sk_first;
+                unsigned* tickets = reinterpret_cast<unsigned*>(a.sk_ws);
+                char* slabs = reinterpret_cast<char*>(a.sk_ws) + 4096 + (size_t)tl * S * SLAB;
+                // (1) this slice's accumulators into its slab, write-through (sc1: no release fence needed, the bytes are at the memory
+                // side when vmcnt says so): [wave][i][j][lane] f32x4, 1 KB per store instruction
+                {
+                    const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)slice * SLAB, 0, (int)SLAB, 0x00020000);
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, (((wave * MR + i) * 4 + j) * 64 + lane) * 16, 0, 16);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains (this also lands the next item's first K-tile)
+                __builtin_amdgcn_s_barrier();
+                if (threadIdx.x == 0)
+                    sk_ticket[0] = __hip_atomic_fetch_add(tickets + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const unsigned ticket = sk_ticket[0];
+                if (ticket != (unsigned)(S - 1)) {
+                    run_epilogue = false;                              // somebody else finishes this tile
+                } else {
+                    // (2) the last arriver: every slab is complete.  One agent-scope acquire (this CU's L1), then plain loads; the
+                    // ticket word goes back to zero for the next launch (nobody else touches it any more).
+                    if (threadIdx.x == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        __hip_atomic_store(tickets + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    // slabs in slice order: the sum does not depend on which slice this workgroup computed
+                    const f32x4* sl = reinterpret_cast<const f32x4*>(slabs) + (size_t)(wave * MR * 4) * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = sl[(size_t)(i * 4 + j) * 64];
+                        for (int sx = 1; sx < S; ++sx) {
+                            const f32x4* sp = sl + (size_t)sx * (SLAB / 16);
+                            f32x4 v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = sp[(size_t)(i * 4 + j) * 64];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + v[j];
+                        }
+                    }
+                }
+            }
+        }
+        if (run_epilogue) {
         if (fold_st) {      // uniform over the workgroup
             if (fold_many) {
                 if (tid < TBM) st_table[tid] = row_stat(a, m0 + tid);       // sums the partials in index order (deterministic), 8 loads in flight
@@ -1365,10 +1442,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
         if (!staged)
             gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre, smem + ((par + nt + 1) & 1) * STAGE_BYTES,
                                         fold_st ? st_table : nullptr);
+        }       // run_epilogue
         PPSTAMP(5);
         ++stamp_tile;
         if (!has_next) break;
         tile = next;
+        tix = tixn;
+        slice = slicen;
+        kt0 = kt0n;
+        nt = ntn;
         m0 = m0n;
         n0 = n0n;
         par = par_next;
@@ -1939,6 +2021,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
                         mr = c;
                     }
             }
+            if (EPI == EPI_HEAD && a.sk_ws) mr = 8;       // the split-K instantiation is built for 256-row tiles; the head is bound by its weight bytes
             const int tiles_mr = tiles_of(mr);
             // persistent grid: one workgroup per CU (a multiple of 8 so that a workgroup's tiles keep their XCD)
             static const bool persist = !(getenv("HIPTS_GEMM_PERSIST") && strcmp(getenv("HIPTS_GEMM_PERSIST"), "0") == 0);
@@ -1950,6 +2033,48 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             GemmArgs ar = a;
             ar.raster_gm = (raster > 0 && tiles_n >= 8) ? raster : 0;
             ar.raster_gn = (raster_gn > 0 && tiles_n >= 8 && tiles_n > raster_gn) ? raster_gn : 0;
+            // Split-K tail (GemmArgs::sk_*): the residual GEMMs with a long K whose last round fills less than half of the chip -- EVA02-L's
+            // proj / fc2 at the reference's batch of 10 (84 tiles per sub-batch on 256 CUs), the ViT's fc2 per 32-image sub-batch (294 tiles:
+            // 38 in the second round).  S <= HIPTS_GEMM_SPLITK, at least HIPTS_GEMM_SPLITK_MINKT K-tiles per slice (default 5: a slice's slab
+            // costs its writer ~3 us and the last arriver ~3 us per slab, a K-tile ~1.5 us).
+            // OFF unless HIPTS_GEMM_SPLITK >= 2: a tile summed as S partial chains has other low bits than the same tile summed as one chain,
+            // and WHICH tiles are split depends on the launch's size -- an image's logits would depend on the batch it travels in
+            // (tests/test_gpu_vit.py::test_folded_layernorm_path..., test_gpu_gemm.py::test_forward_is_deterministic_and_batch_invariant) and
+            // the sharded CLIs' byte-equal output files on the shard sizes.  Run to run the split IS deterministic (slabs added in slice order).
+            // The tag head (EPI_HEAD) is split by default: its launch is ONE row panel (batch <= 256) of 43 column tiles whatever the batch, so
+            // every image's logits are summed as the same four partial chains in every batch -- 43 workgroups pulling 33 MB of weights took
+            // 51 us per sub-batch forward.  HIPTS_GEMM_SPLITK_HEAD=0 turns it off.
+            if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_RESID_ROWSTAT || EPI == EPI_HEAD) {
+                static const int sk_env = getenv("HIPTS_GEMM_SPLITK") ? atoi(getenv("HIPTS_GEMM_SPLITK")) : 0;
+                static const int sk_head = getenv("HIPTS_GEMM_SPLITK_HEAD") ? atoi(getenv("HIPTS_GEMM_SPLITK_HEAD")) : 4;
+                const int sk_max = EPI == EPI_HEAD ? (tiles_mr == 1 ? sk_head : 0) : sk_env;
+                static const int sk_minkt = getenv("HIPTS_GEMM_SPLITK_MINKT") ? atoi(getenv("HIPTS_GEMM_SPLITK_MINKT")) : 5;
+                const int nkt = a.K / BK;
+                const int rem = ntile % slots;      // tiles of the partial last round (the whole launch when it is smaller than the chip)
+                if (a.sk_ws && mr == 8 && sk_max >= 2 && rem > 0 && rem * 2 <= slots && rem <= 1024) {
+                    int sl = std::min(sk_max, std::min(slots / rem, nkt / (sk_minkt > 0 ? sk_minkt : 1)));
+                    while (sl >= 2 && 4096 + (size_t)rem * sl * ((size_t)BM * BN * 4) > a.sk_ws_bytes) --sl;
+                    if (sl >= 2) {
+                        static PerDevice attr_sk;
+                        {
+                            std::lock_guard<std::mutex> lk(attr_sk.mu);
+                            if (!attr_sk.done(dev)) {
+                                HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                                HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                                attr_sk.mark(dev);
+                            }
+                        }
+                        ar.sk_first = ntile - rem;
+                        ar.sk_slices = sl;
+                        const int items = ar.sk_first + rem * sl;
+                        const int grid_sk = (persist && items > slots) ? slots : items;
+                        if (a.f16) gemm_pp_kernel<EPI, 8, true, false, true><<<grid_sk, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
+                        else gemm_pp_kernel<EPI, 8, false, false, true><<<grid_sk, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
+                        HIPTS_LAUNCH_CHECK();
+                        return HIPTS_OK;
+                    }
+                }
+            }
             if (a.f16) {
                 if (mr == 6) gemm_pp_kernel<EPI, 6, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_mr, tiles_n);
                 else if (mr == 7) gemm_pp_kernel<EPI, 7, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_mr, tiles_n);

@@ -40,9 +40,22 @@ struct hipts_bm25 {
     DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
     DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out;
     PinBuf pin_in, pin_out;                    // hipts_search: one H2D of the packed queries, one D2H of the packed results
+    // hipts_search_submit / _collect (round 4): two batches in flight -- the host packs and launches batch i + 1 while the device runs batch i.
+    // The device workspaces are shared (the batches run on one stream, in order); only the pinned buffers exist per slot.
+    struct SearchSlot {
+        PinBuf pin_in, pin_out;
+        hipEvent_t done = nullptr;
+        int nq = 0, k = 0, kk = 0;
+        bool pending = false, host_result = false;      // host_result: the one-query path ran synchronously, its results wait in ids1 / vals1
+        std::vector<int32_t> ids1;
+        std::vector<double> vals1;
+    } slot[2];
     DevBuf s1_state;                           // one-query path: Search1State + group maxima + per-workgroup candidate slots
     uint32_t s1_seq = 0;                       // sequence number of the last one-query call (completion flag in pinned memory)
     bool s1_dirty = true;                      // s1_state may hold leftovers (first use, or a call that failed half way)
+    // batched hipts_search (round 4): BM25 postings on a side stream beside the index product -- the two do not depend on each other
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_bm25 = nullptr;
     // per-kernel HIP-event timing (hipts_query_profile_*): events on the stream each kernel is launched on
     bool prof = false;
     struct ProfRec { int cat; hipEvent_t a, b; double bytes; };
@@ -2020,6 +2033,14 @@ int hipts_bm25_build(const int64_t* doc_ptr, const int32_t* term_ids, int64_t nu
 int hipts_bm25_destroy(hipts_bm25_t* h) {
     if (h) {
         (void)hipSetDevice(h->device);
+        if (h->side) {
+            (void)hipStreamSynchronize(h->side);
+            (void)hipStreamDestroy(h->side);
+        }
+        for (auto& sl : h->slot)
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+        if (h->ev_bm25) (void)hipEventDestroy(h->ev_bm25);
         delete h;
     }
     return HIPTS_OK;
@@ -2306,31 +2327,44 @@ int hipts_topk_after(const double* vals, int64_t n, int k, double after_val, int
     return hipts_topk(mbuf.as<double>(), 1, n, k, ids_out, vals_out, HIPTS_HOST, device, stream);
 }
 
-int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights,
-                 const int32_t* q_ptr, const float* q_vectors, int nq, double w_bm25, double w_sim, int k, int32_t* ids_out,
-                 double* vals_out, double* final_out_device, void* stream) {
-    HIPTS_REQUIRE(bm25 && index && q_ptr && q_vectors && ids_out && vals_out && nq >= 1, "hipts_search: bad arguments");
+// One batch of queries: pack, copy, launch everything and the copy back into slot `sl`'s pinned buffer, record its event.  Does not wait.
+static int search_submit_impl(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr,
+                              const float* q_vectors, int nq, double w_bm25, double w_sim, int k, double* final_out_device, int sl, hipStream_t s) {
+    HIPTS_REQUIRE(bm25 && index && q_ptr && q_vectors && nq >= 1, "hipts_search: bad arguments");
+    HIPTS_REQUIRE(sl == 0 || sl == 1, "hipts_search_submit: slot must be 0 or 1");
     HIPTS_REQUIRE(bm25->device == index->device, "hipts_search: handles live on different devices");
     HIPTS_REQUIRE(bm25->D == index->len, "hipts_search: BM25 corpus has %lld documents, index has %lld rows",
                   (long long)bm25->D, (long long)index->len);
     HIPTS_TRY(use_device(bm25->device));
-    hipStream_t s = (hipStream_t)stream;
+    hipts_bm25::SearchSlot& S = bm25->slot[sl];
+    HIPTS_REQUIRE(!S.pending, "hipts_search_submit: slot %d still holds an uncollected batch", sl);
     const int64_t D = bm25->D;
     HIPTS_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "hipts_search: k must be in [1, %d]", TOPK_MAX_K);
     const int nt = q_ptr[nq];
     HIPTS_REQUIRE(q_ptr[0] == 0 && nt >= 0, "q_ptr must start at 0 and be non-decreasing");
+    S.nq = nq;
+    S.k = k;
     static const bool allow_one = !(getenv("HIPTS_SEARCH1") && strcmp(getenv("HIPTS_SEARCH1"), "0") == 0);       // A/B switch
-    if (nq == 1 && allow_one && nt <= S1_MAX_TERMS && index->dim <= S1_MAX_DIM && index->dim % 4 == 0 && index->tiled.p && D >= S1_MIN_DOCS)
-        return search_one(bm25, index, q_terms, q_weights, nt, q_vectors, w_bm25, w_sim, k, ids_out, vals_out, final_out_device, s);
+    if (nq == 1 && allow_one && nt <= S1_MAX_TERMS && index->dim <= S1_MAX_DIM && index->dim % 4 == 0 && index->tiled.p && D >= S1_MIN_DOCS) {
+        // the one-query path completes inside the call (its last kernel stores into pinned memory and the host spins on a flag)
+        S.ids1.resize((size_t)k);
+        S.vals1.resize((size_t)k);
+        HIPTS_TRY(search_one(bm25, index, q_terms, q_weights, nt, q_vectors, w_bm25, w_sim, k, S.ids1.data(), S.vals1.data(), final_out_device, s));
+        S.host_result = true;
+        S.pending = true;
+        return HIPTS_OK;
+    }
+    S.host_result = false;
+    if (!S.done) HIPTS_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
     // queries, weights, offsets and the query vectors travel as ONE packed copy from pinned memory (no bounce buffer, no
     // synchronisation before the kernels); the results come back the same way
     const size_t off_w = ((size_t)nt * 4 + 15) / 16 * 16;
     const size_t off_p = off_w + (size_t)nt * 8;
     const size_t off_v = (off_p + (size_t)(nq + 1) * 4 + 15) / 16 * 16;
     const size_t in_bytes = off_v + (size_t)nq * index->dim * 4;
-    HIPTS_TRY(bm25->pin_in.reserve(in_bytes));
+    HIPTS_TRY(S.pin_in.reserve(in_bytes));
     HIPTS_TRY(bm25->ws_q.reserve(in_bytes));
-    char* hin = bm25->pin_in.as<char>();
+    char* hin = S.pin_in.as<char>();
     if (nt) {
         memcpy(hin, q_terms, (size_t)nt * 4);
         memcpy(hin + off_w, q_weights, (size_t)nt * 8);
@@ -2359,15 +2393,31 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
     HIPTS_TRY(bm25->ws_max.reserve((size_t)nq * 16));
     double* ma = bm25->ws_max.as<double>();
     float* mb = reinterpret_cast<float*>(ma + nq);
+    // BM25 and the index product share no data.  Round 4 measured them on two streams (HIPTS_SEARCH_OVERLAP=1): 396-398 k queries/s either
+    // way -- side by side BM25 takes 234-336 us instead of 156-167 and the product 262-363 instead of 233: both fill the wave slots of
+    // every CU, so they take turns rather than share.  One stream stays the default.
+    static const bool overlap = getenv("HIPTS_SEARCH_OVERLAP") && atoi(getenv("HIPTS_SEARCH_OVERLAP")) != 0;
+    hipStream_t sb = s;
+    if (overlap) {
+        if (!bm25->side) {
+            HIPTS_HIP(hipStreamCreateWithFlags(&bm25->side, hipStreamNonBlocking));
+            HIPTS_HIP(hipEventCreateWithFlags(&bm25->ev_in, hipEventDisableTiming));
+            HIPTS_HIP(hipEventCreateWithFlags(&bm25->ev_bm25, hipEventDisableTiming));
+        }
+        sb = bm25->side;
+        HIPTS_HIP(hipEventRecord(bm25->ev_in, s));              // the packed queries are on the device
+        HIPTS_HIP(hipStreamWaitEvent(sb, bm25->ev_in, 0));
+    }
     {
         // algorithmic bytes: the posting lists of the queries' terms (8 B per entry + the document length gathered with it) and the
         // three passes over each query's score row (clear, mask / maximum) -- DESIGN.md section 4
         double pb = 0.0;
         for (int j = 0; j < nt; ++j)
             if (q_terms[j] >= 0 && q_terms[j] < bm25->V) pb += (double)bm25->h_df[q_terms[j]] * 12.0;
-        QueryProfScope ps(bm25, s, QP_BM25, pb + (double)nq * D * 8.0 * 3);
-        HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), s, ma));
+        QueryProfScope ps(bm25, sb, QP_BM25, pb + (double)nq * D * 8.0 * 3);
+        HIPTS_TRY(launch_bm25(bm25, qt, qw, qp, nq, bm25->ws_scores.as<double>(), sb, ma));
     }
+    if (overlap) HIPTS_HIP(hipEventRecord(bm25->ev_bm25, sb));
     {
         QueryProfScope ps(bm25, s, QP_SIM, (double)sim_index_passes(index->tiled.p != nullptr, index->dim, nq) * D * index->dim * 4.0 + (double)nq * D * 4.0);
         HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s));
@@ -2377,6 +2427,7 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
         rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
         HIPTS_LAUNCH_CHECK();
     }
+    if (overlap) HIPTS_HIP(hipStreamWaitEvent(s, bm25->ev_bm25, 0));      // BM25 rows and their maxima are complete
     if (!fused) {
         QueryProfScope ps(bm25, s, QP_COMBINE, (double)nq * D * 20.0);
         dim3 grid(ceil_div(D, 256), nq);
@@ -2385,9 +2436,10 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
         HIPTS_LAUNCH_CHECK();
     }
     const int kk = (int)std::min<int64_t>(k, D);
+    S.kk = kk;
     const size_t out_bytes = (size_t)nq * kk * 12;
     HIPTS_TRY(bm25->ws_out.reserve(out_bytes + 64));
-    HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 64));
+    HIPTS_TRY(S.pin_out.reserve(out_bytes + 64));
     double* ov = bm25->ws_out.as<double>();
     int32_t* oi = reinterpret_cast<int32_t*>(ov + (size_t)nq * kk);
     {
@@ -2406,16 +2458,57 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_term
         }
         HIPTS_LAUNCH_CHECK();
     }
-    HIPTS_HIP(hipMemcpyAsync(bm25->pin_out.p, ov, out_bytes, hipMemcpyDeviceToHost, s));
-    HIPTS_HIP(hipStreamSynchronize(s));
-    const double* hv = bm25->pin_out.as<double>();
-    const int32_t* hi = reinterpret_cast<const int32_t*>(hv + (size_t)nq * kk);
-    for (int q = 0; q < nq; ++q)
-        for (int i = 0; i < k; ++i) {
-            ids_out[(size_t)q * k + i] = i < kk ? hi[(size_t)q * kk + i] : -1;
-            vals_out[(size_t)q * k + i] = i < kk ? hv[(size_t)q * kk + i] : -INFINITY;
-        }
+    HIPTS_HIP(hipMemcpyAsync(S.pin_out.p, ov, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPTS_HIP(hipEventRecord(S.done, s));
+    S.pending = true;
     return HIPTS_OK;
+}
+
+static int search_collect_impl(hipts_bm25_t* bm25, int sl, int32_t* ids_out, double* vals_out) {
+    HIPTS_REQUIRE(bm25 && ids_out && vals_out && (sl == 0 || sl == 1), "hipts_search_collect: bad arguments");
+    hipts_bm25::SearchSlot& S = bm25->slot[sl];
+    HIPTS_REQUIRE(S.pending, "hipts_search_collect: slot %d holds no submitted batch", sl);
+    S.pending = false;
+    const int k = S.k;
+    if (S.host_result) {
+        memcpy(ids_out, S.ids1.data(), (size_t)k * 4);
+        memcpy(vals_out, S.vals1.data(), (size_t)k * 8);
+        return HIPTS_OK;
+    }
+    HIPTS_TRY(use_device(bm25->device));
+    HIPTS_HIP(hipEventSynchronize(S.done));
+    const int nq = S.nq, kk = S.kk;
+    const double* hv = S.pin_out.as<double>();
+    const int32_t* hi = reinterpret_cast<const int32_t*>(hv + (size_t)nq * kk);
+    if (kk == k) {
+        memcpy(ids_out, hi, (size_t)nq * k * 4);
+        memcpy(vals_out, hv, (size_t)nq * k * 8);
+    } else {
+        for (int q = 0; q < nq; ++q)
+            for (int i = 0; i < k; ++i) {
+                ids_out[(size_t)q * k + i] = i < kk ? hi[(size_t)q * kk + i] : -1;
+                vals_out[(size_t)q * k + i] = i < kk ? hv[(size_t)q * kk + i] : -INFINITY;
+            }
+    }
+    return HIPTS_OK;
+}
+
+int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights,
+                 const int32_t* q_ptr, const float* q_vectors, int nq, double w_bm25, double w_sim, int k, int32_t* ids_out,
+                 double* vals_out, double* final_out_device, void* stream) {
+    HIPTS_REQUIRE(bm25 && ids_out && vals_out, "hipts_search: bad arguments");
+    HIPTS_REQUIRE(!bm25->slot[0].pending, "hipts_search: a submitted batch waits in slot 0 (hipts_search_collect it first)");
+    HIPTS_TRY(search_submit_impl(bm25, index, q_terms, q_weights, q_ptr, q_vectors, nq, w_bm25, w_sim, k, final_out_device, 0, (hipStream_t)stream));
+    return search_collect_impl(bm25, 0, ids_out, vals_out);
+}
+
+int hipts_search_submit(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr,
+                        const float* q_vectors, int nq, double w_bm25, double w_sim, int k, int slot, void* stream) {
+    return search_submit_impl(bm25, index, q_terms, q_weights, q_ptr, q_vectors, nq, w_bm25, w_sim, k, nullptr, slot, (hipStream_t)stream);
+}
+
+int hipts_search_collect(hipts_bm25_t* bm25, int slot, int32_t* ids_out, double* vals_out) {
+    return search_collect_impl(bm25, slot, ids_out, vals_out);
 }
 
 }  // extern "C"

@@ -63,6 +63,7 @@ struct hipts_vit {
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, q, k, v, att, hmid, pool_part, pooled2, logits, probs, stat_part;
+    DevBuf sk_ws;                                 // split-K workspaces of the residual GEMMs (GemmArgs::sk_ws), one per sub-batch stream, zeroed once
     bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default; HIPTS_LN_FOLD=0 turns it off)
     bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
     bool split_att = false;                       // cfg.operand_f16 bit 4: the attention output travels as a hi | lo pair, proj runs K = 2 dim against [W | W]
@@ -217,16 +218,27 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
     float4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = t0 + wave; t < t1; t += 4) {
-        const float4* xr = reinterpret_cast<const float4*>(x + ((int64_t)b * tokens + t) * D);
-        float4 v[4];
-        float s = 0.f;
+    // the next row's loads are in flight under this row's two wave reductions (round 4: the kernel was a chain of ~25 dependent
+    // load -> reduce -> reduce steps per wave, 58 us for 15 us of bytes; with 28 splits instead of 8 a wave owns 7 rows)
+    auto load_row = [&](int t, float4 (&v)[4]) {
+        const float4* xr = reinterpret_cast<const float4*>(x + ((int64_t)b * tokens + (t < t1 ? t : t1 - 1)) * D);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = lane + 64 * i;
             v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 vn[4];
+    if (t0 + wave < t1) load_row(t0 + wave, vn);
+    for (int t = t0 + wave; t < t1; t += 4) {
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = vn[i];
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
+        if (t + 4 < t1) load_row(t + 4, vn);
         float mean = 0.f, rstd = 1.f;
         if (normalize) {
             mean = wave_sum(s) / (float)D;
@@ -364,7 +376,8 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     }
     const size_t B = cfg->max_batch, M = B * h->tokens, D = cfg->dim;
     const size_t qkv_elems = B * cfg->heads * (size_t)h->tokens_pad * 64;
-    h->pool_splits = h->tokens >= 64 ? 8 : 1;
+    h->pool_splits = h->tokens >= 64 ? std::min(32, std::max(8, h->tokens / 28)) : 1;      // 784 tokens: 28 splits of 28 tokens, 7 per wave
+    if (getenv("HIPTS_POOL_SPLITS") && h->tokens >= 64) h->pool_splits = std::max(1, std::min(32, atoi(getenv("HIPTS_POOL_SPLITS"))));      // A/B
     int st = HIPTS_OK;
     if ((st = h->a0.alloc(M * h->patch_k * 2 * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
         (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->v.alloc(qkv_elems * 2)) ||
@@ -390,6 +403,13 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
                 delete h;
                 return st;
             }
+    }
+    {   // split-K tail of the residual GEMMs: tickets must start at zero (the kernels leave them so)
+        hipError_t e2;
+        if ((st = h->sk_ws.alloc(hipts_vit::kMaxSub * GEMM_SK_WS_BYTES)) || (e2 = hipMemset(h->sk_ws.p, 0, h->sk_ws.bytes)) != hipSuccess) {
+            delete h;
+            return st ? st : set_error(HIPTS_ERR_HIP, "hipMemset failed");
+        }
     }
     // padded token rows of q / k / v must be finite (zero): cleared once, never written afterwards
     hipError_t e;
@@ -603,7 +623,7 @@ int prof_resolve(hipts_vit* h) {
 // buffer is indexed by image (rows of M = batch * tokens, or (image, head) blocks), so disjoint image
 // ranges can run on different streams at the same time.
 int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb, float* lg, float* pr, hipStream_t s, bool shared_chip,
-                   int stagger_at = 0) {
+                   int stagger_at = 0, int sub = 0) {
     const auto& c = h->cfg;
     const int D = c.dim, P = c.patch, S = c.image_size, T = h->tokens, Tp = h->tokens_pad, H = c.heads;
     const int M = nb * T;
@@ -684,6 +704,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         r.f16 = f16;
         r.shared_chip = shared_chip;
         r.A = A; r.W = W; r.M = M; r.N = D; r.K = K; r.bias = bias; r.out_f32 = x;
+        r.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; r.sk_ws_bytes = GEMM_SK_WS_BYTES;      // this stream's split-K workspace
         if (next_gamma) {
             r.out_bf16 = xn; r.ln_gamma = next_gamma; r.stat_part = stat_p; r.stat_stride = M;
         }
@@ -763,6 +784,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     g.f16 = f16;
     g.shared_chip = shared_chip;
     g.A = pooled2; g.W = h->head_w.as<bf16_t>(); g.M = nb; g.N = c.num_classes; g.K = 2 * D;
+    g.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; g.sk_ws_bytes = GEMM_SK_WS_BYTES;      // split-K: 43 tiles on 256 CUs
     g.bias = h->head_b.as<float>(); g.out_f32 = lg ? lg + (size_t)i0 * c.num_classes : nullptr;
     g.out2_f32 = pr ? pr + (size_t)i0 * c.num_classes : nullptr;
     {
@@ -830,7 +852,7 @@ int vit_forward_impl(hipts_vit* h, const void* input, int in_memspace, bool is_u
             const int i0 = (int)((int64_t)batch * i / ns), i1 = (int)((int64_t)batch * (i + 1) / ns);
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
             if (i > 0 && stagger_at > 0) HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_stagger, 0));
-            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i], true, i == 0 ? stagger_at : 0));
+            HIPTS_TRY(vit_run_images(h, in_dev, is_u8, i0, i1 - i0, lg, pr, h->sub[i], true, i == 0 ? stagger_at : 0, i));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
             if (!h->deferred_join || !dev_out) HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
@@ -1074,6 +1096,12 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     hipEvent_t e0, e1;
     HIPTS_HIP(hipEventCreate(&e0));
     HIPTS_HIP(hipEventCreate(&e1));
+    DevBuf skws;
+    if (getenv("HIPTS_DBG_GEMM_SK")) {
+        HIPTS_TRY(skws.alloc(GEMM_SK_WS_BYTES));
+        HIPTS_HIP(hipMemset(skws.p, 0, skws.bytes));
+        g.sk_ws = skws.p; g.sk_ws_bytes = GEMM_SK_WS_BYTES; g.shared_chip = 1;
+    }
     for (int i = 0; i < 3; ++i) HIPTS_TRY(launch_gemm((GemmEpilogue)epi, g, nullptr));
     HIPTS_HIP(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; ++i) HIPTS_TRY(launch_gemm((GemmEpilogue)epi, g, nullptr));
@@ -1142,7 +1170,19 @@ extern "C" int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, co
     GemmArgs g{};
     g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>(); g.out_f32 = out.as<float>();
     g.f16 = getenv("HIPTS_DBG_GEMM_F16") ? 1 : 0;       // the 16-bit patterns are IEEE half (tests/test_gpu_gemm.py: the 192-row tiles exist for half operands only)
+    DevBuf skws;
+    if (getenv("HIPTS_DBG_GEMM_SK")) {                  // the split-K tail as the forwards use it: a zeroed workspace, 256-row tiles (sub-batch streams)
+        HIPTS_TRY(skws.alloc(GEMM_SK_WS_BYTES));
+        HIPTS_HIP(hipMemset(skws.p, 0, skws.bytes));
+        g.sk_ws = skws.p; g.sk_ws_bytes = GEMM_SK_WS_BYTES; g.shared_chip = 1;
+    }
     HIPTS_TRY(launch_gemm(EPI_RESID, g, nullptr));
+    if (skws.p) HIPTS_TRY(launch_gemm(EPI_RESID, g, nullptr));      // a second launch on the same workspace: the tickets must be back at zero
+    if (skws.p) {                                                     // ... and are
+        std::vector<unsigned> tk(1024);
+        HIPTS_HIP(hipMemcpy(tk.data(), skws.p, 4096, hipMemcpyDeviceToHost));
+        for (unsigned v : tk) HIPTS_REQUIRE(v == 0, "hiptsdbg_gemm_run: a split-K ticket was left at %u", v);
+    }
     HIPTS_HIP(hipMemcpy(out_host, out.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return HIPTS_OK;
 }

@@ -258,6 +258,13 @@ struct GemmArgs {
     int op8 = 0;                    // A and W are e4m3 bytes (K counts elements, K % 128 == 0; W holds W * 2^w_exp); 16-bit outputs are half
     int w_exp = 0;                  // op8: the weight scale exponent
     int out8 = 0;                   // STAR / RESID_LN: the 16-bit output (out_bf16) is written as e4m3 bytes instead (ld_out in bytes)
+    // Split-K tail (round 4; persistent loop, residual epilogues only): the last tiles of the launch order -- the partial last round, or all
+    // tiles of a launch smaller than the chip -- are cut into sk_slices K ranges, each a work item of its own.  A slice leaves its fp32
+    // accumulators in a slab of the workspace (write-through stores) and draws a ticket; the LAST arriver adds the slabs in slice order
+    // (the bits do not depend on who arrives last) and runs the epilogue.  Nobody waits for anybody: no residency assumption.
+    void* sk_ws = nullptr;                  // caller-owned, zeroed once, one per stream: [4 KB of tickets][slabs]; null = never split
+    size_t sk_ws_bytes = 0;
+    int sk_first = 0, sk_slices = 1;        // set by the launcher: tiles [sk_first, tiles) are split sk_slices ways
     int raster_gn = 0;                      // > 0: column groups of this many column tiles outermost, row-major inside (set by the launcher)
     int raster_gm = 0;                      // > 0: tile order in groups of this many row panels, column-major inside (set by the launcher)
     int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
@@ -266,6 +273,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+constexpr size_t GEMM_SK_WS_BYTES = 4096 + 256 * (size_t)(256 * 256 * 4);      // tickets + one 256 x 256 fp32 slab per work item of a full round
 
 // softmax(Q K^T) V for every (image, head): q,k [B*H][tokens_pad][64] bf16 (q pre-scaled by
 // head_dim^-0.5), vT [B*H][64][tokens_pad] bf16, out [B*tokens][H*64] bf16.

@@ -104,6 +104,8 @@ _SIGNATURES = {
     "hipts_topk_after": [c_void_p, c_int64, c_int, c_double, c_int64, c_void_p, c_void_p, c_int, c_void_p],
     "hipts_search": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                      c_void_p, c_void_p, c_void_p, c_void_p],
+    "hipts_search_submit": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_int, c_void_p],
+    "hipts_search_collect": [c_void_p, c_int, c_void_p, c_void_p],
     "hipts_query_profile_enable": [c_void_p, c_int],
     "hipts_query_profile_read": [c_void_p, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double)],
     "hipts_query_profile_name": [c_int, c_char_p, c_size_t],

@@ -148,6 +148,32 @@ class SearchEngine:
                   _lib.ptr(final_out) if final_out is not None else None, _lib.current_stream_ptr())
         return ids, vals
 
+    def submit_topk(self, query_weights: Sequence[Dict[int, float]], query_vectors: np.ndarray, k: int, slot: int = 0):
+        """First half of score_topk for a host that serves a stream of batches: packs and launches the batch into `slot` (0 or 1) and returns
+        a ticket without waiting; `collect_topk(ticket)` returns what score_topk would have.  With the two slots used alternately the host
+        prepares batch i + 1 while the device runs batch i (hipts_search_submit / hipts_search_collect)."""
+        nq = len(query_weights)
+        qp = np.zeros(nq + 1, dtype=np.int32)
+        np.cumsum(np.fromiter(map(len, query_weights), dtype=np.int32, count=nq), out=qp[1:])
+        nt = int(qp[nq])
+        if nt:
+            qt_a = np.fromiter(itertools.chain.from_iterable(query_weights), dtype=np.int32, count=nt)
+            qw_a = np.fromiter(itertools.chain.from_iterable(map(dict.values, query_weights)), dtype=np.float64, count=nt)
+        else:
+            qt_a = np.zeros(1, dtype=np.int32)
+            qw_a = np.zeros(1, dtype=np.float64)
+        qv = np.ascontiguousarray(np.atleast_2d(query_vectors), dtype=np.float32)
+        _lib.call("hipts_search_submit", self.bm25._h, self.index._h, _lib.ptr(qt_a), _lib.ptr(qw_a), _lib.ptr(qp), _lib.ptr(qv), nq,
+                  c_double(BM25_WEIGHT), c_double(DOC2VEC_WEIGHT), k, slot, _lib.current_stream_ptr())
+        return (slot, nq, k)
+
+    def collect_topk(self, ticket) -> Tuple[np.ndarray, np.ndarray]:
+        slot, nq, k = ticket
+        ids = np.empty((nq, k), dtype=np.int32)
+        vals = np.empty((nq, k), dtype=np.float64)
+        _lib.call("hipts_search_collect", self.bm25._h, slot, _lib.ptr(ids), _lib.ptr(vals))
+        return ids, vals
+
     # ---- webui.py:345-390 -----------------------------------------------------------------------
     def find_similar_documents(self, new_doc: str, topn: int = 50) -> List[Tuple[int, float]]:
         import torch

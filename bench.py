@@ -120,7 +120,21 @@ def query_section(device):
     for s in range(0, NQ, chunk):
         ids, vals = eng.score_topk(qs[s:s + chunk], qv[s:s + chunk], TOPK)
     torch.cuda.synchronize()
-    batched = NQ / (time.perf_counter() - t0)
+    batched_sync = NQ / (time.perf_counter() - t0)            # one batch at a time: the host's packing / launching / unpacking is not hidden
+    # The serving loop (round 4): two batches in flight -- the host prepares and launches batch i + 1 while the device runs batch i
+    # (SearchEngine.submit_topk / collect_topk = hipts_search_submit / _collect); same kernels, same results (asserted below).
+    reps = 4
+    starts = [s for _ in range(reps) for s in range(0, NQ, chunk)]
+    t0 = time.perf_counter()
+    pending = eng.submit_topk(qs[starts[0]:starts[0] + chunk], qv[starts[0]:starts[0] + chunk], TOPK, slot=0)
+    for j in range(1, len(starts)):
+        s = starts[j]
+        nxt = eng.submit_topk(qs[s:s + chunk], qv[s:s + chunk], TOPK, slot=j & 1)
+        pids, pvals = eng.collect_topk(pending)
+        pending = nxt
+    pids, pvals = eng.collect_topk(pending)
+    batched = len(starts) * chunk / (time.perf_counter() - t0)
+    assert np.array_equal(pids, ids) and pvals.tobytes() == vals.tobytes(), "pipelined batches differ from the synchronous call"
     for i in range(8):
         eng.score_topk(qs[i:i + 1], qv[i:i + 1], TOPK)                # warm-up of the one-query path (first launch loads its kernels)
     n_single = 256
@@ -262,7 +276,10 @@ def query_section(device):
     bytes_single = D * K * 4 + bm.nnz * 8 + D * (8 + 4 + 8 + 4) + D * 20 + D * 8
     bytes_batched = D * K * 4 / 32.0 + D * (8 * 3 + 4 + 4 + 20 + 8)
     return {"metric": "top-100 queries/sec over 100k-doc index (BM25 + 300-d index product, fused)",
-            "batched_qps": batched, "single_query_qps": single, "single_query_c_abi_qps": single_c_abi, "batch": chunk,
+            "batched_qps": batched, "batched_one_at_a_time_qps": batched_sync,
+            "batched_note": "batched_qps: two batches of 256 in flight (submit / collect: the host prepares batch i + 1 while the device runs batch i); "
+                            "batched_one_at_a_time_qps: every call waits for its own result (rounds 1-3's figure)",
+            "single_query_qps": single, "single_query_c_abi_qps": single_c_abi, "batch": chunk,
             "roofline": roof,
             "algorithmic_bytes_per_query": {"single": bytes_single, "batched": bytes_batched,
                                             "note": "batched: one 120 MB index pass per 32 queries + per-query score rows (posting lists counted per launch in roofline)"},
@@ -594,7 +611,12 @@ def main():
         torch.cuda.synchronize()
         same_rows = bool(torch.equal(ref_rows, last_rows))
         same_probs = bool(torch.equal(ref_probs, probs2[(counter[0] - 1) & 1]))
-        assert same_rows and same_probs, "timed-region outputs differ from a fresh single-stream forward"
+        # (HIPTS_GEMM_SPLITK >= 2, an opt-in A/B mode, gives up exactly this property: which tiles are summed as partial chains depends on
+        # the launch's size, so the two-stream and the one-stream forward differ in low bits.  Rows still have to agree.)
+        if int(os.environ.get("HIPTS_GEMM_SPLITK", "0")) >= 2:
+            assert same_rows, "timed-region tag rows differ from a fresh single-stream forward"
+        else:
+            assert same_rows and same_probs, "timed-region outputs differ from a fresh single-stream forward"
         check = {"rows_equal_single_stream_forward": same_rows, "probs_bit_equal": same_probs,
                  "tags_selected_per_image_mean": float((last_rows[:, 0] + last_rows[:, 1]).float().mean().item())}
         if world > 1:

@@ -373,6 +373,14 @@ int hipts_search(hipts_bm25_t* bm25, hipts_index_t* index,
                  const int32_t* q_terms, const double* q_weights, const int32_t* q_ptr,
                  const float* q_vectors, int nq, double w_bm25, double w_sim, int k,
                  int32_t* ids_out, double* vals_out, double* final_out_device, void* stream);
+/* The same call in two halves, for a host that serves a stream of query batches (the reference's webui.py:586 loop is one query at a
+ * time; a batch is what a server front end accumulates): submit packs and launches a batch into slot 0 or 1 and returns without
+ * waiting; collect waits for that slot's batch and unpacks it.  With two slots the host prepares batch i + 1 while the device runs
+ * batch i -- same kernels, same results (hipts_search is submit + collect on slot 0).  All batches of a handle must use ONE stream. */
+int hipts_search_submit(hipts_bm25_t* bm25, hipts_index_t* index, const int32_t* q_terms, const double* q_weights,
+                        const int32_t* q_ptr, const float* q_vectors, int nq, double w_bm25, double w_sim, int k,
+                        int slot, void* stream);
+int hipts_search_collect(hipts_bm25_t* bm25, int slot, int32_t* ids_out, double* vals_out);
 
 /* Per-kernel timing of the query path for roofline accounting (bench.py), as hipts_vit_profile_* above: while enabled, every
  * kernel hipts_search launches is bracketed by HIP events on the stream it is launched on.  read() resolves them (synchronises) and

@@ -82,6 +82,35 @@ def test_gemm_half_operands_and_tile_heights():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("half", [0, 1])
+def test_gemm_split_k_tail(half):
+    """The split-K tail of the residual GEMMs (GemmArgs::sk_*): work items past the last full round are (tile, K slice) pairs, slices leave
+    their accumulators in slabs, the last arriver adds them in slice order and runs the epilogue.  Against float64, twice (bit-equal: the
+    sum does not depend on who arrives last), two launches per run on one workspace (the tickets return to zero):
+    (5125, 1024, 1024) = EVA02-L's proj per sub-batch of 5 images, 84 tiles x 3 slices; (5125, 1024, 2752) its fc2; (25088, 768, 3072) =
+    the ViT's fc2 per 32 images, 256 whole tiles + 38 x 4 slices; (777, 768, 3072) ragged rows, 12 tiles x 4; (300, 272, 128) too short
+    to split (one launch path must survive the workspace being there)."""
+    env = {k: v for k, v in os.environ.items() if k != "HIPTS_GEMM"}
+    env["HIPTS_DBG_GEMM_SK"] = "1"
+    env["HIPTS_GEMM_SPLITK"] = "4"              # opt-in: the split is off by default (it gives up batch invariance, gemm.hip launcher)
+    shapes = [(5125, 1024, 1024), (5125, 1024, 2752), (25088, 768, 3072), (777, 768, 3072), (300, 272, 128), (25088, 768, 768)]
+    code = _CHILD % {"pkg": os.path.join(ROOT, "anime-illust-image-searcher_amd"), "shapes": shapes}
+    # the runner launches twice into the same zero-initialised output: out = 2 A W^T
+    code = code.replace("want = a.astype(np.float64) @ w.astype(np.float64).T", "want = 2.0 * (a.astype(np.float64) @ w.astype(np.float64).T)")
+    code = code.replace("tol = 2e-6 * K ** 0.5 * 4 + 1e-6", "tol = 2 * (2e-6 * K ** 0.5 * 4 + 1e-6)")
+    if half:
+        env["HIPTS_DBG_GEMM_F16"] = "1"
+        code = code.replace("a = synth.round_to_bf16(rng.standard_normal((M, K)).astype(np.float32))",
+                            "a = rng.standard_normal((M, K)).astype(np.float16).astype(np.float32)")
+        code = code.replace("w = synth.round_to_bf16((rng.standard_normal((N, K)) * 0.05).astype(np.float32))",
+                            "w = (rng.standard_normal((N, K)) * 0.05).astype(np.float16).astype(np.float32)")
+        code = code.replace("a16 = (a.view(np.uint32) >> 16).astype(np.uint16); w16 = (w.view(np.uint32) >> 16).astype(np.uint16)",
+                            "a16 = a.astype(np.float16).view(np.uint16); w16 = w.astype(np.float16).view(np.uint16)")
+        assert "round_to_bf16" not in code
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_forward_is_deterministic_and_batch_invariant():
     from hiptagsearch import synth
     from hiptagsearch.tagger import ViTTagger

@@ -521,3 +521,41 @@ def test_sharded_query_two_processes_gloo():
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     assert "identical to the unsharded engine" in outs[0]
+
+
+def test_submit_collect_pipeline_matches_the_synchronous_call(corpus20k):
+    """hipts_search_submit / hipts_search_collect: two batches in flight on the two slots give, batch for batch, the bytes of hipts_search --
+    batches of different sizes (the last is ragged), a one-query batch in the middle (it takes the one-query path inside submit), and the
+    misuse cases are refused: a slot submitted twice, a slot collected without a submit."""
+    import hiptagsearch
+    from hiptagsearch import synth
+    from hiptagsearch.bm25 import BM25Index
+    from hiptagsearch.index import Similarity
+    from hiptagsearch.search import SearchEngine
+    ptr, terms, V = corpus20k
+    D, K, TOPK = len(ptr) - 1, 128, 50
+    bm = BM25Index(ptr, terms, V)
+    idx = Similarity("pipe", None, K, capacity=D)
+    idx.add_matrix(synth.index_vectors(D, K, seed=46))
+    eng = SearchEngine(None, idx, {}, bm, [])
+    qs = [dict(q) for q in synth.queries(300, V, seed=77)]
+    qv = np.random.default_rng(6).standard_normal((300, K))
+    qv = (qv / np.linalg.norm(qv, axis=1, keepdims=True)).astype(np.float32)
+    cuts = [0, 96, 97, 224, 300]                                     # batches of 96, 1, 127, 76 queries
+    want = [eng.score_topk(qs[a:b], qv[a:b], TOPK) for a, b in zip(cuts[:-1], cuts[1:])]
+    got = []
+    pending = eng.submit_topk(qs[cuts[0]:cuts[1]], qv[cuts[0]:cuts[1]], TOPK, slot=0)
+    for j in range(1, len(cuts) - 1):
+        nxt = eng.submit_topk(qs[cuts[j]:cuts[j + 1]], qv[cuts[j]:cuts[j + 1]], TOPK, slot=j & 1)
+        got.append(eng.collect_topk(pending))
+        pending = nxt
+    got.append(eng.collect_topk(pending))
+    for (gi, gv), (wi, wv) in zip(got, want):
+        np.testing.assert_array_equal(gi, wi)
+        assert gv.tobytes() == wv.tobytes()
+    t = eng.submit_topk(qs[:4], qv[:4], TOPK, slot=1)
+    with pytest.raises(hiptagsearch.HipTagSearchError):
+        eng.submit_topk(qs[:4], qv[:4], TOPK, slot=1)                # the slot is taken
+    eng.collect_topk(t)
+    with pytest.raises(hiptagsearch.HipTagSearchError):
+        eng.collect_topk(t)                                           # nothing submitted any more

@@ -14,7 +14,7 @@ for B in (10, 32):
     probs = torch.empty((B, cfg["num_classes"]), dtype=torch.float32, device="cuda")
     for _ in range(2): m.forward_u8(imgs, probs=probs, want="probs")
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 4
+    n = 12
     for _ in range(n): m.forward_u8(imgs, probs=probs, want="probs")
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     fl = m.flops_per_image()
