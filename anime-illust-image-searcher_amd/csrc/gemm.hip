@@ -2021,7 +2021,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
                         mr = c;
                     }
             }
-            if (EPI == EPI_HEAD && a.sk_ws) mr = 8;       // the split-K instantiation is built for 256-row tiles; the head is bound by its weight bytes
+            if (EPI == EPI_HEAD && a.sk_ws && getenv("HIPTS_GEMM_SPLITK_HEAD") && atoi(getenv("HIPTS_GEMM_SPLITK_HEAD")) >= 2) mr = 8;       // the split-K instantiation is built for 256-row tiles
             const int tiles_mr = tiles_of(mr);
             // persistent grid: one workgroup per CU (a multiple of 8 so that a workgroup's tiles keep their XCD)
             static const bool persist = !(getenv("HIPTS_GEMM_PERSIST") && strcmp(getenv("HIPTS_GEMM_PERSIST"), "0") == 0);
@@ -2033,20 +2033,20 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             GemmArgs ar = a;
             ar.raster_gm = (raster > 0 && tiles_n >= 8) ? raster : 0;
             ar.raster_gn = (raster_gn > 0 && tiles_n >= 8 && tiles_n > raster_gn) ? raster_gn : 0;
-            // Split-K tail (GemmArgs::sk_*): the residual GEMMs with a long K whose last round fills less than half of the chip -- EVA02-L's
-            // proj / fc2 at the reference's batch of 10 (84 tiles per sub-batch on 256 CUs), the ViT's fc2 per 32-image sub-batch (294 tiles:
-            // 38 in the second round).  S <= HIPTS_GEMM_SPLITK, at least HIPTS_GEMM_SPLITK_MINKT K-tiles per slice (default 5: a slice's slab
-            // costs its writer ~3 us and the last arriver ~3 us per slab, a K-tile ~1.5 us).
-            // OFF unless HIPTS_GEMM_SPLITK >= 2: a tile summed as S partial chains has other low bits than the same tile summed as one chain,
-            // and WHICH tiles are split depends on the launch's size -- an image's logits would depend on the batch it travels in
-            // (tests/test_gpu_vit.py::test_folded_layernorm_path..., test_gpu_gemm.py::test_forward_is_deterministic_and_batch_invariant) and
-            // the sharded CLIs' byte-equal output files on the shard sizes.  Run to run the split IS deterministic (slabs added in slice order).
-            // The tag head (EPI_HEAD) is split by default: its launch is ONE row panel (batch <= 256) of 43 column tiles whatever the batch, so
-            // every image's logits are summed as the same four partial chains in every batch -- 43 workgroups pulling 33 MB of weights took
-            // 51 us per sub-batch forward.  HIPTS_GEMM_SPLITK_HEAD=0 turns it off.
+            // Split-K tail (GemmArgs::sk_*), an EXPERIMENT that lost (round 4) and stays off: the residual GEMMs with a long K whose last round
+            // fills less than half of the chip -- EVA02-L's proj / fc2 at the reference's batch of 10 (84 tiles per sub-batch on 256 CUs), the
+            // ViT's fc2 per 32-image sub-batch (294 tiles: 38 in the second round) -- with S <= HIPTS_GEMM_SPLITK slices of at least
+            // HIPTS_GEMM_SPLITK_MINKT K-tiles.  Measured (tools/gpurun/r4_splitk.sh, one box): ViT-B/16 5093-5103 -> 4894-4898 images/s
+            // (S = 4; S = 2: 4982), EVA02-L batch 10 1044 -> 829-832 images/s (S = 3), batch 32 unchanged.  A 256 x 256 fp32 slab is 256 KB:
+            // 84 tiles x 3 slices write 64 MB through to memory and their last arrivers read it back, ~50 us per launch, more than the
+            // under-filled main loop costs (cdna_hip_programming.md says as much: combine in-launch only when the slabs of a tile are tens of
+            // KB).  It also gives up batch invariance -- a tile summed as S partial chains has other low bits than the same tile summed as one
+            // chain, and WHICH tiles are split depends on the launch's size (tests/test_gpu_vit.py::test_folded_layernorm_path..., the sharded
+            // CLIs' byte-equal output files) -- though run to run it is deterministic (slabs are added in slice order).  The tag head's launch
+            // (EPI_HEAD: one row panel of 43 column tiles whatever the batch) would keep the invariance; HIPTS_GEMM_SPLITK_HEAD=4 enables it.
             if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_RESID_ROWSTAT || EPI == EPI_HEAD) {
                 static const int sk_env = getenv("HIPTS_GEMM_SPLITK") ? atoi(getenv("HIPTS_GEMM_SPLITK")) : 0;
-                static const int sk_head = getenv("HIPTS_GEMM_SPLITK_HEAD") ? atoi(getenv("HIPTS_GEMM_SPLITK_HEAD")) : 4;
+                static const int sk_head = getenv("HIPTS_GEMM_SPLITK_HEAD") ? atoi(getenv("HIPTS_GEMM_SPLITK_HEAD")) : 0;
                 const int sk_max = EPI == EPI_HEAD ? (tiles_mr == 1 ? sk_head : 0) : sk_env;
                 static const int sk_minkt = getenv("HIPTS_GEMM_SPLITK_MINKT") ? atoi(getenv("HIPTS_GEMM_SPLITK_MINKT")) : 5;
                 const int nkt = a.K / BK;
