@@ -39,7 +39,6 @@ struct Block {
     bool has_rs1 = false, has_rs2 = false;
     float s1 = 1.f, b1 = 0.f;      // token-mixer StarReLU
     float s2 = 1.f, b2 = 0.f;      // MLP StarReLU
-    int e_out = 0, e_fc1 = 0, e_fc2 = 0;   // e4m3 mode: the weights are stored as W * 2^e
 };
 
 struct Stage {
@@ -232,7 +231,7 @@ constexpr int DW_PH = DW_TH + 6, DW_PW = DW_TW + 6, DW_PITCH = 160;
 constexpr int DW_IN_BYTES = DW_PH * DW_PW * DW_PITCH;          // 49,280 B
 constexpr int DW_LDS_BYTES = DW_IN_BYTES + 49 * DW_CS * 4;     // + 12,544 B of weights
 
-template <bool F16, bool OUT8 = false>
+template <bool F16>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w,
                                                       bf16_t* __restrict__ out, int H, int C, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -302,11 +301,6 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const bf16_t* __restrict__
         for (int o = 0; o < 4; ++o) {
             const int ox = x0t + xo + o;
             if (ox >= H) continue;
-            if constexpr (OUT8) {       // e4m3 bytes: the A operand of an e4m3 pwconv2
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out) + ((img0 + (int64_t)oy * H + ox) * C + c0 + g * 8)) =
-                    make_uint2(pack4_e4m3(acc[o][0], acc[o][1], acc[o][2], acc[o][3]), pack4_e4m3(acc[o][4], acc[o][5], acc[o][6], acc[o][7]));
-                continue;
-            }
             bf16x8 ov;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = to_op<F16>(acc[o][e]);
@@ -418,17 +412,17 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     GemmArgs g;
     bool xn_ready = false;          // xn already holds the LayerNorm the next consumer needs
     // x = rs * x + A W^T, optionally followed in the same epilogue by xn = LN(x) * gamma
-    const bool mode8 = c.operand_f16 == 2;      // e4m3 operands for the pointwise / MLP / qkv GEMMs (configs[4]); 16-bit tensors are half
-    auto layernorm_xn = [&](const float* gamma, int64_t rows, int D, bool to8) -> int {
-        return to8 ? launch_layernorm8(x, gamma, nullptr, reinterpret_cast<uint8_t*>(xn), rows, D, c.ln_eps, s)
-                   : launch_layernorm(x, gamma, nullptr, xn, rows, D, c.ln_eps, f16, s);
+    // (The e4m3 operand mode of rounds 1-3 -- operand_f16 = 2, BASELINE.json configs[4]'s "fp8 MFMA" -- was withdrawn in round 4:
+    // hipts_ccip_create refuses it.  DESIGN.md section 6 has the numbers: cosine 0.968 against the float32 oracle, 1 % slower than half
+    // operands, and no scaling scheme the MFMA offers lifts e4m3's three mantissa bits above 0.995 through 36 blocks.)
+    auto layernorm_xn = [&](const float* gamma, int64_t rows, int D) -> int {
+        return launch_layernorm(x, gamma, nullptr, xn, rows, D, c.ln_eps, f16, s);
     };
-    auto residual = [&](GemmArgs& ga, const float* rs, const float* gamma, bool ln8) -> int {
+    auto residual = [&](GemmArgs& ga, const float* rs, const float* gamma) -> int {
         ga.res_scale = rs;
         if (gamma) {
             ga.ln_gamma = gamma;
             ga.ln_eps = c.ln_eps;
-            ga.out8 = ln8 ? 1 : 0;
             ga.out_bf16 = xn;
             return launch_gemm(EPI_RESID_LN, ga, s);
         }
@@ -467,7 +461,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         if (si > 0) {
             // downsample: LN(x) -> 3x3 s2 p1 conv (+bias) -> x
             const Stage& Pv = h->st[si - 1];
-            if (!xn_ready) HIPTS_TRY(layernorm_xn(St.ds_norm.as<float>(), (int64_t)batch * Pv.T, Pv.C, false));
+            if (!xn_ready) HIPTS_TRY(layernorm_xn(St.ds_norm.as<float>(), (int64_t)batch * Pv.T, Pv.C));
             xn_ready = false;
             const int64_t chunks = (int64_t)M * 9 * (Pv.C / 8);
             ds_im2col_kernel<<<ceil_div(chunks, 256), 256, 0, s>>>(xn, col, batch, Pv.H, Pv.C);
@@ -491,14 +485,9 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         // that produces the row (EPI_RESID_LN): the separate pass over the fp32 stream is the largest HBM
         // consumer of the wide early stages.
         const bool fuse_ln = C <= 256 && !getenv("HIPTS_CCIP_NO_LN_FUSION");
-        // e4m3 stage: pwconv2, fc1 and fc2 take e4m3 operands -- norm2's output, the dwconv output and the MLP hidden
-        // tensor are e4m3 bytes (K = C, 2C, 4C multiples of 128).  pwconv1 and qkv stay 16-bit: their outputs are 16-bit
-        // and their launches are bound by those stores, so e4m3 operands bought nothing there (measured, gemm_bench:
-        // 36864 x 2048 x 512 97.5 us either way) and only added rounding error.
-        const bool q8 = mode8 && C % 128 == 0;
         for (size_t bi = 0; bi < St.blocks.size(); ++bi) {
             Block& B = St.blocks[bi];
-            if (!xn_ready) HIPTS_TRY(layernorm_xn(B.n1.as<float>(), M, C, false));
+            if (!xn_ready) HIPTS_TRY(layernorm_xn(B.n1.as<float>(), M, C));
             xn_ready = false;
             // LayerNorm that follows this block's MLP: the next block's norm1, or the next stage's downsample norm
             const float* next_gamma = bi + 1 < St.blocks.size() ? St.blocks[bi + 1].n1.as<float>()
@@ -513,16 +502,14 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 HIPTS_TRY(gemm(EPI_STAR, g, s));
                 const int tiles_x = ceil_div(H, DW_TW), tiles_y = ceil_div(H, DW_TH);
                 const int dw_grid = batch * tiles_y * tiles_x * (2 * C / DW_CS);
-                if (q8) dwconv7_kernel<true, true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
-                else if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
+                if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
                 else dwconv7_kernel<false><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
                 HIPTS_LAUNCH_CHECK();
                 g = GemmArgs{};
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
                 g.A = h2; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = 2 * C; g.bias = zeros; g.out_f32 = x;
-                g.op8 = q8; g.w_exp = B.e_out;
-                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr, q8));
+                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr));
             } else {
                 const int heads = C / c.head_dim;
                 g = GemmArgs{};
@@ -546,24 +533,22 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
                 g.A = h1; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = C; g.bias = zeros; g.out_f32 = x;
-                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr, q8));
+                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr));
             }
             // MLP: fc1 + StarReLU, fc2 + residual
-            if (!fuse_ln) HIPTS_TRY(layernorm_xn(B.n2.as<float>(), M, C, q8));
+            if (!fuse_ln) HIPTS_TRY(layernorm_xn(B.n2.as<float>(), M, C));
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
             g.A = xn; g.W = B.fc1.as<bf16_t>(); g.M = M; g.N = 4 * C; g.K = C; g.bias = zeros;
-            g.op8 = q8; g.w_exp = B.e_fc1; g.out8 = q8;
             g.out_bf16 = m1; g.star_scale = B.s2; g.star_bias = B.b2;
             HIPTS_TRY(gemm(EPI_STAR, g, s));
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
             g.A = m1; g.W = B.fc2.as<bf16_t>(); g.M = M; g.N = C; g.K = 4 * C; g.bias = zeros; g.out_f32 = x;
-            g.op8 = q8; g.w_exp = B.e_fc2;
             const bool fuse_next = fuse_ln && next_gamma != nullptr;
-            HIPTS_TRY(residual(g, B.has_rs2 ? B.rs2.as<float>() : nullptr, fuse_next ? next_gamma : nullptr, false));
+            HIPTS_TRY(residual(g, B.has_rs2 ? B.rs2.as<float>() : nullptr, fuse_next ? next_gamma : nullptr));
             xn_ready = fuse_next;
         }
     }
@@ -634,6 +619,9 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
     HIPTS_REQUIRE(cfg->image_size >= 32 && cfg->image_size % 32 == 0, "image_size %d must be a multiple of 32", cfg->image_size);
     HIPTS_REQUIRE(cfg->head_dim == 32, "head_dim %d: only 32 is built", cfg->head_dim);
     HIPTS_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
+    HIPTS_REQUIRE(cfg->operand_f16 == 0 || cfg->operand_f16 == 1,
+                  "operand_f16 = %d: 0 (bf16) or 1 (IEEE half); the e4m3 mode (2) was withdrawn in round 4 -- cosine 0.968 against the float32 "
+                  "forward and no faster than half operands (DESIGN.md section 6)", cfg->operand_f16);
     HIPTS_REQUIRE(cfg->attn_from_stage >= 0 && cfg->attn_from_stage <= 4, "attn_from_stage must be 0 .. 4");
     for (int s = 0; s < 4; ++s) {
         HIPTS_REQUIRE(cfg->dims[s] >= 64 && cfg->dims[s] % 64 == 0 && cfg->dims[s] <= 1024, "dims[%d] = %d must be a multiple of 64, at most 1024",
@@ -704,7 +692,6 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dwconv7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dwconv7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dwconv7_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
     if (e != hipSuccess) {
         delete h;
         return set_error(HIPTS_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -798,20 +785,17 @@ int hipts_ccip_set_tensor(hipts_ccip_t* h, const char* key_c, const float* data,
             if (bi < 0 || bi >= (int)St.blocks.size()) return set_error(HIPTS_ERR_INVALID, "tensor %s: block out of range", key_c);
             Block& B = St.blocks[bi];
             const std::string t = sub.substr(d2 + 1);
-            const bool q8 = h->cfg.operand_f16 == 2 && C % 128 == 0;
-            auto up = [&](DevBuf& buf, int rows, int cols, int rows_pad, int* e) -> int {
-                return q8 ? upload_matrix8(buf, data, rows, cols, rows_pad, e) : upload_matrix16(buf, data, rows, cols, rows_pad, f16);
-            };
+            auto up = [&](DevBuf& buf, int rows, int cols, int rows_pad) -> int { return upload_matrix16(buf, data, rows, cols, rows_pad, f16); };
             if (t == "norm1.weight") { EXPECT(C); st = upload_f32(B.n1, data, C); }
             else if (t == "norm2.weight") { EXPECT(C); st = upload_f32(B.n2, data, C); }
             else if (t == "res_scale1.scale") { EXPECT(C); st = upload_f32(B.rs1, data, C); B.has_rs1 = true; }
             else if (t == "res_scale2.scale") { EXPECT(C); st = upload_f32(B.rs2, data, C); B.has_rs2 = true; }
-            else if (t == "mlp.fc1.weight") { EXPECT((int64_t)4 * C * C); st = up(B.fc1, 4 * C, C, round_up(4 * C, 256), &B.e_fc1); }
-            else if (t == "mlp.fc2.weight") { EXPECT((int64_t)4 * C * C); st = up(B.fc2, C, 4 * C, round_up(C, 256), &B.e_fc2); }
+            else if (t == "mlp.fc1.weight") { EXPECT((int64_t)4 * C * C); st = up(B.fc1, 4 * C, C, round_up(4 * C, 256)); }
+            else if (t == "mlp.fc2.weight") { EXPECT((int64_t)4 * C * C); st = up(B.fc2, C, 4 * C, round_up(C, 256)); }
             else if (t == "mlp.act.scale") { EXPECT(1); B.s2 = data[0]; }
             else if (t == "mlp.act.bias") { EXPECT(1); B.b2 = data[0]; }
             else if (!B.attn && t == "token_mixer.pwconv1.weight") { EXPECT((int64_t)2 * C * C); st = upload_matrix16(B.w_in, data, 2 * C, C, round_up(2 * C, 256), f16); }
-            else if (!B.attn && t == "token_mixer.pwconv2.weight") { EXPECT((int64_t)2 * C * C); st = up(B.w_out, C, 2 * C, round_up(C, 256), &B.e_out); }
+            else if (!B.attn && t == "token_mixer.pwconv2.weight") { EXPECT((int64_t)2 * C * C); st = up(B.w_out, C, 2 * C, round_up(C, 256)); }
             else if (!B.attn && t == "token_mixer.act1.scale") { EXPECT(1); B.s1 = data[0]; }
             else if (!B.attn && t == "token_mixer.act1.bias") { EXPECT(1); B.b1 = data[0]; }
             else if (!B.attn && t == "token_mixer.dwconv.weight") {

@@ -69,9 +69,8 @@ def main(arg_str: list) -> None:
     parser.add_argument('--device', type=int, default=0)
     parser.add_argument('--workers', type=int, default=0,
                         help='decode / resize in this many processes (hiptagsearch/pipeline.py); the uint8 images go to the device u8 entry point')
-    parser.add_argument('--operands', choices=['bf16', 'half', 'e4m3'], default='half',
-                        help='MFMA operand type of the encoder GEMMs (half: same matrix rate as bf16, 8x smaller activation rounding; '
-                             'e4m3 = the fp8 mode: 3 mantissa bits)')
+    parser.add_argument('--operands', choices=['bf16', 'half'], default='half',
+                        help='MFMA operand type of the encoder GEMMs (half: same matrix rate as bf16, 8x smaller activation rounding)')
     parser.add_argument('--gpu-resize', action='store_true',
                         help='decode threads only decode; the bilinear resize of gen_cfeatures.py:101 runs on the device (Pillow-exact kernel)')
     parser.add_argument('--arch', choices=['b36', 'tiny'], default='b36', help='b36: CAFormer-B36 widths @384 (the CCIP encoder); tiny: test geometry')
@@ -92,7 +91,7 @@ def main(arg_str: list) -> None:
     from hiptagsearch import cfeatures as cf
     from hiptagsearch.index import Similarity
     base = synth.CCIP_TINY if args.arch == 'tiny' else synth.CCIP_B36_384
-    cfg = dict(base, operand_f16={'bf16': 0, 'half': 1, 'e4m3': 2}[args.operands])
+    cfg = dict(base, operand_f16={'bf16': 0, 'half': 1}[args.operands])
     if args.checkpoint:
         encoder = cf.CCIPEncoder.from_safetensors(args.checkpoint, cfg, max_batch=args.batch, device=device)
     else:

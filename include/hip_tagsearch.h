@@ -184,11 +184,11 @@ typedef struct hipts_ccip_config {
     int32_t attn_from_stage;  /* 2: stages 0,1 SepConv, stages 2,3 attention               */
     float   ln_eps;           /* 1e-6                                                      */
     int32_t max_batch;        /* workspace is sized for this many images per forward call  */
-    int32_t operand_f16;      /* 0 / 1 as hipts_vit_config_t.operand_f16; 2: the fp8 mode BASELINE.json configs[4]
-                               * names -- OCP e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4, weights with a per-tensor
-                               * power-of-two scale undone by the instruction's scale operand) for pwconv2, fc1 and fc2 in
-                               * stages whose width is a multiple of 128, IEEE half everywhere else.  Costs accuracy
-                               * (3 mantissa bits; measured in tests/test_gpu_ccip.py), off by default.              */
+    int32_t operand_f16;      /* 0: bf16, 1: IEEE half MFMA operands (hipts_vit_config_t.operand_f16 bit 0).  The value 2 of
+                               * rounds 1-3 (OCP e4m3 operands for pwconv2 / fc1 / fc2: BASELINE.json configs[4]'s "fp8 MFMA") is
+                               * refused since round 4 (HIPTS_ERR_INVALID): cosine 0.968 against the float32 forward, not
+                               * faster than half operands, and per-32-element block scales do not change that (DESIGN.md
+                               * section 6, tools/ccip_fp8_emulation.py).                                             */
 } hipts_ccip_config_t;
 
 int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t** out);

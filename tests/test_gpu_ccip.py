@@ -9,13 +9,8 @@ max |df| 3.5e-2 (tiny) / 6.9e-2 (B36), cosine 0.99988; IEEE-half operands 4e-3 /
 an 8x ratio, i.e. operand rounding only.  Bounds: bf16 max |df| <= 1e-1 and cosine >= 0.9995; half
 max |df| <= 2e-2 and cosine >= 0.99999.
 
-operand_f16 = 2 is the fp8 mode BASELINE.json configs[4] names: e4m3 operands (3 mantissa bits) for pwconv2 / fc1 /
-fc2.  Its distance to the float32 oracle is the format's rounding noise, which the oracle can emulate
-(`metaformer_forward(e4m3=True)` rounds the same operands on the CPU): emulation vs float32 measures cosine
-0.9975 (tiny) / 0.9655 (B36), the device path 0.9969 / 0.9680.  The two e4m3 computations are not expected to agree
-closely with each other -- a value near a rounding boundary flips on a 1-ulp difference and the network amplifies
-it (device vs emulation: 0.9994 / 0.985) -- so the test bounds the device's distance to float32 by the emulation's:
-cosine >= emulation's cosine - 0.01, and an absolute floor of 0.99 (tiny) / 0.95 (B36)."""
+operand_f16 = 2 (e4m3 operands) is refused since round 4: test_ccip_e4m3_mode_is_withdrawn.
+"""
 import numpy as np
 import pytest
 
@@ -94,34 +89,17 @@ def test_ccip_b36_384_matches_oracle(f16):
     print("CCIP B36@384: %.2f GFLOP / image" % (enc.flops_per_image() / 1e9))
 
 
-@pytest.mark.parametrize("which", ["tiny", "b36"])
-def test_ccip_e4m3_operands_noise_is_the_formats(which):
+def test_ccip_e4m3_mode_is_withdrawn():
+    """operand_f16 = 2 (e4m3 operands for pwconv2 / fc1 / fc2, BASELINE.json configs[4]'s fp8 leg) was built in round 1 and withdrawn in
+    round 4: cosine 0.968 against the float32 oracle on B36 @384, 1 % slower than half operands, and a CPU emulation of every scaling
+    scheme the scaled MFMA offers (per-tensor, per-32-element E8M0 blocks, later stages only, activations only:
+    tools/ccip_fp8_emulation.py) stays at 0.985 .. 0.995 -- three mantissa bits do not survive 36 blocks.  The library refuses it."""
+    import hiptagsearch
     from hiptagsearch import synth
     from hiptagsearch.cfeatures import CCIPEncoder
-    from oracle import ccip as oc
-    base = synth.CCIP_TINY if which == "tiny" else synth.CCIP_B36_384
-    cfg = dict(base, operand_f16=2)
-    n = 4 if which == "tiny" else 2
-    w = synth.ccip_weights(cfg, seed=3)
-    imgs = synth.images_u8(n, cfg["image_size"], seed=47)
-    x = oc.preprocess_u8_nhwc(imgs)
-    kw = dict(dims=cfg["dims"], depths=cfg["depths"], head_dim=cfg["head_dim"], eps=cfg["ln_eps"])
-    want = oc.metaformer_forward(oc.to_torch(w), x, **kw).numpy()
-    emu = oc.metaformer_forward(oc.to_torch(w), x, e4m3=True, **kw).numpy()
-    enc = CCIPEncoder(cfg, w, max_batch=n)
-    got = enc.forward_u8(imgs)
-    assert np.isfinite(got).all()
-    np.testing.assert_array_equal(enc.forward_u8(imgs), got)                      # run to run identical
-
-    def cos(a, b):
-        return float(((a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))).min())
-    c_dev, c_emu = cos(got, want), cos(emu, want)
-    print("CCIP e4m3 (%s): cosine to float32 oracle %.4f (emulation %.4f), device vs emulation %.4f" % (which, c_dev, c_emu, cos(got, emu)))
-    assert c_dev >= c_emu - 0.01
-    assert c_dev >= (0.99 if which == "tiny" else 0.95)
-    # the 16-bit mode of the same weights is far closer: the e4m3 path really ran
-    ref16 = CCIPEncoder(dict(base, operand_f16=1), w, max_batch=n).forward_u8(imgs)
-    assert cos(ref16, want) > 0.99999 and not np.array_equal(ref16, got)
+    cfg = dict(synth.CCIP_TINY, operand_f16=2)
+    with pytest.raises(hiptagsearch.HipTagSearchError):
+        CCIPEncoder(cfg, synth.ccip_weights(cfg, seed=3), max_batch=2)
 
 
 def test_ccip_two_sub_batch_streams_match_single_stream():

@@ -7,7 +7,7 @@ import numpy as np, torch
 from hiptagsearch import synth
 from hiptagsearch.cfeatures import CCIPEncoder
 w = synth.ccip_weights(dict(synth.CCIP_B36_384), seed=46)
-modes = [int(a) for a in sys.argv[1:]] or [0]
+modes = [int(a) for a in sys.argv[1:]] or [1]      # 0 bf16, 1 half (2, the e4m3 mode, was withdrawn in round 4)
 for mode, B in [(m, b) for m in modes for b in (20, 64)]:
     cfg = dict(synth.CCIP_B36_384, operand_f16=mode)
     enc = CCIPEncoder(cfg, w, max_batch=B)
@@ -19,5 +19,5 @@ for mode, B in [(m, b) for m in modes for b in (20, 64)]:
     for _ in range(n): enc.forward_u8(imgs, out=out)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     fl = enc.flops_per_image()
-    print("operands %s batch %d: %.2f ms  %.0f images/s  %.1f TFLOP/s (%.2f GFLOP/img)" % (("bf16", "half", "e4m3")[mode], B, dt * 1e3, B / dt, B * fl / dt / 1e12, fl / 1e9))
+    print("operands %s batch %d: %.2f ms  %.0f images/s  %.1f TFLOP/s (%.2f GFLOP/img)" % (("bf16", "half")[mode], B, dt * 1e3, B / dt, B * fl / dt / 1e12, fl / 1e9))
     del enc
