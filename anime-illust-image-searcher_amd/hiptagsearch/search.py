@@ -33,20 +33,16 @@ REQUIRE_TAG_MAGIC_NUMBER = 1000        # webui.py:60
 TOPK_MAX = 1024                        # hipts_topk limit
 
 
-def filter_searched_result(sorted_scores: List[Tuple[int, float]]) -> List[Tuple[int, float]]:
-    """webui.py:63-80: cut the ranked list at the second place where consecutive scores differ by
-    less than 1e-6 (equal scores do not count), drop non-positive scores, divide by the maximum."""
-    scores_ndarr = np.array([s for _, s in sorted_scores])
-    diff_arr = scores_ndarr[:-1] - scores_ndarr[1:]
-    diff_arr = np.where(diff_arr == 0, np.inf, diff_arr)
-    t = len(sorted_scores)
-    found_points = np.where(diff_arr < DIFF_FILTER_THRESH)[0]
-    if len(found_points) == 1:
-        t = found_points[0]
-    elif len(found_points) >= 2:
-        t = found_points[1]
-    max_val = scores_ndarr.max()
-    return [(sorted_scores[i][0], sorted_scores[i][1] / float(max_val)) for i in range(int(t)) if sorted_scores[i][1] > 0]
+def filter_searched_result(ranked: List[Tuple[int, float]]) -> List[Tuple[int, float]]:
+    """The result filter of webui.py:63-80 on a list ranked by descending score: the list ends at the SECOND place where two neighbours
+    are closer than 1e-6 without being equal (at the first if there is only one), entries with a non-positive score are dropped, and
+    the scores are divided by the largest one.  Pinned by tests/golden/g5_filter.json (vectors produced by the reference's function)."""
+    vals = np.fromiter((score for _, score in ranked), dtype=np.float64, count=len(ranked))
+    gaps = vals[:-1] - vals[1:]
+    close = np.flatnonzero((gaps != 0) & (gaps < DIFF_FILTER_THRESH))      # equal neighbours (gap 0) do not count; NaN gaps neither
+    cut = len(ranked) if close.size == 0 else int(close[min(1, close.size - 1)])
+    top = float(vals.max())
+    return [(doc, score / top) for doc, score in ranked[:cut] if score > 0]
 
 
 def _split_weight(tag: str):
