@@ -636,6 +636,7 @@ constexpr int TOPK_U = 16;
 constexpr int TOPK_SORT_TARGET = 256;
 
 struct Search1State;
+struct Search1Witness;
 __device__ void search1_state_clear(Search1State* st);
 __device__ void search1_state_debug(Search1State* st, uint32_t cnt, uint32_t fast);
 constexpr int S1_BLOCK_CAP = 64;     // candidates one search1_collect_kernel workgroup (1024 documents) may hand on: at least this many (search_one sizes it)
@@ -1252,6 +1253,13 @@ struct Search1State {            // device resident; the maxima slots are all ze
     uint32_t dbg[4];                         // NOT cleared: {candidates, took the candidate path, 0, 0} of the last query (hiptsdbg_search1_last)
 };
 
+struct Search1Witness {          // 32 B per wave of search1_score_kernel (64 documents)
+    double bm_a;                 // the wave's largest BM25 score ...
+    float sim_a, pad0;           // ... and that document's index product
+    double bm_b;                 // the BM25 score of the document with ...
+    float sim_b, pad1;           // ... the wave's largest index product
+};
+
 __device__ void search1_state_clear(Search1State* st) {
     uint32_t* w = reinterpret_cast<uint32_t*>(st);
     for (int i = threadIdx.x; i < (int)(offsetof(Search1State, dbg) / 4); i += blockDim.x) w[i] = 0;
@@ -1268,7 +1276,7 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
                                                                    const int32_t* __restrict__ tf, const int32_t* __restrict__ dl,
                                                                    const double* __restrict__ idf, int32_t V, double avgdl,
                                                                    double* __restrict__ bm_out, float* __restrict__ sim_out,
-                                                                   Search1State* __restrict__ st) {
+                                                                   Search1State* __restrict__ st, Search1Witness* __restrict__ wit) {
     __shared__ int32_t sterm[S1_LDS_TERMS];
     __shared__ int sptr[S1_THREADS + 1];
     __shared__ int32_t stf[S1_MAX_TERMS][S1_THREADS];          // tf of query term j in this thread's document (0 = absent)
@@ -1397,9 +1405,25 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
     // ---- per-workgroup maxima -> one of 256 slots (atomicMax on order-preserving images; 0 is below every value): ~3 adds per slot
     double ma = valid ? s : -INFINITY;
     float mb = valid ? acc : -INFINITY;
+    const double s_own = ma;
+    const float acc_own = mb;
     for (int o = 32; o >= 1; o >>= 1) {
         ma = fmax(ma, __shfl_xor(ma, o));
         mb = fmaxf(mb, __shfl_xor(mb, o));
+    }
+    if (wit) {
+        // Two WITNESS documents per wave for search1_finish_kernel's threshold: the one with the wave's largest BM25 score and the one with
+        // its largest index product, each with BOTH of its scores.  Whatever the global maxima turn out to be, the combined score of a real
+        // document is a lower bound of its wave's best combined score -- and the wave's best is, in practice, one of these two.
+        const unsigned long long ba = __ballot(s_own == ma), bb = __ballot(acc_own == mb);
+        const int la = ba ? __ffsll(ba) - 1 : 0, lb = bb ? __ffsll(bb) - 1 : 0;      // (an all-NaN wave: any lane; its witness then scores NaN = digit 0)
+        const float sim_at_a = __shfl(acc_own, la);
+        const double bm_at_b = __shfl(s_own, lb);
+        if ((tid & 63) == 0) {
+            Search1Witness w;
+            w.bm_a = ma; w.sim_a = sim_at_a; w.bm_b = bm_at_b; w.sim_b = mb; w.pad0 = 0.f; w.pad1 = 0.f;
+            wit[d >> 6] = w;                        // d of lane 0 = the wave's first document (D rounded up to whole waves is allocated)
+        }
     }
     __shared__ double pa[S1_THREADS / 64];
     __shared__ float pb[S1_THREADS / 64];
@@ -1592,6 +1616,99 @@ __global__ __launch_bounds__(S1_COLLECT_THREADS) void search1_collect_kernel(con
     }
 }
 
+// search1_combine_kernel + search1_collect_kernel in ONE launch (round 4): the threshold no longer comes from the group maxima of the
+// combined scores (which only exist after a pass over all documents, hence the launch boundary between the two kernels) but from the
+// WITNESS documents the score kernel left behind, two per wave: a workgroup combines the 2 G witnesses itself (G x 32 B from L2),
+// takes per wave the larger of its two, and uses the digit of the k-th largest of those G values -- still a lower bound of the k-th
+// largest combined score, because every value belongs to a real document and no two waves share one.  Then it combines its own 1024
+// documents (webui.py:377-383, combine_kernel's expression, operation for operation), stores them for the fallback paths and the
+// caller, and hands on the candidates as search1_collect_kernel does.  Used when a group is a whole wave (gl == 64, gw == 1: 160 k <=
+// D <= 262 k documents at k = 100); other sizes keep the two kernels.
+__global__ __launch_bounds__(S1_COLLECT_THREADS) void search1_finish_kernel(const double* __restrict__ bm, const float* __restrict__ sim, int64_t D, int k,
+                                                                            double wa, float wb, double* __restrict__ final_out,
+                                                                            const Search1State* __restrict__ st, const Search1Witness* __restrict__ wit,
+                                                                            int groups, uint32_t* __restrict__ bcnt, uint32_t* __restrict__ bflag,
+                                                                            unsigned long long* __restrict__ bkey, uint32_t* __restrict__ bid, int bcap) {
+    __shared__ uint32_t hist[4096];
+    __shared__ int scan[17];
+    __shared__ int sh_dmin;
+    __shared__ uint32_t sh_n, sh_other;
+    const int tid = threadIdx.x, lane = tid & 63;
+    double ma;
+    float mb;
+    search1_maxima(st, &ma, &mb);
+    auto comb = [&](double A, float B) -> double {       // search1_combine_kernel / combine_kernel, operation for operation
+        if (ma > 0.0) A = A / ma;
+        if (mb > 0.0f) B = B / mb;
+        const float wB = wb * B;
+        return wa * A + (double)wB;
+    };
+    for (int i = tid; i < 4096; i += S1_COLLECT_THREADS) hist[i] = 0;
+    if (tid == 0) {
+        sh_n = 0;
+        sh_other = 0;
+    }
+    __syncthreads();
+    for (int g0 = 0; g0 < groups; g0 += S1_COLLECT_THREADS) {
+        const int g = g0 + tid;
+        uint32_t dg = 0u;
+        if (g < groups) {
+            const Search1Witness w = wit[g];
+            dg = value_digit(fmax(comb(w.bm_a, w.sim_a), comb(w.bm_b, w.sim_b)));
+        }
+        hist_add(hist, dg, dg != 0u);
+    }
+    __syncthreads();
+    int own[4], ssum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int bin = 4095 - (4 * tid + j);
+        own[j] = bin >= 1 ? (int)hist[bin] : 0;
+        ssum += own[j];
+    }
+    int total;
+    const int excl = block_excl_scan(ssum, scan, &total);
+    if (tid == 0) sh_dmin = 1;
+    __syncthreads();
+    if (excl < k && k <= excl + ssum) {
+        int run = excl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (run < k && k <= run + own[j]) sh_dmin = 4095 - (4 * tid + j);
+            run += own[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t dmin = (uint32_t)sh_dmin;
+    const int64_t d = (int64_t)blockIdx.x * S1_COLLECT_THREADS + tid;
+    double f = -INFINITY;
+    if (d < D) {
+        f = comb(bm[d], sim[d]);
+        final_out[d] = f;
+    }
+    const bool take = d < D && value_digit(f) >= dmin;
+    if (d < D && !take && f != -INFINITY) sh_other = 1u;
+    const uint64_t m = __ballot(take);
+    if (m != 0) {
+        uint32_t base = 0;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if (lane == leader) base = atomicAdd(&sh_n, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (take) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (slot < (uint32_t)bcap) {
+                bkey[(int64_t)blockIdx.x * bcap + slot] = order_key(f);
+                bid[(int64_t)blockIdx.x * bcap + slot] = (uint32_t)d;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bcnt[blockIdx.x] = sh_n;
+        bflag[blockIdx.x] = sh_other;
+    }
+}
+
 // Handle-less entry points (hipts_combine / hipts_topk) keep their small scratch here: one slot
 // per (device, purpose), intentionally never freed (freeing at static-destruction time would
 // race the HIP runtime's own teardown).  Callers are single-threaded per device by contract.
@@ -1614,7 +1731,7 @@ int copy_out(void* dst, const void* src_dev, size_t bytes, int memspace, hipStre
 enum QueryProfCat { QP_BM25 = 0, QP_SIM, QP_ROWMAX, QP_COMBINE, QP_TOPK, QP_S1_SCORE, QP_S1_COMBINE, QP_S1_COLLECT, QP_S1_TOPK, QP_COUNT };
 static_assert(QP_COUNT == HIPTS_QUERY_PROF_CATEGORIES, "category count");
 const char* const kQueryProfNames[QP_COUNT] = {"bm25_postings_kernel", "sim_mfma_kernel", "rowmax_kernel<float>", "combine_kernel", "topk_kernel",
-                                               "search1_score_kernel", "search1_combine_kernel", "search1_collect_kernel", "topk_kernel<candidates>"};
+                                               "search1_score_kernel", "search1_combine_kernel", "search1_collect_kernel | search1_finish_kernel", "topk_kernel<candidates>"};
 
 struct QueryProfScope {
     hipts_bm25* h;
@@ -1808,7 +1925,12 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     const size_t off_bflag = off_bcnt + (size_t)blocks3 * 4;
     const size_t off_bkey = (off_bflag + (size_t)blocks3 * 4 + 15) / 16 * 16;
     const size_t off_bid = off_bkey + (size_t)blocks3 * bcap * 8;
-    const size_t ws_bytes = off_bid + (size_t)blocks3 * bcap * 4;
+    // combine + collect in one launch (search1_finish_kernel) when a group is exactly one wave of the score kernel: its threshold comes from
+    // the score kernel's witness records (HIPTS_SEARCH1_FINISH=0: the two kernels, for A/B)
+    static const bool allow_finish = !(getenv("HIPTS_SEARCH1_FINISH") && atoi(getenv("HIPTS_SEARCH1_FINISH")) == 0);
+    const bool finish = allow_finish && gl == 64 && gw == 1;
+    const size_t off_wit = (off_bid + (size_t)blocks3 * bcap * 4 + 31) / 32 * 32;
+    const size_t ws_bytes = off_wit + (finish ? (size_t)ceil_div(D, S1_THREADS) * (S1_THREADS / 64) * sizeof(Search1Witness) : 0);
     if (bm25->s1_state.bytes < ws_bytes) {
         HIPTS_TRY(bm25->s1_state.alloc(ws_bytes));
         bm25->s1_dirty = true;
@@ -1822,6 +1944,7 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     uint32_t* bflag = reinterpret_cast<uint32_t*>(ws + off_bflag);
     unsigned long long* bkey = reinterpret_cast<unsigned long long*>(ws + off_bkey);
     uint32_t* bid = reinterpret_cast<uint32_t*>(ws + off_bid);
+    Search1Witness* wit = finish ? reinterpret_cast<Search1Witness*>(ws + off_wit) : nullptr;
     const size_t out_bytes = (size_t)kk * 12;
     HIPTS_TRY(bm25->pin_out.reserve(out_bytes + 192));
     double* hv = bm25->pin_out.as<double>();                  // pinned + mapped: the last kernel stores the results here
@@ -1845,19 +1968,26 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
         search1_score_kernel<<<ceil_div(D, S1_THREADS), S1_THREADS, 0, s>>>(Q, index->tiled.as<float4>(), D, bm25->d_ptr.as<int64_t>(),
                                                                             bm25->d_term.as<int32_t>(), bm25->d_tf.as<int32_t>(),
                                                                             bm25->d_dl.as<int32_t>(), bm25->d_idf.as<double>(), bm25->V, bm25->avgdl,
-                                                                            bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), st);
+                                                                            bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), st, wit);
         HIPTS_LAUNCH_CHECK();
     }
-    {
-        QueryProfScope ps(bm25, s, QP_S1_COMBINE, (double)D * 20.0);
-        search1_combine_kernel<<<blocks2, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, final_dev,
-                                                       st, wmax, gw, gl);
+    if (finish) {
+        QueryProfScope ps(bm25, s, QP_S1_COLLECT, (double)D * 20.0 + (double)blocks3 * (double)waves * 32.0);
+        search1_finish_kernel<<<blocks3, S1_COLLECT_THREADS, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, kk, w_bm25, (float)w_sim,
+                                                                     final_dev, st, wit, (int)waves, bcnt, bflag, bkey, bid, bcap);
         HIPTS_LAUNCH_CHECK();
-    }
-    {
-        QueryProfScope ps(bm25, s, QP_S1_COLLECT, (double)D * 8.0);
-        search1_collect_kernel<<<blocks3, S1_COLLECT_THREADS, 0, s>>>(final_dev, D, kk, wmax, groups, bcnt, bflag, bkey, bid, bcap);
-        HIPTS_LAUNCH_CHECK();
+    } else {
+        {
+            QueryProfScope ps(bm25, s, QP_S1_COMBINE, (double)D * 20.0);
+            search1_combine_kernel<<<blocks2, 256, 0, s>>>(bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), D, w_bm25, (float)w_sim, final_dev,
+                                                           st, wmax, gw, gl);
+            HIPTS_LAUNCH_CHECK();
+        }
+        {
+            QueryProfScope ps(bm25, s, QP_S1_COLLECT, (double)D * 8.0);
+            search1_collect_kernel<<<blocks3, S1_COLLECT_THREADS, 0, s>>>(final_dev, D, kk, wmax, groups, bcnt, bflag, bkey, bid, bcap);
+            HIPTS_LAUNCH_CHECK();
+        }
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_TOPK, (double)kk * 24.0);
