@@ -88,24 +88,14 @@ __device__ __forceinline__ i32x8 read_frag8(const char* lds_tile, int rowblk, in
     return i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 }
 
-__device__ __forceinline__ float gelu_f(float x, int tanh_form) {
-    if (tanh_form) {
-        // torch gelu(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
-        // 0.5 (1 + tanh(u)) = sigmoid(2u) = 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 + one v_rcp_f32.
-        // exponent of 2: -2 log2(e) sqrt(2/pi) (x + 0.044715 x^3) = x (c1 + c2 x^2), explicit fma (the file is
-        // built with -ffp-contract=off)
-        const float c1 = -2.885390081777927f * 0.7978845608028654f, c2 = c1 * 0.044715f;
-        const float e = __builtin_amdgcn_exp2f(x * fmaf(c2, x * x, c1));
-        return x * __builtin_amdgcn_rcpf(1.0f + e);
-    }
-    return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
-}
-
-// Four values at once: the tanh form in packed fp32 (v_pk_mul/fma/add_f32 process two floats per lane and
-// issue slot -- the GELU epilogue is VALU-bound: 128 values per lane, two waves per SIMD), same operation
-// order and roundings as gelu_f.
+// GELU of four values at once, in packed fp32 (v_pk_mul/fma/add_f32 process two floats per lane and issue slot -- the GELU epilogue
+// is VALU-bound: 128 values per lane, two waves per SIMD).  Every epilogue form calls this one function, so a value does not depend on
+// the path its tile took.
 __device__ __forceinline__ f32x4 gelu_f4(f32x4 x, int tanh_form) {
     if (tanh_form) {
+        // torch gelu(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
+        // 0.5 (1 + tanh(u)) = sigmoid(2u) = 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 + one v_rcp_f32 per value.
+        // exponent of 2: -2 log2(e) sqrt(2/pi) (x + 0.044715 x^3) = x (c1 + c2 x^2), explicit fma (the file is built with -ffp-contract=off)
         const float c1 = -2.885390081777927f * 0.7978845608028654f, c2 = c1 * 0.044715f;
         const f32x4 t = x * x;
         const f32x4 g = x * __builtin_elementwise_fma(f32x4{c2, c2, c2, c2}, t, f32x4{c1, c1, c1, c1});
@@ -113,7 +103,28 @@ __device__ __forceinline__ f32x4 gelu_f4(f32x4 x, int tanh_form) {
         e = e + f32x4{1.f, 1.f, 1.f, 1.f};
         return x * f32x4{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), __builtin_amdgcn_rcpf(e[2]), __builtin_amdgcn_rcpf(e[3])};
     }
-    return f32x4{gelu_f(x[0], 0), gelu_f(x[1], 0), gelu_f(x[2], 0), gelu_f(x[3], 0)};
+    // erf form, x Phi(x) with Phi(x) - 1/2 = xc P(xc^2) / Q(xc^2), xc = x clamped to +-5.5 (Phi(-5.5) = 1.9e-8), P and Q of degree 5: a
+    // weighted minimax fit (tools/fit_gelu_erf.py) whose fp32 evaluation is within 2.5e-7 max(1, |x|) of the exact value -- the
+    // fp32 expression 0.5 x (1 + erff(x / sqrt 2)) is within 1.1e-7 max(1, |x|), and what is stored is rounded to 16 bits (4.9e-4 relative).
+    // Everything but the clamp and the reciprocal is packed fp32: about 12 issue slots a value, like the tanh form, where libm's
+    // branchy erff (rounds 1-3) took about 55 -- more than the tile's main loop.
+    const f32x4 xc{__builtin_amdgcn_fmed3f(x[0], -5.5f, 5.5f), __builtin_amdgcn_fmed3f(x[1], -5.5f, 5.5f), __builtin_amdgcn_fmed3f(x[2], -5.5f, 5.5f),
+                   __builtin_amdgcn_fmed3f(x[3], -5.5f, 5.5f)};
+    const f32x4 t = xc * xc;
+    auto k4 = [](float c) { return f32x4{c, c, c, c}; };
+    f32x4 p = __builtin_elementwise_fma(k4(2.2240455115528255e-08f), t, k4(6.478198381570408e-06f));
+    p = __builtin_elementwise_fma(p, t, k4(0.00017989516452868775f));
+    p = __builtin_elementwise_fma(p, t, k4(0.00474442647621276f));
+    p = __builtin_elementwise_fma(p, t, k4(0.03488362160853281f));
+    p = __builtin_elementwise_fma(p, t, k4(0.39894214428114516f));
+    f32x4 q = __builtin_elementwise_fma(k4(1.1920686967418627e-06f), t, k4(7.74708620425572e-05f));
+    q = __builtin_elementwise_fma(q, t, k4(0.0019464965294343475f));
+    q = __builtin_elementwise_fma(q, t, k4(0.02924650260921815f));
+    q = __builtin_elementwise_fma(q, t, k4(0.25410501090673415f));
+    q = __builtin_elementwise_fma(q, t, k4(1.0f));
+    const f32x4 rq{__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1]), __builtin_amdgcn_rcpf(q[2]), __builtin_amdgcn_rcpf(q[3])};
+    const f32x4 r = (xc * p) * rq;
+    return x * (r + k4(0.5f));
 }
 
 // (rstd, rstd * mean) of row m for a folded LayerNorm: finished by a kernel (rowstat) or from the producer's per-tile partial
@@ -309,6 +320,31 @@ __device__ __forceinline__ void staged_store_2blocks(char* image, int lane, int 
     __builtin_amdgcn_wave_barrier();
 }
 
+// staged_store_2blocks for a tile that lies inside the matrix: two full row blocks, nothing predicated (one basic block)
+template <bool F16, typename ValueOf>
+__device__ __forceinline__ void staged_store_2blocks_interior(char* image, int lane, bf16_t* out_rows, int ld, ValueOf value_of) {
+    const int lr = lane & 15, lq = lane >> 4, lc = lane & 7, lrow = lane >> 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = u * 16 + lr;
+            const int pc = (j * 2 + (lq >> 1)) ^ ((row >> 1) & 7);
+            const f32x4 v = value_of(u, j);
+            *reinterpret_cast<bf16x4*>(image + row * 128 + pc * 16 + (lq & 1) * 8) = pack4<F16>(v[0], v[1], v[2], v[3]);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r8 = 0; r8 < 4; ++r8) {
+        const int row = r8 * 8 + lrow;
+        const uint4 v = *reinterpret_cast<const uint4*>(image + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+        *reinterpret_cast<uint4*>(out_rows + (size_t)row * ld + lc * 8) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // A (16 MR) x 32 block of 16-bit values (the SwiGLU product: half as many output columns as accumulator columns):
 // 64 B per row, the image geometry of staged_store_rows8 with 8 B per (row block, column block) -- lane (lr, lq) writes
 // columns 16 jj + 4 lq ..+3 of row 16 i + lr; bank = 16 (row & 3) + 4 (chunk ^ (row >> 2) & 3) + 2 (lq & 1) per half wave.
@@ -350,9 +386,14 @@ __device__ __forceinline__ void staged_store_half_rows(char* region, int lane, i
 // wave's 128 rows, j: 16-column block of its 64 columns).  Loads that feed the epilogue (bias,
 // positional embedding, residual) are issued in batches of four before their first use so their
 // latencies overlap instead of forming a chain of 32 dependent round trips.
-template <int EPI, int MR = 8, bool F16 = false>
+template <int EPI, int MR = 8, bool F16 = false, bool INT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR][4], int m0, int n0, int wave_m, int wave_n,
-                                              int lane, const f32x4* bias_pre = nullptr, char* scratch = nullptr, const float2* st_lds = nullptr) {
+                                              int lane, const f32x4* bias_pre = nullptr, char* scratch = nullptr, const float2* st_lds = nullptr,
+                                              const f32x4* colvec = nullptr) {
+    // colvec (INT): gamma | bias | col_u of ALL the launch's columns (N <= 1024; 256 f32x4 each), staged into LDS once per workgroup: a
+    // per-tile load issued here, behind the next tile's sixteen LDS-DMA requests, is only back when those have all landed.
+    // INT (RESID_XG / RESID_XGI, MR 8): the launcher promises that every tile of the launch lies inside the matrix (M and N multiples of
+    // 256), that there is no positional table and that the 16-bit copy and the row sums are both wanted
     // st_lds: (rstd, rstd * mean) of the tile's rows m0 .. m0 + 255 finished into LDS by the caller (RESID_ROWSTAT / RESID_XGI with the
     // statistics still as the producer's partials); null: read per lane (row_stat)
     const int lr = lane & 15, lq = lane >> 4;
@@ -505,7 +546,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             // of rows 0..63 -- needs 64 load registers, 128 accumulators, gamma and bias at once: 95 spilled registers, 242 us.)
             f32x4 uv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) uv[j] = (fold && nv[j]) ? *reinterpret_cast<const f32x4*>(a.col_u + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) uv[j] = (!INT && fold && nv[j]) ? *reinterpret_cast<const f32x4*>(a.col_u + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
             // ---- two 16-row blocks at a time: residual read-modify-write, then -- while the next blocks' loads are issued -- this
             // pair's share of the row sums and its gamma-scaled 16-bit copy through a 4 KB wave-private LDS image.  (With the copy
             // and the statistics after the whole read-modify-write the 16-bit stores formed a tail of their own: 215 us per
@@ -515,9 +556,69 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             const bool copy = a.out_bf16 != nullptr;
             f32x4 gv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gv[j] = (copy && nv[j]) ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j)
+                gv[j] = (!INT && copy && nv[j]) ? *reinterpret_cast<const f32x4*>(a.ln_gamma + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
             char* image = scratch + (wave_m * 4 + wave_n) * 4096;                     // 8 x 4 KB
             float2* red = reinterpret_cast<float2*>(scratch + 8 * 4096);              // [256 rows][4 waves] behind the images
+            // ---- INT: launches whose tiles all lie inside the matrix (round 4; the ViT's 23 launches per forward) get an instantiation of
+            // their own in which nothing is predicated per lane.  The general loop below compiles into one exec-masked basic block per
+            // load and per store -- 142 branches, the block's loads drained with s_waitcnt vmcnt(0) together with the stores of the
+            // block before, four drains per tile (profiles/r04_c_resid_epilogue.txt).  Here the loop is one basic block: the next
+            // pair's eight loads are requested BEFORE this pair's read-modify-write, statistics and staged 16-bit copy (two register
+            // sets; the waits are counted), and the stores never wait.  Same operations in the same order: the bits do not change.
+            if constexpr (INT) {
+                static_assert(MR == 8, "interior epilogue: full tiles");
+                // the per-column vectors (gamma, bias, col_u) are read from LDS where they are used instead of living in 48 registers:
+                // with them, 128 accumulators and two sets of 32 load registers the allocator spilled addresses, and a scratch reload is
+                // a VMEM operation -- s_waitcnt vmcnt(0), i.e. a drain of every store in flight, in front of each use
+                const f32x4* cvec = colvec + (ncol0 >> 2);
+                const int lane_off = lr * ld + 4 * lq;
+                float* base = a.out_f32 + (size_t)(m0 + wave_m * 128) * ld + ncol0;            // uniform: row block i adds 16 i ld
+                f32x4 xv[2][RB][4];
+                auto request = [&](int buf, int i2) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            xv[buf][u][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(i2 + u) * 16 * ld + lane_off + j * 16);
+                };
+                request(0, 0);
+#pragma unroll
+                for (int i2 = 0; i2 < 8; i2 += RB) {
+                    const int cur = (i2 / RB) & 1;
+                    if (i2 + RB < 8) request(cur ^ 1, i2 + RB);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        float2 st = make_float2(1.f, 0.f);
+                        if constexpr (fold) st = st_lds ? st_lds[wave_m * 128 + (i2 + u) * 16 + lr] : row_stat(a, m0 + wave_m * 128 + (i2 + u) * 16 + lr);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 bj = cvec[256 + j * 4 + lq];
+                            if constexpr (fold) acc[i2 + u][j] = xv[cur][u][j] + (acc[i2 + u][j] * st.x + (bj - cvec[512 + j * 4 + lq] * st.y));
+                            else acc[i2 + u][j] = xv[cur][u][j] + (acc[i2 + u][j] + bj);
+                            *reinterpret_cast<f32x4*>(base + (size_t)(i2 + u) * 16 * ld + lane_off + j * 16) = acc[i2 + u][j];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int i = i2 + u;
+                        f32x4 t = acc[i][0], q = acc[i][0] * acc[i][0];
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) {
+                            t = t + acc[i][j];
+                            q = q + acc[i][j] * acc[i][j];
+                        }
+                        float s1 = (t[0] + t[1]) + (t[2] + t[3]), s2 = (q[0] + q[1]) + (q[2] + q[3]);
+                        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                        if (lq == 0) red[(wave_m * 128 + i * 16 + lr) * 4 + wave_n] = make_float2(s1, s2);
+                    }
+                    staged_store_2blocks_interior<F16>(image, lane, a.out_bf16 + (size_t)(m0 + wave_m * 128 + i2 * 16) * ld + ncol0, ld,
+                                                       [&](int u, int j) { return acc[i2 + u][j] * cvec[j * 4 + lq]; });
+                    __builtin_amdgcn_sched_barrier(0);      // the pair after next is not requested early (registers)
+                }
+            } else {
 #pragma unroll
             for (int i2 = 0; i2 < MR; i2 += RB) {
                 f32x4 xv[RB][4];
@@ -569,6 +670,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 staged_store_2blocks<F16>(image, lane, m0 + wave_m * (MR * 16) + i2 * 16, (MR - i2) < RB ? (MR - i2) : RB, a.M, a.out_bf16, ld, ncol0, a.N,
                                           [&](int u, int j) { return acc[i2 + u][j] * gv[j]; });
             }
+            }       // !INT
             if (copy && a.stat_part) {
                 // the four waves that hold a row meet (uniform); red is written again only after the next tile's main loop
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -694,8 +796,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 for (int j = 0; j < 4; ++j) {
                     if (!nv[j]) continue;
                     const f32x4 v = acc[i][j] + bv[j];
-                    const bf16x4 o = pack4<F16>(gelu_f(v[0], a.gelu_tanh), gelu_f(v[1], a.gelu_tanh), gelu_f(v[2], a.gelu_tanh),
-                                                gelu_f(v[3], a.gelu_tanh));
+                    const f32x4 gv = gelu_f4(v, a.gelu_tanh);           // the staged epilogue's function, so a value does not depend on the path
+                    const bf16x4 o = pack4<F16>(gv[0], gv[1], gv[2], gv[3]);
                     *reinterpret_cast<bf16x4*>(a.out_bf16 + (size_t)m * ld + nc[j]) = o;
                 }
             } else if constexpr (EPI == EPI_QK) {
@@ -1038,8 +1140,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // waits are unchanged.  W fragments are read in phases 0/1 and kept; A fragments in phases 0 and 2.
 // SK (round 4): the split-K tail of GemmArgs::sk_* -- work items past sk_first are (tile, K slice) pairs.  A separate instantiation, so
 // the default kernels' code is untouched.
-template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false, bool SK = false>
+template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false, bool SK = false, bool INT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+    static_assert(!INT || ((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && MR == 8 && !OP8 && !SK), "INT: the residual epilogues' interior form");
     static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
     static_assert(!SK || (!OP8 && MR == 8), "split-K: 16-bit operands, full tiles");
     constexpr int TBM = 2 * MR * 16;
@@ -1047,6 +1150,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
     __shared__ float2 st_table[256];        // folded LayerNorm: (rstd, rstd * mean) of the current tile's rows
     __shared__ float2 sw_red[EPI == EPI_SWIGLU ? 1024 : 1];      // SWIGLU: [256 rows][4 waves] partial row sums of the product
     __shared__ unsigned sk_ticket[SK ? 4 : 1];                  // SK: the ticket lane 0 drew, for the whole workgroup
+    __shared__ f32x4 colvec[INT ? (EPI == EPI_RESID_XGI ? 768 : 512) : 1];      // INT: ln_gamma | bias | col_u of the launch's N <= 1024 columns
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
@@ -1120,6 +1224,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
     // prologue of the first tile: K-tile 0 complete
     if (wave * 4 < 4 * MR) stage_tile(a.A, a.M, K, m0, kt0, smem, wave, lane);     // 4 MR sub-tiles of 8 rows (wave 7 idle for MR = 7)
     stage_tile(a.W, w_rows, K, n0, kt0, smem + TILE_BYTES, wave, lane);
+    if constexpr (INT) {
+        // the per-column vectors of the residual epilogue, once per workgroup (behind the first K-tile's requests; the barrier that opens
+        // the first main loop publishes them)
+        for (int i = tid; i < (a.N >> 2); i += 512) {
+            colvec[i] = reinterpret_cast<const f32x4*>(a.ln_gamma)[i];
+            colvec[256 + i] = reinterpret_cast<const f32x4*>(a.bias)[i];
+            if constexpr (EPI == EPI_RESID_XGI) colvec[512 + i] = reinterpret_cast<const f32x4*>(a.col_u)[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 
     for (;;) {
         f32x4 acc[MR][4];
@@ -1330,7 +1444,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
         // read in K-tile nt - 2) receives K-tile 0 of this workgroup's next tile now, so that its HBM
         // latency is covered by the epilogue; the stage of the last K-tile is the epilogue's scratch.
         f32x4 bias_pre[4];
-        load_bias<EPI>(a, n0, wave_n, lane, bias_pre);      // in flight while the next prologue is issued
+        if constexpr (INT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias_pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};      // INT reads bias (and gamma, col_u) from colvec
+        } else {
+            load_bias<EPI>(a, n0, wave_n, lane, bias_pre);      // in flight while the next prologue is issued
+        }
         constexpr bool FOLDABLE = EPI == EPI_VT || EPI == EPI_GELU || EPI == EPI_STAR || EPI == EPI_QK || EPI == EPI_QK_ROPE || EPI == EPI_SWIGLU ||
                                   EPI == EPI_RESID_ROWSTAT || EPI == EPI_RESID_XGI;
         const bool fold_st = FOLDABLE && a.stat_in != nullptr;
@@ -1440,8 +1559,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
             }
         }
         if (!staged)
-            gemm_epilogue<EPI, MR, F16>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre, smem + ((par + nt + 1) & 1) * STAGE_BYTES,
-                                        fold_st ? st_table : nullptr);
+            gemm_epilogue<EPI, MR, F16, INT>(a, acc, m0, n0, wave_m, wave_n, lane, bias_pre, smem + ((par + nt + 1) & 1) * STAGE_BYTES,
+                                             fold_st ? st_table : nullptr, INT ? colvec : nullptr);
         }       // run_epilogue
         PPSTAMP(5);
         ++stamp_tile;
@@ -2033,6 +2152,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             GemmArgs ar = a;
             ar.raster_gm = (raster > 0 && tiles_n >= 8) ? raster : 0;
             ar.raster_gn = (raster_gn > 0 && tiles_n >= 8 && tiles_n > raster_gn) ? raster_gn : 0;
+            static const bool resid_general = getenv("HIPTS_RESID_GENERAL") && atoi(getenv("HIPTS_RESID_GENERAL")) != 0;      // A/B: the predicated residual epilogue on interior tiles too
             // Split-K tail (GemmArgs::sk_*), an EXPERIMENT that lost (round 4) and stays off: the residual GEMMs with a long K whose last round
             // fills less than half of the chip -- EVA02-L's proj / fc2 at the reference's batch of 10 (84 tiles per sub-batch on 256 CUs), the
             // ViT's fc2 per 32-image sub-batch (294 tiles: 38 in the second round) -- with S <= HIPTS_GEMM_SPLITK slices of at least
@@ -2073,6 +2193,21 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
                         HIPTS_LAUNCH_CHECK();
                         return HIPTS_OK;
                     }
+                }
+            }
+            if constexpr (EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) {
+                // every tile inside the matrix: the instantiation without per-lane predication (HIPTS_RESID_GENERAL=1: the general one, A/B)
+                if (mr == 8 && a.M % 256 == 0 && a.N % 256 == 0 && a.N <= 1024 && !a.pos && a.out_bf16 && a.stat_part && !resid_general) {
+                    static bool attr_int = false;
+                    if (!attr_int) {
+                        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                        attr_int = true;
+                    }
+                    if (a.f16) gemm_pp_kernel<EPI, 8, true, false, false, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
+                    else gemm_pp_kernel<EPI, 8, false, false, false, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
+                    HIPTS_LAUNCH_CHECK();
+                    return HIPTS_OK;
                 }
             }
             if (a.f16) {
@@ -2151,4 +2286,26 @@ int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s) {
     return set_error(HIPTS_ERR_INVALID, "gemm: unknown epilogue");
 }
 
+namespace {
+__global__ void gelu_probe_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int n4, int tanh_form) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) y[i] = gelu_f4(x[i], tanh_form);
+}
+}  // namespace
+
 }  // namespace hipts
+
+// Development/test aid (not part of the public ABI): the GELU of the fc1 epilogue (gelu_f4) on n host floats, n % 4 == 0.
+extern "C" int hiptsdbg_gelu(const float* x_host, int n, int tanh_form, float* y_host) {
+    using namespace hipts;
+    HIPTS_TRY(use_device(0));
+    HIPTS_REQUIRE(x_host && y_host && n > 0 && n % 4 == 0, "hiptsdbg_gelu: n must be a positive multiple of 4");
+    DevBuf x, y;
+    HIPTS_TRY(x.alloc((size_t)n * 4));
+    HIPTS_TRY(y.alloc((size_t)n * 4));
+    HIPTS_TRY(upload(x.p, x_host, (size_t)n * 4));
+    gelu_probe_kernel<<<(n / 4 + 255) / 256, 256>>>(x.as<f32x4>(), y.as<f32x4>(), n / 4, tanh_form);
+    HIPTS_LAUNCH_CHECK();
+    HIPTS_HIP(hipMemcpy(y_host, y.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}

@@ -1129,6 +1129,11 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     g.out_f32 = of32.as<float>(); g.out_bf16 = obf.as<bf16_t>(); g.out2_bf16 = obf2.as<bf16_t>(); g.pos = pos.as<float>();
     g.tokens = 784; g.tokens_pad = 832; g.heads = N / 128 > 0 ? N / 128 : 1; g.dim = N / 2; g.qscale = 0.125f;
     if (epi == EPI_VT) { g.heads = N / 64; g.dim = N; }
+    DevBuf statp;
+    if (epi == EPI_RESID_XG) {      // the ViT's residual launches: x += ..., the next LayerNorm's 16-bit gamma * x copy and row sums
+        HIPTS_TRY(statp.alloc((size_t)(Np / 256) * M * 8));
+        g.pos = nullptr; g.ln_gamma = bias.as<float>(); g.stat_part = statp.as<float>(); g.stat_stride = M;
+    }
     if (op8) { g.op8 = 1; g.f16 = 1; g.w_exp = 3; g.out8 = (epi == EPI_STAR && getenv("HIPTS_GEMM_OUT8")) ? 1 : 0; }
     DevBuf stamps;
     if (getenv("HIPTS_GEMM_STAMPS")) {

@@ -22,6 +22,8 @@ int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out);
 /* The same, and the shader clock (GHz) held inside the main loop of the stamped workgroup (s_memtime against the
  * 100 MHz s_memrealtime); 0 when the library was built without HIPTS_GEMM_STAMPS support for that epilogue. */
 int hiptsdbg_gemm_clock(int M, int N, int K, int epi, int iters, float* ms_out, float* loop_ghz);
+/* y_host[i] = the GELU of the fc1 epilogue (csrc/gemm.hip gelu_f4) of x_host[i]; n % 4 == 0; tanh_form as hipts_vit_config::gelu_tanh. */
+int hiptsdbg_gelu(const float* x_host, int n, int tanh_form, float* y_host);
 /* out_host float32 [M][N] = A W^T for bf16 bit patterns a_bf16 [M][K], w_bf16 [N][K] (plain epilogue). */
 int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host);
 /* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in

@@ -153,3 +153,31 @@ def test_gemm_e4m3_operands_match_float64():
         got8 = torch.from_numpy(out8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
         want8 = torch.from_numpy(out).to(torch.float8_e4m3fn).to(torch.float32).numpy()      # RNE of the fp32 result
         np.testing.assert_array_equal(got8, want8)
+
+
+@pytest.mark.parametrize("form", ["erf", "tanh"])
+def test_fc1_epilogue_gelu_against_float64(form):
+    """The GELU the fc1 epilogue applies (gemm.hip gelu_f4): the erf form is a rational approximation in packed fp32 (round 4; libm's
+    erff before), the tanh form one exp2 and one reciprocal per value.  Against the float64 definitions (timm's nn.GELU / GELU(tanh),
+    tagging.py:174's model.forward) on a dense grid, the tails and the clamp point: within 3e-7 max(1, |x|) -- the fp32 expression
+    0.5 x (1 + erf(x / sqrt 2)) itself is within 1.1e-7 -- where what is stored is a 16-bit value (4.9e-4 relative)."""
+    import ctypes
+    from math import sqrt, pi
+    from scipy.special import erf
+    sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
+    from hiptagsearch import _lib
+    lib = _lib.load()
+    f = lib.hiptsdbg_gelu
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.linspace(-12, 12, 400001), rng.standard_normal(200000) * 2.5, [0.0, -0.0, 5.5, -5.5, 5.4999995, 40.0, -40.0, 1e-30, -1e-30, 6e4, -6e4]])
+    x = np.resize(x.astype(np.float32), (len(x) + 3) // 4 * 4)
+    y = np.empty_like(x)
+    st = f(x.ctypes.data, len(x), 1 if form == "tanh" else 0, y.ctypes.data)
+    assert st == 0, _lib.last_error()
+    xd = x.astype(np.float64)
+    want = 0.5 * xd * (1 + np.tanh(sqrt(2 / pi) * (xd + 0.044715 * xd ** 3))) if form == "tanh" else 0.5 * xd * (1 + erf(xd / sqrt(2)))
+    err = np.abs(y - want) / np.maximum(1.0, np.abs(xd))
+    assert np.isfinite(y).all()
+    assert err.max() <= 3e-7, (err.max(), x[err.argmax()])
+    assert (y[x >= 0] >= 0).all() and (np.abs(y[x > 6] / x[x > 6] - 1) <= 1.2e-7).all()

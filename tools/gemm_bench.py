@@ -7,7 +7,7 @@ from hiptagsearch import _lib
 lib = _lib.load()
 f = lib.hiptsdbg_gemm_time
 f.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_float)]
-EPI = {"patch": 0, "qk": 1, "vt": 2, "resid": 3, "gelu": 4, "star": 6}
+EPI = {"patch": 0, "qk": 1, "vt": 2, "resid": 3, "gelu": 4, "star": 6, "xg": 13}
 shapes = [("qk", 50176, 1536, 768), ("vt", 50176, 768, 768), ("resid", 50176, 768, 768), ("gelu", 50176, 3072, 768),
           ("resid", 50176, 768, 3072), ("gelu", 4096, 4096, 4096), ("gelu", 8192, 8192, 8192), ("gelu", 50176, 3072, 3072)]
 if len(sys.argv) > 1:
