@@ -1,0 +1,364 @@
+/* Host half of the hybrid JPEG decode (see jpeg_slot.h): marker parsing and Huffman entropy decoding of a baseline or
+ * extended-sequential 8-bit JPEG into quantised DCT coefficient blocks.  Plain C, no GPU runtime: built into libhipts_jpeg_host.so,
+ * which the decode worker processes of hiptagsearch/pipeline.py load (a worker must never initialise the GPU).
+ *
+ * What it follows: ITU-T T.81 (markers B.2, Huffman procedures F.2.2 / Annex C) -- the same stream libjpeg-turbo's jdmarker.c /
+ * jdhuff.c read when the reference calls PIL's Image.open (tagging.py:234-252).  Anything this file does not handle -- progressive or
+ * arithmetic coding, 12-bit samples, CMYK / RGB-coded files, sampling other than 4:4:4 / 4:2:2 / 4:2:0, several scans, tiny images --
+ * and any irregularity in the stream is reported (status 1 or 3) and the caller decodes that file with Pillow as before: the fast
+ * path never has to guess what libjpeg's error recovery would have produced. */
+#include <emmintrin.h> /* SSE2: part of the x86-64 baseline */
+#include <string.h>
+
+#include "jpeg_slot.h"
+
+enum { JH_OK = 0, JH_UNSUPPORTED = 1, JH_TOO_SMALL = 2, JH_CORRUPT = 3 };
+
+/* zigzag position -> natural index; positions 64..79 (a run that overshoots the block: an irregular stream, detected after the block)
+ * land in a spare row of the local block buffer */
+static const uint8_t ZIGZAG[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                                   6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                   39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79};
+
+#define LOOK 11 /* bits of lookahead of the decoding tables */
+typedef struct {
+    uint16_t lut[1 << LOOK];  /* prefix -> (length << 8) | symbol; 0: the code is longer than LOOK bits */
+    int32_t fast[1 << LOOK];  /* AC tables: prefix -> (value << 8) | (run << 4) | (code length + magnitude bits) when code AND magnitude
+                                 bits fit in the prefix (the common small coefficients: one lookup per coefficient); 0: decode the
+                                 symbol, then its bits */
+    int32_t maxcode[17];      /* largest code of length l, -1 if there is none */
+    int32_t mincode[17];
+    int32_t valptr[17];       /* index of the first symbol of length l */
+    uint8_t vals[256];
+    int present;
+} Huff;
+
+/* T.81 Annex C: canonical codes from the list of code lengths */
+static int huff_build(Huff* h, const uint8_t* counts, const uint8_t* symbols, int nsym, int is_ac) {
+    int code = 0, p = 0;
+    memset(h->lut, 0, sizeof(h->lut));
+    memset(h->fast, 0, sizeof(h->fast));
+    memcpy(h->vals, symbols, (size_t)nsym);
+    for (int l = 1; l <= 16; ++l) {
+        const int n = counts[l - 1];
+        h->valptr[l] = p;
+        h->mincode[l] = code;
+        if (n == 0) {
+            h->maxcode[l] = -1;
+        } else {
+            if (code + n > (1 << l)) return JH_CORRUPT; /* more codes than the length can hold */
+            h->maxcode[l] = code + n - 1;
+            if (l <= LOOK)
+                for (int i = 0; i < n; ++i) {
+                    const int first = (code + i) << (LOOK - l), span = 1 << (LOOK - l);
+                    for (int j = 0; j < span; ++j) h->lut[first + j] = (uint16_t)((l << 8) | symbols[p + i]);
+                }
+        }
+        p += n;
+        code = (code + n) << 1;
+    }
+    if (is_ac)
+        for (int i = 0; i < (1 << LOOK); ++i) {
+            const int e = h->lut[i];
+            if (!e) continue;
+            const int len = e >> 8, run = (e >> 4) & 15, mag = e & 15;
+            if (mag == 0 || len + mag > LOOK) continue;
+            int k = ((i << len) & ((1 << LOOK) - 1)) >> (LOOK - mag);
+            if (k < (1 << (mag - 1))) k += (int)((~0u) << mag) + 1;
+            h->fast[i] = k * 256 + run * 16 + (len + mag);
+        }
+    h->present = 1;
+    return JH_OK;
+}
+
+typedef struct {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t bits; /* left-justified */
+    int nbits;
+    int fake;      /* bits appended after the data ran into a marker (or the end of the file) */
+} BitReader;
+
+/* at least 32 valid bits afterwards: a symbol (<= 16 bits) and its magnitude bits (<= 15) */
+static inline void refill(BitReader* b) {
+    if (b->nbits > 32) return;
+    if (b->fake == 0 && b->p + 4 <= b->end) {
+        uint32_t v;
+        memcpy(&v, b->p, 4);
+        v = __builtin_bswap32(v);
+        const uint32_t x = ~v;
+        if (!((x - 0x01010101u) & ~x & 0x80808080u)) { /* no 0xFF among the four bytes: nothing stuffed, no marker */
+            b->bits |= (uint64_t)v << (32 - b->nbits);
+            b->nbits += 32;
+            b->p += 4;
+            return;
+        }
+    }
+    while (b->nbits <= 56) {
+        uint32_t c = 0;
+        if (b->fake == 0 && b->p < b->end) {
+            c = *b->p;
+            if (c == 0xFF) {
+                if (b->p + 1 < b->end && b->p[1] == 0) {
+                    b->p += 2; /* stuffed zero byte */
+                } else {
+                    c = 0; /* a marker: stay on it */
+                    b->fake += 8;
+                }
+            } else {
+                b->p++;
+            }
+        } else {
+            b->fake += 8;
+        }
+        b->bits |= (uint64_t)c << (56 - b->nbits);
+        b->nbits += 8;
+    }
+}
+
+static inline int huff_decode(BitReader* b, const Huff* h) {
+    const uint32_t e = h->lut[b->bits >> (64 - LOOK)];
+    if (e) {
+        const int l = (int)(e >> 8);
+        b->bits <<= l;
+        b->nbits -= l;
+        return (int)(e & 255u);
+    }
+    const int32_t code16 = (int32_t)(b->bits >> 48);
+    for (int l = LOOK + 1; l <= 16; ++l) {
+        const int32_t code = code16 >> (16 - l);
+        if (code <= h->maxcode[l]) {
+            b->bits <<= l;
+            b->nbits -= l;
+            return h->vals[h->valptr[l] + code - h->mincode[l]];
+        }
+    }
+    return -1;
+}
+
+/* T.81 F.2.2.1: s more bits, sign-extended */
+static inline int receive_extend(BitReader* b, int s) {
+    const int v = (int)(b->bits >> (64 - s));
+    b->bits <<= s;
+    b->nbits -= s;
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+static inline unsigned be16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_t slot_bytes) {
+    if (!data || !slot || n < 4 || slot_bytes < HIPTS_JPEG_HEADER_BYTES) return JH_TOO_SMALL;
+    if (data[0] != 0xFF || data[1] != 0xD8) return JH_UNSUPPORTED;
+    uint16_t qt[4][64];
+    int qt_present[4] = {0, 0, 0, 0};
+    static _Thread_local Huff dc[4], ac[4];
+    for (int i = 0; i < 4; ++i) dc[i].present = ac[i].present = 0;
+    int width = 0, height = 0, ncomp = 0, have_sof = 0, restart = 0, saw_jfif = 0, saw_adobe = 0, adobe_transform = 0;
+    int cid[3] = {0, 0, 0}, ch[3] = {1, 1, 1}, cv[3] = {1, 1, 1}, ctq[3] = {0, 0, 0};
+    int64_t pos = 2;
+    for (;;) {
+        if (pos + 4 > n) return JH_CORRUPT;
+        if (data[pos] != 0xFF) return JH_CORRUPT;
+        while (pos < n && data[pos] == 0xFF) ++pos; /* fill bytes */
+        if (pos >= n) return JH_CORRUPT;
+        const int m = data[pos++];
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD8 || m == 0xD9 || m == 0x00) return JH_CORRUPT;
+        if (pos + 2 > n) return JH_CORRUPT;
+        const int len = (int)be16(data + pos);
+        if (len < 2 || pos + len > n) return JH_CORRUPT;
+        const uint8_t* seg = data + pos + 2;
+        int sl = len - 2;
+        if (m == 0xDB) {
+            while (sl > 0) {
+                const int pq = seg[0] >> 4, tq = seg[0] & 15;
+                if (tq > 3 || pq > 1 || sl < 1 + 64 * (pq + 1)) return JH_CORRUPT;
+                for (int i = 0; i < 64; ++i) qt[tq][ZIGZAG[i]] = pq ? (uint16_t)be16(seg + 1 + 2 * i) : seg[1 + i];
+                qt_present[tq] = 1;
+                seg += 1 + 64 * (pq + 1);
+                sl -= 1 + 64 * (pq + 1);
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (have_sof || sl < 6) return JH_CORRUPT;
+            if (seg[0] != 8) return JH_UNSUPPORTED;
+            height = (int)be16(seg + 1);
+            width = (int)be16(seg + 3);
+            ncomp = seg[5];
+            if (ncomp != 1 && ncomp != 3) return JH_UNSUPPORTED;
+            if (sl < 6 + 3 * ncomp) return JH_CORRUPT;
+            for (int c = 0; c < ncomp; ++c) {
+                cid[c] = seg[6 + 3 * c];
+                ch[c] = seg[7 + 3 * c] >> 4;
+                cv[c] = seg[7 + 3 * c] & 15;
+                ctq[c] = seg[8 + 3 * c];
+                if (ctq[c] > 3 || ch[c] < 1 || cv[c] < 1) return JH_CORRUPT;
+            }
+            have_sof = 1;
+        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return JH_UNSUPPORTED; /* progressive, lossless, arithmetic, hierarchical */
+        } else if (m == 0xCC) {
+            return JH_UNSUPPORTED;
+        } else if (m == 0xC4) {
+            while (sl > 0) {
+                if (sl < 17) return JH_CORRUPT;
+                const int tc = seg[0] >> 4, th = seg[0] & 15;
+                int nsym = 0;
+                for (int i = 0; i < 16; ++i) nsym += seg[1 + i];
+                if (tc > 1 || th > 3 || nsym > 256 || sl < 17 + nsym) return JH_CORRUPT;
+                if (huff_build(tc ? &ac[th] : &dc[th], seg + 1, seg + 17, nsym, tc) != JH_OK) return JH_CORRUPT;
+                seg += 17 + nsym;
+                sl -= 17 + nsym;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return JH_CORRUPT;
+            restart = (int)be16(seg);
+        } else if (m == 0xE0) {
+            if (sl >= 5 && memcmp(seg, "JFIF\0", 5) == 0) saw_jfif = 1;
+        } else if (m == 0xEE) {
+            if (sl >= 12 && memcmp(seg, "Adobe", 5) == 0) {
+                saw_adobe = 1;
+                adobe_transform = seg[11];
+            }
+        } else if (m == 0xDA) {
+            if (!have_sof || sl < 1) return JH_CORRUPT;
+            const int ns = seg[0];
+            if (ns != ncomp) return JH_UNSUPPORTED; /* several scans */
+            if (sl < 1 + 2 * ns + 3) return JH_CORRUPT;
+            int tdc[3], tac[3];
+            for (int c = 0; c < ns; ++c) {
+                if (seg[1 + 2 * c] != cid[c]) return JH_UNSUPPORTED;
+                tdc[c] = seg[2 + 2 * c] >> 4;
+                tac[c] = seg[2 + 2 * c] & 15;
+                if (tdc[c] > 3 || tac[c] > 3 || !dc[tdc[c]].present || !ac[tac[c]].present) return JH_CORRUPT;
+                if (!qt_present[ctq[c]]) return JH_CORRUPT;
+            }
+            if (seg[1 + 2 * ns] != 0 || seg[2 + 2 * ns] != 63 || seg[3 + 2 * ns] != 0) return JH_UNSUPPORTED;
+            pos += len;
+            /* ---- colour model and sampling, by libjpeg's rules (jdapimin.c default_decompress_parms) */
+            if (width < 16 || height < 16) return JH_UNSUPPORTED; /* (jdsample.c leaves the fancy upsampling below 3 chroma columns) */
+            if (ncomp == 3) {
+                int ycc = 1;
+                if (saw_jfif) ycc = 1;
+                else if (saw_adobe) ycc = adobe_transform != 0;
+                else if (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') ycc = 0;
+                if (!ycc) return JH_UNSUPPORTED;
+                if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1) return JH_UNSUPPORTED;
+                if (!((ch[0] == 1 && cv[0] == 1) || (ch[0] == 2 && cv[0] == 1) || (ch[0] == 2 && cv[0] == 2))) return JH_UNSUPPORTED;
+            } else {
+                ch[0] = cv[0] = 1; /* a single-component scan is not interleaved: one block per MCU whatever the factors say */
+            }
+            const int hmax = ch[0], vmax = cv[0];
+            const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            hipts_jpeg_header* hd = (hipts_jpeg_header*)slot;
+            memset(hd, 0, HIPTS_JPEG_HEADER_BYTES);
+            hd->magic = HIPTS_JPEG_MAGIC;
+            hd->kind = 1;
+            hd->width = width;
+            hd->height = height;
+            hd->ncomp = ncomp;
+            hd->hmax = hmax;
+            hd->vmax = vmax;
+            int64_t off = 0;
+            for (int c = 0; c < ncomp; ++c) {
+                hipts_jpeg_component* k = &hd->comp[c];
+                k->h = ch[c];
+                k->v = cv[c];
+                k->blocks_w = mcux * ch[c];
+                k->blocks_h = mcuy * cv[c];
+                k->dw = (width * ch[c] + hmax - 1) / hmax;
+                k->dh = (height * cv[c] + vmax - 1) / vmax;
+                k->offset = (int32_t)off;
+                off += (int64_t)k->blocks_w * k->blocks_h * 64;
+                memcpy(hd->quant[c], qt[ctq[c]], sizeof(qt[0]));
+            }
+            if (off > 0x7fffffff / 2) return JH_UNSUPPORTED;
+            hd->total_bytes = HIPTS_JPEG_HEADER_BYTES + off * 2;
+            if (hd->total_bytes > slot_bytes) return JH_TOO_SMALL;
+            int16_t* coef = (int16_t*)((char*)slot + HIPTS_JPEG_HEADER_BYTES);
+            /* every block is decoded into a local buffer and leaves as eight non-temporal 16-byte stores: the slot (megabytes of a
+             * shared-memory ring, not in any cache) is neither cleared first nor read for ownership */
+            _Alignas(16) int16_t local[80];
+            /* ---- the entropy-coded segment (T.81 F.2.2): MCU by MCU, restart markers every `restart` MCUs */
+            BitReader br = {data + pos, data + n, 0, 0, 0};
+            int pred[3] = {0, 0, 0};
+            int until_restart = restart, next_rst = 0;
+            for (int my = 0; my < mcuy; ++my)
+                for (int mx = 0; mx < mcux; ++mx) {
+                    if (restart && until_restart == 0) {
+                        /* the interval's bits are used up (but for the padding of its last byte): the marker follows */
+                        if (br.fake > br.nbits) return JH_CORRUPT;
+                        if ((br.nbits - br.fake) >= 8) return JH_CORRUPT; /* whole unread data bytes in front of the marker */
+                        const uint8_t* q = br.p; /* the reader stays on a marker's 0xFF; if it has not met it yet, the next unread byte */
+                        if (q + 2 > br.end || q[0] != 0xFF) return JH_CORRUPT;
+                        while (q + 1 < br.end && q[1] == 0xFF) ++q;
+                        if (q + 2 > br.end || q[1] != 0xD0 + next_rst) return JH_CORRUPT;
+                        br.p = q + 2;
+                        br.bits = 0;
+                        br.nbits = 0;
+                        br.fake = 0;
+                        next_rst = (next_rst + 1) & 7;
+                        pred[0] = pred[1] = pred[2] = 0;
+                        until_restart = restart;
+                    }
+                    for (int c = 0; c < ncomp; ++c) {
+                        const hipts_jpeg_component* k = &hd->comp[c];
+                        const Huff* hdc = &dc[tdc[c]];
+                        const Huff* hac = &ac[tac[c]];
+                        for (int v = 0; v < k->v; ++v)
+                            for (int h = 0; h < k->h; ++h) {
+                                int16_t* out = coef + k->offset + ((int64_t)(my * k->v + v) * k->blocks_w + (mx * k->h + h)) * 64;
+                                int16_t* blk = local;
+                                for (int z = 0; z < 10; ++z) _mm_store_si128((__m128i*)local + z, _mm_setzero_si128());
+                                refill(&br);
+                                int s = huff_decode(&br, hdc);
+                                if (s < 0 || s > 15) return JH_CORRUPT;
+                                if (s) pred[c] += receive_extend(&br, s);
+                                if (pred[c] < -32768 || pred[c] > 32767) return JH_CORRUPT;
+                                blk[0] = (int16_t)pred[c];
+                                for (int kk = 1; kk < 64;) {
+                                    refill(&br);
+                                    const int f = hac->fast[br.bits >> (64 - LOOK)];
+                                    if (f) { /* run, code and magnitude bits in one lookup */
+                                        kk += (f >> 4) & 15;
+                                        br.bits <<= (f & 15);
+                                        br.nbits -= (f & 15);
+                                        blk[ZIGZAG[kk++]] = (int16_t)(f >> 8);
+                                        continue;
+                                    }
+                                    const int rs = huff_decode(&br, hac);
+                                    if (rs < 0) return JH_CORRUPT;
+                                    const int r = rs >> 4;
+                                    s = rs & 15;
+                                    if (s == 0) {
+                                        if (r != 15) break; /* end of block */
+                                        kk += 16;
+                                        continue;
+                                    }
+                                    kk += r;
+                                    blk[ZIGZAG[kk]] = (int16_t)receive_extend(&br, s);
+                                    ++kk;
+                                    if (kk > 64) return JH_CORRUPT; /* (kk <= 79 here: the spare row took the store) */
+                                }
+                                {
+                                    int spill = 0;
+                                    for (int z = 64; z < 80; ++z) spill |= local[z];
+                                    if (spill) return JH_CORRUPT; /* a coefficient beyond position 63 */
+                                }
+                                for (int z = 0; z < 8; ++z) _mm_stream_si128((__m128i*)out + z, _mm_load_si128((const __m128i*)local + z));
+                            }
+                    }
+                    if (br.fake > br.nbits) return JH_CORRUPT; /* read past the end of the segment */
+                    if (restart) --until_restart;
+                }
+            _mm_sfence();
+            return JH_OK;
+        }
+        pos += len;
+    }
+}
+
+/* Size of the slot a width x height image needs at most (4:4:4: three full planes of int16, padded to whole MCUs of 16 x 16). */
+int64_t hipts_jpeg_slot_bytes(int width, int height) {
+    const int64_t bw = (width + 15) / 16 * 2, bh = (height + 15) / 16 * 2;
+    return HIPTS_JPEG_HEADER_BYTES + 3 * bw * bh * 128;
+}

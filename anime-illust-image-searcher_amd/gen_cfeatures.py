@@ -73,6 +73,8 @@ def main(arg_str: list) -> None:
                         help='MFMA operand type of the encoder GEMMs (half: same matrix rate as bf16, 8x smaller activation rounding)')
     parser.add_argument('--gpu-resize', action='store_true',
                         help='decode threads only decode; the bilinear resize of gen_cfeatures.py:101 runs on the device (Pillow-exact kernel)')
+    parser.add_argument('--gpu-jpeg', action='store_true',
+                        help='with --workers: the worker processes only entropy-decode baseline JPEGs, the rest of the decode runs on the device')
     parser.add_argument('--arch', choices=['b36', 'tiny'], default='b36', help='b36: CAFormer-B36 widths @384 (the CCIP encoder); tiny: test geometry')
     args = parser.parse_args(arg_str)
     after_date = None
@@ -175,8 +177,8 @@ def main(arg_str: list) -> None:
             progress(len(paths))
         if args.workers > 0:
             from hiptagsearch import pipeline
-            with pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP, device_resize=args.gpu_resize,
-                                     device=device) as dpool:
+            with pipeline.DecodePool(args.workers, cfg["image_size"], args.batch, pipeline.CCIP, device_resize=args.gpu_resize or args.gpu_jpeg,
+                                     device=device, device_jpeg=args.gpu_jpeg) as dpool:
                 for kept, images in dpool.batches(file_list):
                     add(kept, encoder.forward_u8(images))                               # /255 and the CLIP normalisation on the device
         else:

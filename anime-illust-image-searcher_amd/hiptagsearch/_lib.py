@@ -96,6 +96,10 @@ _SIGNATURES = {
     "hipts_synth_images_u8": [c_void_p, c_int64, c_int64, c_int, ctypes.c_uint64, c_int, c_void_p],
     "hipts_resize_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "hipts_resize_batch_u8": [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "hipts_jpeg_entropy_decode": [c_void_p, c_int64, c_void_p, c_int64],
+    "hipts_jpeg_slot_bytes": [c_int, c_int],
+    "hipts_jpeg_decode_rgb": [c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p],
+    "hipts_jpeg_batch_u8": [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "hipts_ccip_metric": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "hipts_comm_unique_id": [c_void_p, c_size_t],
     "hipts_comm_create": [c_void_p, c_size_t, c_int, c_int, c_int, POINTER(c_void_p)],
@@ -144,6 +148,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the header and the library disagree
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.hipts_jpeg_slot_bytes.restype = ctypes.c_int64      # the one entry point that returns a size, not a status
     # the three configuration structures are passed by pointer: a layout that differs from the library's would be read past
     for kind, st in enumerate((VitConfig, EvaConfig, CcipConfig)):
         n = c_size_t(0)

@@ -19,6 +19,13 @@ resize on the host, which the reference does on 8 threads inside the GIL (taggin
                  `input_pipeline`), so N workers feed ~3.5x the images; the ring is registered as pinned memory so the copies
                  are asynchronous DMA.  Images larger than a slot (`max_pixels`) are resized by the worker as before.
 
+  DecodePool(device_resize=True, device_jpeg=True)   (round 4) hybrid JPEG decode: for a baseline JPEG the worker runs only the serial half
+                 of libjpeg -- markers and Huffman decoding (csrc/jpeg_host.c in libhipts_jpeg_host.so, a library without any GPU runtime
+                 behind it) -- and leaves quantised DCT coefficients in its ring slot; inverse DCT, chroma upsampling and YCbCr -> RGB
+                 (libjpeg-turbo's arithmetic byte for byte: csrc/jpeg.hip) run on the device in front of the pad + resize
+                 (`hipts_jpeg_batch_u8`).  Files that path does not take (PNG, progressive or CMYK JPEGs, alpha, anything irregular) are
+                 decoded by Pillow in the same worker as before; the two kinds mix freely inside a batch.
+
 Workers are started with the `forkserver` method so that no child is forked from a process that holds a GPU
 context; create the pool before or after the model, either is safe.
 """
@@ -72,21 +79,60 @@ def decode_image(path: str, size: int, mode: str = TAGGER, raw_max_pixels: int =
 _W = {}
 
 
-def _worker_init(shm_name: str, slots: int, size: int, mode: str, raw_max_pixels: int = 0) -> None:
+JPEG_HOST_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libhipts_jpeg_host.so")
+
+
+def load_jpeg_host_lib():
+    """The host half of the hybrid JPEG decode as a ctypes library (no GPU runtime behind it: safe in worker processes)."""
+    import ctypes
+    if not os.path.exists(JPEG_HOST_LIB):
+        raise ImportError("libhipts_jpeg_host.so not found at %s -- build it with `make -C anime-illust-image-searcher_amd/csrc`" % JPEG_HOST_LIB)
+    lib = ctypes.CDLL(JPEG_HOST_LIB)
+    lib.hipts_jpeg_entropy_decode.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    lib.hipts_jpeg_entropy_decode.restype = ctypes.c_int
+    lib.hipts_jpeg_slot_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.hipts_jpeg_slot_bytes.restype = ctypes.c_int64
+    return lib
+
+
+def _raw_slot_bytes(raw_max_pixels: int, size: int, jpeg: bool) -> int:
+    """Bytes of a ring slot in raw mode: the decoded image, or -- device_jpeg -- the coefficient blocks of a 4:2:0 / 4:2:2 JPEG of that
+    many pixels: 2 B per sample, at most 2 samples per pixel, planes padded to whole 16 x 16 MCUs, a 1 KB header (csrc/jpeg_slot.h).
+    A JPEG that does not fit (4:4:4 above two thirds of max_pixels) is decoded by Pillow like any other file."""
+    px = max(raw_max_pixels, size * size)
+    return px * 3 if not jpeg else px * 4 + 2 * 16 * 4 * (int(px ** 0.5) + 16) + 4096
+
+
+def _worker_init(shm_name: str, slots: int, size: int, mode: str, raw_max_pixels: int = 0, jpeg: bool = False) -> None:
     shm = shared_memory.SharedMemory(name=shm_name)
     _W["shm"] = shm
     if raw_max_pixels > 0:
-        _W["ring"] = np.ndarray((slots, max(raw_max_pixels, size * size) * 3), dtype=np.uint8, buffer=shm.buf)
+        _W["ring"] = np.ndarray((slots, _raw_slot_bytes(raw_max_pixels, size, jpeg)), dtype=np.uint8, buffer=shm.buf)
     else:
         _W["ring"] = np.ndarray((slots, size, size, 3), dtype=np.uint8, buffer=shm.buf)
     _W["size"] = size
     _W["mode"] = mode
     _W["raw"] = raw_max_pixels
+    _W["jpeg"] = load_jpeg_host_lib() if jpeg else None
 
 
 def _worker_decode(task: Tuple[int, str]):
-    """-> False (decode failed), True (model-input image in the slot) or (h, w) (raw mode: the composited image at its own size)."""
+    """-> False (decode failed), True (model-input image in the slot), (h, w) (raw mode: the composited image at its own size) or
+    (h, w, 1) (raw mode with device_jpeg: the slot holds the JPEG's coefficient blocks, csrc/jpeg_slot.h)."""
     slot, path = task
+    if _W.get("jpeg") is not None:
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+        except OSError:
+            data = b""
+        if len(data) > 4 and data[0] == 0xFF and data[1] == 0xD8:
+            row = _W["ring"][slot]
+            src = np.frombuffer(data, dtype=np.uint8)
+            if _W["jpeg"].hipts_jpeg_entropy_decode(src.ctypes.data, len(data), row.ctypes.data, row.nbytes) == 0:
+                hd = row[:16].view(np.int32)
+                return (int(hd[3]), int(hd[2]), 1)
+        # everything else -- and every file the fast path refused -- goes the way it always went
     a = decode_image(path, _W["size"], _W["mode"], _W["raw"])
     if a is None:
         return False
@@ -107,15 +153,18 @@ class DecodePool:
     Files that fail to decode are dropped from `paths` (message printed by the worker), like the reference."""
 
     def __init__(self, workers: Optional[int] = None, size: int = 448, batch: int = 64, mode: str = TAGGER,
-                 device_resize: bool = False, device: int = 0, max_pixels: int = 1600 * 1600):
+                 device_resize: bool = False, device: int = 0, max_pixels: int = 1600 * 1600, device_jpeg: bool = False):
+        if device_jpeg and not device_resize:
+            raise ValueError("device_jpeg needs device_resize: the decoded image only exists on the device")
         self.workers = max(1, workers or (os.cpu_count() or 1))
         self.size, self.batch, self.mode = size, batch, mode
         self.slots = 2 * batch
         self.raw = max(int(max_pixels), size * size) if device_resize else 0
         self.device = device
+        self.jpeg = bool(device_jpeg)
         self._pinned = False
         self._events = [None, None]
-        slot_bytes = self.raw * 3 if self.raw else size * size * 3
+        slot_bytes = _raw_slot_bytes(self.raw, size, self.jpeg) if self.raw else size * size * 3
         self._shm = shared_memory.SharedMemory(create=True, size=self.slots * slot_bytes)
         if self.raw:
             self._ring = np.ndarray((self.slots, slot_bytes), dtype=np.uint8, buffer=self._shm.buf)
@@ -127,7 +176,7 @@ class DecodePool:
         else:
             self._ring = np.ndarray((self.slots, size, size, 3), dtype=np.uint8, buffer=self._shm.buf)
         ctx = mp.get_context("forkserver")
-        self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self._shm.name, self.slots, size, mode, self.raw))
+        self._pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self._shm.name, self.slots, size, mode, self.raw, self.jpeg))
 
     def _to_device(self, base: int, results, stream) -> "object":
         """Raw mode: the ring slots base .. of one decoded batch -> uint8 [n,S,S,3] CUDA tensor on `stream`: copied, padded (tagger: white,
@@ -137,6 +186,12 @@ class DecodePool:
         from . import _lib
         S = self.size
         out = torch.empty((len(results), S, S, 3), dtype=torch.uint8, device="cuda:%d" % self.device)
+        if self.jpeg:       # coefficient slots and Pillow-decoded slots side by side: decode on the device, then the same pad + resize
+            hw = np.ascontiguousarray(np.asarray([r[:2] for r in results], dtype=np.int32))
+            kinds = np.ascontiguousarray(np.asarray([1 if len(r) > 2 else 0 for r in results], dtype=np.int32))
+            _lib.call("hipts_jpeg_batch_u8", self._ring[base].ctypes.data, self._ring.shape[1], _lib.ptr(kinds), _lib.ptr(hw), len(results),
+                      1 if self.mode == TAGGER else 0, _lib.ptr(out), S, 3 if self.mode == TAGGER else 2, self.device, stream.cuda_stream)
+            return out
         hw = np.ascontiguousarray(np.asarray(results, dtype=np.int32).reshape(-1, 2))
         _lib.call("hipts_resize_batch_u8", self._ring[base].ctypes.data, _lib.HOST, self._ring.shape[1], _lib.ptr(hw), len(results),
                   1 if self.mode == TAGGER else 0, _lib.ptr(out), S, 3 if self.mode == TAGGER else 2, self.device, stream.cuda_stream)

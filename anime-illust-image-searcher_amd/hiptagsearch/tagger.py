@@ -215,11 +215,12 @@ class Predictor:
     the reference downloads from the HF hub (tagging.py:146-151); offline it takes local files or the
     seeded synthetic stand-ins."""
 
-    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False, gpu_resize: bool = False) -> None:
+    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False, gpu_resize: bool = False, gpu_jpeg: bool = False) -> None:
         self.device = device
         self.max_batch = max_batch
         self.compat = compat            # reproduce the reference's dropped tail batch (SURVEY.md section 0.4)
         self.gpu_resize = gpu_resize    # the decode threads only decode and pad; Resize(bicubic) runs on the device (hipts_resize_u8)
+        self.gpu_jpeg = gpu_jpeg        # worker processes only entropy-decode baseline JPEGs; the rest of libjpeg runs on the device (pipeline.DecodePool)
         self.tagger_model: Optional[ViTTagger] = None
         self.selector: Optional[TagSelector] = None
         self.tag_names: Optional[List[str]] = None
@@ -421,7 +422,7 @@ class Predictor:
             from . import pipeline
             mine = file_list[lo:hi]
             where = {p: i for i, p in enumerate(mine)}
-            pool = pipeline.DecodePool(workers, size, bs, pipeline.TAGGER, device_resize=self.gpu_resize, device=self.device)
+            pool = pipeline.DecodePool(workers, size, bs, pipeline.TAGGER, device_resize=self.gpu_resize, device=self.device, device_jpeg=self.gpu_jpeg)
             def batches():
                 for kept, images in pool.batches(mine):
                     yield [where[p] for p in kept], images
@@ -523,7 +524,7 @@ class Predictor:
                 source = pipeline.iter_shards(shards, min(batch_size, self.max_batch))
             else:
                 pool = pipeline.DecodePool(workers, size, min(batch_size, self.max_batch), pipeline.TAGGER, device_resize=self.gpu_resize,
-                                           device=self.device)
+                                           device=self.device, device_jpeg=self.gpu_jpeg)
                 source = pool.batches(file_list)
             try:
                 for kept, images in source:

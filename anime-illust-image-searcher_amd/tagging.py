@@ -35,6 +35,9 @@ def main(arg_str: list) -> None:
     parser.add_argument('--gpu-resize', action='store_true',
                         help='decode threads (or the --workers processes) only decode; padding and the Resize(bicubic) of the transform run on the '
                              'device (Pillow-exact kernel)')
+    parser.add_argument('--gpu-jpeg', action='store_true',
+                        help='with --workers and --gpu-resize: the worker processes only entropy-decode baseline JPEGs; inverse DCT, chroma '
+                             'upsampling and colour conversion (libjpeg-turbo\'s arithmetic, byte for byte) run on the device; other files as before')
     parser.add_argument('--synthetic', type=int, default=0, metavar='N',
                         help='tag N images of the synthetic benchmark corpus generated on the device (BASELINE.json configs[3]; --dir is ignored)')
     parser.add_argument('--device', type=int, default=0)
@@ -43,7 +46,7 @@ def main(arg_str: list) -> None:
     from hiptagsearch import dist as hdist
     dist, rank, world, device = hdist.init_from_env(args.device)
     from hiptagsearch.tagger import Predictor
-    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat, gpu_resize=args.gpu_resize)
+    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat, gpu_resize=args.gpu_resize or args.gpu_jpeg, gpu_jpeg=args.gpu_jpeg)
     from hiptagsearch import synth
     model_cfg = {'vit-b16': synth.VIT_B16_448, 'eva02-l14': synth.EVA02_L14_448, 'vit-tiny': synth.VIT_TINY}[args.model]   # vit-tiny: test geometry
     after_date = None

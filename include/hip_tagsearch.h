@@ -224,6 +224,31 @@ int hipts_resize_u8(const uint8_t* src, int src_memspace, int src_h, int src_w, 
 int hipts_resize_batch_u8(const uint8_t* src_base, int src_memspace, int64_t slot_stride, const int32_t* hw, int n, int pad_square,
                           uint8_t* dst_device, int size, int filter, int device, void* stream);
 
+/* ---- Hybrid JPEG decode (round 4).  What stands behind it in the reference: PIL's Image.open(path) inside Predictor.prepare_image /
+ * gen_image_tensor (tagging.py:100-120, 234-252) and _preprocess_image (gen_cfeatures.py:285-295), i.e. libjpeg-turbo with its defaults.
+ * The serial half (markers, Huffman decoding) runs on the host, in the decode worker processes; the per-block / per-pixel half (accurate
+ * integer inverse DCT, "fancy" chroma upsampling, YCbCr -> RGB) on the device, byte for byte libjpeg's arithmetic.
+ *
+ * hipts_jpeg_entropy_decode (HOST ONLY: also exported by libhipts_jpeg_host.so, which has no GPU runtime behind it -- the library the
+ * worker processes load): file bytes -> a "slot" = hipts_jpeg_header (csrc/jpeg_slot.h) + int16 coefficient blocks.
+ * Returns 0; 1: not a file the fast path takes (progressive / arithmetic / 12-bit / CMYK / RGB-coded / sampling other than 4:4:4, 4:2:2,
+ * 4:2:0 / several scans / smaller than 16 x 16 / not a JPEG); 2: the slot is too small; 3: the stream is irregular (truncated, bad codes,
+ * restart markers out of order).  On 1..3 the caller decodes the file with Pillow as before.  hipts_jpeg_slot_bytes: an upper bound of the
+ * slot a width x height image needs. */
+int hipts_jpeg_entropy_decode(const uint8_t* file_bytes, int64_t n, void* slot, int64_t slot_bytes);
+int64_t hipts_jpeg_slot_bytes(int width, int height);
+
+/* One slot (host memory) -> uint8 [height][width][3] RGB = the bytes of PIL.Image.open(file).convert("RGB"); rgb_out in host or device
+ * memory with room for out_capacity bytes.  Synchronises `stream`. */
+int hipts_jpeg_decode_rgb(const void* slot, int64_t slot_bytes, uint8_t* rgb_out, int out_memspace, int64_t out_capacity, int device, void* stream);
+
+/* The batch entry of the decode pipeline (hiptagsearch/pipeline.py): n ring slots (host memory, slot i at slots + i * slot_stride), each
+ * either a coefficient slot (kinds[i] = 1) or a decoded uint8 [h][w][3] image (kinds[i] = 0: the files Pillow had to decode), image i of
+ * hw[2 i] x hw[2 i + 1] pixels -> uint8 [n][size][size][3] on the device: decode, then exactly hipts_resize_batch_u8 (pad_square, filter).
+ * Everything is ordered on `stream`, nothing is synchronised: keep the slots unchanged until the stream has passed this point. */
+int hipts_jpeg_batch_u8(const uint8_t* slots, int64_t slot_stride, const int32_t* kinds, const int32_t* hw, int n, int pad_square,
+                        uint8_t* dst_device, int size, int filter, int device, void* stream);
+
 /* The synthetic image corpus of the benchmark configurations (BASELINE.json configs[3]: "1M synthetic images sharded
  * 8xMI355X"), generated on the device with no host I/O: images first_index .. first_index + count - 1 of the corpus `seed`, uint8
  * [count][image_size][image_size][3], every byte a counter-hash of (seed, GLOBAL image index, byte offset) -- so a rank produces its own

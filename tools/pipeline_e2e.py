@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development aid (gpurun only): end-to-end images/s of the tagging loop over a directory of JPEGs, by input pipeline --
-the reference's 8 decode threads, the same with the resize on the device, N decode processes, N decode-only processes + device resize.
+the reference's 8 decode threads, the same with the resize on the device, N decode processes, N decode-only processes + device resize,
+N entropy-decode-only processes + the rest of the JPEG decode and the resize on the device (hybrid decode, round 4).
 usage: pipeline_e2e.py [n_images] [workers]"""
 import concurrent.futures, io, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +29,8 @@ with tempfile.TemporaryDirectory() as tmp:
     print("%d JPEGs 1024x768 q90 written in %.1f s (%d processes)" % (N, time.perf_counter() - t0, W), flush=True)
     ref = None
     for name, extra in [("8 threads, host resize (the reference's structure)", []), ("8 threads, device resize", ["--gpu-resize"]),
-                        ("%d processes, host resize" % W, ["--workers", str(W)]), ("%d decode-only processes, device resize" % W, ["--workers", str(W), "--gpu-resize"])]:
+                        ("%d processes, host resize" % W, ["--workers", str(W)]), ("%d decode-only processes, device resize" % W, ["--workers", str(W), "--gpu-resize"]),
+                        ("%d entropy-decode processes, device IDCT + resize" % W, ["--workers", str(W), "--gpu-resize", "--gpu-jpeg"])]:
         out = os.path.join(tmp, "tags-wd-tagger.txt")
         if os.path.exists(out):
             os.remove(out)
@@ -47,4 +49,4 @@ with tempfile.TemporaryDirectory() as tmp:
         # steady state: between the first and the last progress print (pool start-up, first-use allocations and the model's warm-up lie before the first)
         loop = ("%.0f images/s steady (images %d..%d in %.2f s), %.0f incl. start-up" % ((cnt[-1] - cnt[0]) / (el[-1] - el[0]), cnt[0], cnt[-1], el[-1] - el[0], cnt[-1] / el[-1])
                 if len(el) >= 2 else "n/a")
-        print("%-52s %s; whole process %.1f s; output identical: %s" % (name, loop, dt, same), flush=True)
+        print("%-58s %s; whole process %.1f s; output identical: %s" % (name, loop, dt, same), flush=True)
