@@ -310,8 +310,12 @@ class Predictor:
     # ---- tagging.py:156-229
     def predict(self, tensors: List, general_thresh: float, general_mcut_enabled: bool, character_thresh: float,
                 character_mcut_enabled: bool) -> List[str]:
+        return self._select_lines(self._forward_probs(tensors), general_thresh, general_mcut_enabled, character_thresh, character_mcut_enabled)
+
+    def _forward_probs(self, tensors: List) -> List[np.ndarray]:
+        """tagging.py:164-176: the forward + sigmoid of predict, per chunk of max_batch images."""
         first = tensors[0]
-        out: List[str] = []
+        out: List[np.ndarray] = []
         packed = isinstance(tensors, np.ndarray) and tensors.dtype == np.uint8 and tensors.ndim == 4      # [B,S,S,3] from the decode pool / shards
         for s in range(0, len(tensors), self.max_batch):
             chunk = tensors[s:s + self.max_batch]
@@ -326,6 +330,14 @@ class Predictor:
             else:   # float32 CHW tensors exactly as the reference's transform produces (tagging.py:241-243)
                 batch = np.stack([np.asarray(t, dtype=np.float32) for t in chunk])
                 _, probs = self.tagger_model.forward(batch)
+            out.append(probs)
+        return out
+
+    def _select_lines(self, probs_list: List[np.ndarray], general_thresh: float, general_mcut_enabled: bool, character_thresh: float,
+                      character_mcut_enabled: bool) -> List[str]:
+        """tagging.py:185-227: MCut thresholds, selection and the tag strings of predict."""
+        out: List[str] = []
+        for probs in probs_list:
             counts, ids, _ = self.selector.run(probs, general_thresh, general_mcut_enabled, character_thresh,
                                                character_mcut_enabled)
             out.extend(format_lines(self.tag_names, counts, ids))
@@ -526,17 +538,31 @@ class Predictor:
                 pool = pipeline.DecodePool(workers, size, min(batch_size, self.max_batch), pipeline.TAGGER, device_resize=self.gpu_resize,
                                            device=self.device, device_jpeg=self.gpu_jpeg)
                 source = pool.batches(file_list)
+            # predict() in two halves: while one thread selects, formats and writes the lines of batch k (the reference does that part on
+            # the CPU too, tagging.py:185-232), this one is already in the forward of batch k + 1 -- one worker, so the file keeps its order
+            post = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+
+            def finish(kept, probs_list):
+                for p, line in zip(kept, self._select_lines(probs_list, 0.3, True, 0.3, True)):
+                    self.write_to_file(p + ',' + line)
+                self.f.flush()
+            pending = None
             try:
                 for kept, images in source:
-                    for p, line in zip(kept, self.predict(images, 0.3, True, 0.3, True)):
-                        self.write_to_file(p + ',' + line)
-                    self.f.flush()
+                    probs_list = self._forward_probs(images)
+                    fut = post.submit(finish, list(kept), probs_list)
+                    if pending is not None:
+                        pending.result()
+                    pending = fut
                     done += len(kept)
                     if done - last >= PROGRESS_INTERVAL:
                         diff = time.perf_counter() - start
                         print(f'{done} files processed\n{diff:.2f} seconds elapsed\n{diff / done:.4f} seconds per file\n', flush=True)
                         last = done
+                if pending is not None:
+                    pending.result()
             finally:
+                post.shutdown(wait=True)
                 if pool is not None:
                     pool.close()
             self.f.close()

@@ -28,9 +28,12 @@ with tempfile.TemporaryDirectory() as tmp:
         list(ex.map(make, [(d, i) for i in range(N)], chunksize=16))
     print("%d JPEGs 1024x768 q90 written in %.1f s (%d processes)" % (N, time.perf_counter() - t0, W), flush=True)
     ref = None
-    for name, extra in [("8 threads, host resize (the reference's structure)", []), ("8 threads, device resize", ["--gpu-resize"]),
+    only = os.environ.get("E2E_MODES")          # e.g. "3,4": run only those rows (0-based)
+    for mode_i, (name, extra) in enumerate([("8 threads, host resize (the reference's structure)", []), ("8 threads, device resize", ["--gpu-resize"]),
                         ("%d processes, host resize" % W, ["--workers", str(W)]), ("%d decode-only processes, device resize" % W, ["--workers", str(W), "--gpu-resize"]),
-                        ("%d entropy-decode processes, device IDCT + resize" % W, ["--workers", str(W), "--gpu-resize", "--gpu-jpeg"])]:
+                        ("%d entropy-decode processes, device IDCT + resize" % W, ["--workers", str(W), "--gpu-resize", "--gpu-jpeg"])]):
+        if only and str(mode_i) not in only.split(","):
+            continue
         out = os.path.join(tmp, "tags-wd-tagger.txt")
         if os.path.exists(out):
             os.remove(out)
