@@ -38,7 +38,7 @@ struct hipts_bm25 {
     std::vector<double> h_idf;
     DevBuf d_ptr, d_term, d_tf, d_dl, d_idf;   // int64[D+1], int32[nnz], int32[nnz], int32[D], double[V]
     DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
-    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out;
+    DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out, ws_parts;
     PinBuf pin_in, pin_out;                    // hipts_search: one H2D of the packed queries, one D2H of the packed results
     // hipts_search_submit / _collect (round 4): two batches in flight -- the host packs and launches batch i + 1 while the device runs batch i.
     // The device workspaces are shared (the batches run on one stream, in order); only the pinned buffers exist per slot.
@@ -416,12 +416,21 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_mfma_kernel(const float* __re
 // in chunks of 8: the chunk of the query matrix ([8 k][256 queries], 9 KB) is staged in LDS by all threads (double-buffered, one barrier
 // per chunk), each wave multiplies its documents' 8 k-values against NQB query blocks (4 NQB MFMAs) and keeps NQB accumulator tiles.
 // Per (query, document) the MFMA sequence -- operands and order -- is the one of the kernel above: the same bits.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {      // v of the lane the DPP control names (all rows and banks enabled)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
 constexpr int SIMW_QS = 288;       // floats per k-row of the LDS chunk: 256 queries + 32, so that the two half-waves (k, k + 1) use different banks
 template <int NQB>
 __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __restrict__ tiled, int64_t D, int K, const float* __restrict__ q, int nq,
-                                                            float* __restrict__ out, int64_t out_ld) {
+                                                            float* __restrict__ out, int64_t out_ld, float* __restrict__ part_max) {
+    // part_max (round 4, optional): [gridDim.x][256] -- this workgroup's maximum of every query's products, taken from the accumulators
+    // (the row maximum webui.py:377-380 divides by; a second pass over the 100 MB of stored products took 24 us per 256 queries).  The
+    // consumer takes the maximum over the workgroups: max is exact, so the value is rowmax_kernel's bit for bit.
     __shared__ float qs[2][8][SIMW_QS];
+    __shared__ uint32_t wmax[256];               // float_order_key images; 0 = nothing seen
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 256) wmax[tid] = 0u;               // (published by the first barrier of the first walk)
     const int r = lane & 31, h = lane >> 5;
     const int64_t ntiles = (D + 31) / 32;
     const int KQ = K >> 2;                       // float4 per document row
@@ -512,6 +521,34 @@ __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __rest
                 }
             }
         }
+        if (part_max) {                          // uniform
+            // Row maxima out of the accumulators (stored above, so the registers are free): the 32 documents of a half-wave share the
+            // query.  Per value five DPP steps on the ORDER KEY -- unsigned max fuses with the DPP move into one v_max_u32_dpp: within
+            // the quad, the half row, the row of 16, then row_bcast15 hands row 0's result to row 1 (rows 1 and 3 enabled) -- and no LDS
+            // instruction at all; lanes 16 and 48 then hold the half-waves' maxima and add them to the workgroup's table with LDS
+            // atomics issued back to back under ONE branch.  (Measured against the 24.6 us of the second pass this replaces: five
+            // __shfl_xor per value +53 us on the kernel, float DPP steps + a swizzle +31 us, key DPP steps + a swizzle +27 us -- every
+            // swizzle / shuffle is an LDS round trip the next value's waits for.)
+            const bool live = tv && doc < D;     // padding documents of the last tile and idle waves do not take part
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {       // sixteen values at a time: 128 keys beside the accumulators spilled
+                uint32_t kv[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    uint32_t k = live ? float_order_key(acc[b][reg]) : 0u;
+                    k = max(k, dpp_u32<0xB1>(k));       // quad_perm [1, 0, 3, 2]
+                    k = max(k, dpp_u32<0x4E>(k));       // quad_perm [2, 3, 0, 1]
+                    k = max(k, dpp_u32<0x141>(k));      // row_half_mirror
+                    k = max(k, dpp_u32<0x140>(k));      // row_mirror
+                    k = max(k, (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x142, 0xA, 0xF, false));      // row_bcast15 into rows 1 and 3
+                    kv[reg] = k;
+                }
+                if (r == 16) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) atomicMax(&wmax[(qb0 + b) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h], kv[reg]);
+                }
+            }
+        }
     };
     // Full rounds: every wave of every workgroup one tile against all NQB blocks.  What is left over (fewer tiles than wave slots) may be
     // split f ways across the query blocks (f waves per tile, NQB / f blocks each) when that shortens the tail.  A walk costs about
@@ -544,6 +581,10 @@ __global__ __launch_bounds__(512) void sim_mfma_wide_kernel(const float4* __rest
             if constexpr (NQB >= 4) { if (f == 4) walk(std::integral_constant<int, NQB / 4>{}, tile, tv, grp * (NQB / 4)); }
             if constexpr (NQB >= 8) { if (f == 8) walk(std::integral_constant<int, NQB / 8>{}, tile, tv, grp * (NQB / 8)); }
         }
+    }
+    if (part_max) {
+        __syncthreads();
+        if (tid < 256) part_max[(int64_t)blockIdx.x * 256 + tid] = wmax[tid] ? float_from_key(wmax[tid]) : -INFINITY;
     }
 }
 
@@ -659,6 +700,8 @@ struct TopkFused {
     float wb = 0.f;
     const double* max_a = nullptr;   // [nq] row maxima (normalise when > 0)
     const float* max_b = nullptr;
+    const float* max_b_parts = nullptr;      // instead of max_b: [query / 256][SIMW_MAX_GRID][256] per-workgroup maxima of sim_mfma_wide_kernel,
+    int parts = 0;                           //   `parts` workgroups each
 };
 
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ vals, int64_t n, int k,
@@ -681,7 +724,24 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ v
     const double* __restrict__ fa = fused ? fz.a + (int64_t)blockIdx.x * n : nullptr;
     const float* __restrict__ fb = fused ? fz.b + (int64_t)blockIdx.x * n : nullptr;
     const double f_ma = fused ? fz.max_a[blockIdx.x] : 0.0;
-    const float f_mb = fused ? fz.max_b[blockIdx.x] : 0.f;
+    float f_mb = 0.f;
+    if (fused) {
+        if (fz.max_b_parts) {        // the maximum over the product kernel's workgroups (exact: the same value rowmax_kernel finds in the stored row)
+            const float* pp = fz.max_b_parts + (int64_t)(blockIdx.x >> 8) * (256 * 256) + (blockIdx.x & 255);
+            float v = tid < fz.parts ? pp[(int64_t)tid * 256] : -INFINITY;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+            __shared__ float pmax[16];
+            if ((tid & 63) == 0) pmax[tid >> 6] = v;
+            __syncthreads();
+            v = pmax[0];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) v = fmaxf(v, pmax[w]);
+            f_mb = v;
+        } else {
+            f_mb = fz.max_b[blockIdx.x];
+        }
+    }
     auto comb = [&](double A, float B) -> double {       // combine_kernel, operation for operation (the file is built with -ffp-contract=off)
         if (f_ma > 0.0) A = A / f_ma;
         if (f_mb > 0.0f) B = B / f_mb;
@@ -1779,6 +1839,11 @@ struct hipts_index {
 
 namespace {
 
+// HIPTS_SIM_PARTS=0: the batched search takes the index products' row maxima with rowmax_kernel again (A/B; default: from the accumulators)
+bool sim_parts_enabled() {
+    static const bool on = !(getenv("HIPTS_SIM_PARTS") && atoi(getenv("HIPTS_SIM_PARTS")) == 0);
+    return on;
+}
 bool sim_wide_enabled() {
     static const bool on = !(getenv("HIPTS_SIM_WIDE") && atoi(getenv("HIPTS_SIM_WIDE")) == 0) && !(getenv("HIPTS_SIM") && strcmp(getenv("HIPTS_SIM"), "rows") == 0);
     return on;
@@ -1794,8 +1859,13 @@ int sim_index_passes(bool tiled, int K, int nq) {
     return passes + (done < nq ? 1 : 0);
 }
 
+// parts / parts_grid (optional): when every query goes through the wide kernel, its per-workgroup row maxima are left in parts
+// ([query group of 256][SIMW_MAX_GRID][256] floats) and *parts_grid says how many workgroups wrote; *parts_grid = 0 otherwise (the caller
+// then runs rowmax_kernel over the stored products as before).
+constexpr int SIMW_MAX_GRID = 256;
 int launch_sim(const float* index, const float* tiled, int64_t D, int K, const float* q_dev, int nq, float* out_dev, int64_t out_ld,
-               hipStream_t s) {
+               hipStream_t s, float* parts = nullptr, int* parts_grid = nullptr) {
+    if (parts_grid) *parts_grid = 0;
     const size_t lds = (size_t)K * 32 * sizeof(float);
     HIPTS_REQUIRE(lds <= 160 * 1024, "index dim %d too large for the query tile in LDS", K);
     static PerDevice attr_set;
@@ -1819,16 +1889,31 @@ int launch_sim(const float* index, const float* tiled, int64_t D, int K, const f
     int q_done = 0;
     if (tiled && use_tiled && use_wide && K % 4 == 0) {
         // up to one workgroup per CU; a small index still fills them: the kernel splits the tiles it has across the query blocks
-        auto grid_for = [&](int nqb) { return (int)std::max<int64_t>(1, std::min<int64_t>((ntiles * nqb + 7) / 8, 256)); };
+        auto grid_for = [&](int nqb) { return (int)std::max<int64_t>(1, std::min<int64_t>((ntiles * nqb + 7) / 8, SIMW_MAX_GRID)); };
+        // the row maxima come out of the accumulators when no query is left for the 32-query kernel below and the groups share a grid
+        bool want_parts = parts && parts_grid && nq > 32;
+        if (want_parts) {
+            int rem = nq, g0 = -1;
+            while (rem > 32) {
+                const int n = std::min(256, rem), g = grid_for(n <= 64 ? 2 : n <= 128 ? 4 : 8);
+                if (g0 >= 0 && g != g0) want_parts = false;
+                g0 = g;
+                rem -= n;
+            }
+            if (rem > 0) want_parts = false;
+        }
         while (nq - q_done > 32) {
             const int n = std::min(256, nq - q_done);
             const float4* t4 = reinterpret_cast<const float4*>(tiled);
             const float* qp = q_dev + (int64_t)q_done * K;
             float* op = out_dev + (int64_t)q_done * out_ld;
-            if (n <= 64) sim_mfma_wide_kernel<2><<<grid_for(2), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
-            else if (n <= 128) sim_mfma_wide_kernel<4><<<grid_for(4), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
-            else sim_mfma_wide_kernel<8><<<grid_for(8), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld);
+            float* pm = want_parts ? parts + (int64_t)(q_done / 256) * SIMW_MAX_GRID * 256 : nullptr;
+            const int nqb = n <= 64 ? 2 : n <= 128 ? 4 : 8;
+            if (nqb == 2) sim_mfma_wide_kernel<2><<<grid_for(2), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld, pm);
+            else if (nqb == 4) sim_mfma_wide_kernel<4><<<grid_for(4), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld, pm);
+            else sim_mfma_wide_kernel<8><<<grid_for(8), 512, 0, s>>>(t4, D, K, qp, n, op, out_ld, pm);
             HIPTS_LAUNCH_CHECK();
+            if (want_parts) *parts_grid = grid_for(nqb);
             q_done += n;
         }
     }
@@ -2527,6 +2612,7 @@ static int search_submit_impl(hipts_bm25_t* bm25, hipts_index_t* index, const in
     // way -- side by side BM25 takes 234-336 us instead of 156-167 and the product 262-363 instead of 233: both fill the wave slots of
     // every CU, so they take turns rather than share.  One stream stays the default.
     static const bool overlap = getenv("HIPTS_SEARCH_OVERLAP") && atoi(getenv("HIPTS_SEARCH_OVERLAP")) != 0;
+    int parts_grid = 0;          // > 0: the index product left per-workgroup row maxima in ws_parts
     hipStream_t sb = s;
     if (overlap) {
         if (!bm25->side) {
@@ -2550,9 +2636,11 @@ static int search_submit_impl(hipts_bm25_t* bm25, hipts_index_t* index, const in
     if (overlap) HIPTS_HIP(hipEventRecord(bm25->ev_bm25, sb));
     {
         QueryProfScope ps(bm25, s, QP_SIM, (double)sim_index_passes(index->tiled.p != nullptr, index->dim, nq) * D * index->dim * 4.0 + (double)nq * D * 4.0);
-        HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s));
+        if (fused && sim_parts_enabled()) HIPTS_TRY(bm25->ws_parts.reserve((size_t)((nq + 255) / 256) * SIMW_MAX_GRID * 256 * sizeof(float)));
+        HIPTS_TRY(launch_sim(index->rows.as<float>(), index->tiled.as<float>(), D, index->dim, qvec, nq, bm25->ws_sims.as<float>(), D, s,
+                             fused && sim_parts_enabled() ? bm25->ws_parts.as<float>() : nullptr, &parts_grid));
     }
-    {
+    if (parts_grid == 0) {       // (otherwise the maxima came out of the product kernel's accumulators: the top-k kernel reduces its workgroups' values)
         QueryProfScope ps(bm25, s, QP_ROWMAX, (double)nq * D * 4.0);
         rowmax_kernel<float><<<nq, 1024, 0, s>>>(bm25->ws_sims.as<float>(), D, mb);
         HIPTS_LAUNCH_CHECK();
@@ -2582,6 +2670,11 @@ static int search_submit_impl(hipts_bm25_t* bm25, hipts_index_t* index, const in
             fz.wb = (float)w_sim;
             fz.max_a = ma;
             fz.max_b = mb;
+            if (parts_grid > 0) {
+                fz.max_b = nullptr;
+                fz.max_b_parts = bm25->ws_parts.as<float>();
+                fz.parts = parts_grid;
+            }
             topk_kernel<<<nq, 1024, 0, s>>>(nullptr, D, kk, oi, ov, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0u, S1_BLOCK_CAP, fz);
         } else {
             topk_kernel<<<nq, 1024, 0, s>>>(final_dev, D, kk, oi, ov);
