@@ -308,14 +308,15 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                             for (int h = 0; h < k->h; ++h) {
                                 int16_t* out = coef + k->offset + ((int64_t)(my * k->v + v) * k->blocks_w + (mx * k->h + h)) * 64;
                                 int16_t* blk = local;
-                                for (int z = 0; z < 10; ++z) _mm_store_si128((__m128i*)local + z, _mm_setzero_si128());
+                                for (int z = 0; z < 8; ++z) _mm_store_si128((__m128i*)local + z, _mm_setzero_si128());
                                 refill(&br);
                                 int s = huff_decode(&br, hdc);
                                 if (s < 0 || s > 15) return JH_CORRUPT;
                                 if (s) pred[c] += receive_extend(&br, s);
                                 if (pred[c] < -32768 || pred[c] > 32767) return JH_CORRUPT;
                                 blk[0] = (int16_t)pred[c];
-                                for (int kk = 1; kk < 64;) {
+                                int kk = 1;
+                                while (kk < 64) {
                                     refill(&br);
                                     const int f = hac->fast[br.bits >> (64 - LOOK)];
                                     if (f) { /* run, code and magnitude bits in one lookup */
@@ -337,13 +338,10 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                                     kk += r;
                                     blk[ZIGZAG[kk]] = (int16_t)receive_extend(&br, s);
                                     ++kk;
-                                    if (kk > 64) return JH_CORRUPT; /* (kk <= 79 here: the spare row took the store) */
                                 }
-                                {
-                                    int spill = 0;
-                                    for (int z = 64; z < 80; ++z) spill |= local[z];
-                                    if (spill) return JH_CORRUPT; /* a coefficient beyond position 63 */
-                                }
+                                /* a run that overshoots position 63 (kk <= 79: the spare row took any store).  libjpeg reads on
+                                 * silently; here the file goes to Pillow, i.e. to libjpeg itself */
+                                if (kk > 64) return JH_CORRUPT;
                                 for (int z = 0; z < 8; ++z) _mm_stream_si128((__m128i*)out + z, _mm_load_si128((const __m128i*)local + z));
                             }
                     }
