@@ -79,10 +79,12 @@ __device__ __forceinline__ void idct_1d(int (&d)[8]) {
     d[4] = (tmp13 - tmp0 + R) >> SHIFT;
 }
 
-// sample_range_limit + CENTERJSAMPLE indexed with x & RANGE_MASK (jdmaster.c prepare_range_limit_table)
+// the sample of a descaled pass-2 value: + CENTERJSAMPLE, limited to 0..255.  (jidctint.c indexes sample_range_limit with x & RANGE_MASK,
+// which wraps beyond +-512; libjpeg-turbo's SIMD code -- what Pillow runs -- saturates.  The host half only lets blocks through whose values
+// stay far inside both, jpeg_host.c COLSUM_LIMIT; saturation is the form taken here.)
 __device__ __forceinline__ unsigned range_limit(int x) {
-    const int i = x & 1023;
-    return (unsigned)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
+    x += 128;
+    return (unsigned)(x < 0 ? 0 : x > 255 ? 255 : x);
 }
 
 // 32 blocks per workgroup, eight lanes per block: lane c runs column c of pass 1, then row c of pass 2 (the workspace goes through LDS,

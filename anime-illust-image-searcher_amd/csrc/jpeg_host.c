@@ -6,13 +6,21 @@
  * jdhuff.c read when the reference calls PIL's Image.open (tagging.py:234-252).  Anything this file does not handle -- progressive or
  * arithmetic coding, 12-bit samples, CMYK / RGB-coded files, sampling other than 4:4:4 / 4:2:2 / 4:2:0, several scans, tiny images --
  * and any irregularity in the stream is reported (status 1 or 3) and the caller decodes that file with Pillow as before: the fast
- * path never has to guess what libjpeg's error recovery would have produced. */
+ * path never has to guess what libjpeg's error recovery would have produced.
+ *
+ * That includes streams that parse but carry coefficients no 8-bit image produces (flipped bits): libjpeg-turbo's SIMD inverse DCT works on
+ * 16-bit lanes (wrapping products and sums, saturating packs) where the C code and the device kernel compute in 32 bits, so beyond the
+ * range of real data the two differ.  Per block and coefficient column the sum of |coefficient x quantiser| is held to COLSUM_LIMIT:
+ * below it no 16-bit lane of either pass can wrap or saturate (pass 1 scales a column by at most 4 sqrt 8 / 2 = 5.66, pass 2 adds two such
+ * values), so 16-bit and 32-bit arithmetic agree; an 8 x 8 block of 8-bit samples cannot exceed sqrt 8 x 1024 = 2896 (Parseval).  A block
+ * above the limit sends the file to Pillow. */
 #include <emmintrin.h> /* SSE2: part of the x86-64 baseline */
 #include <string.h>
 
 #include "jpeg_slot.h"
 
 enum { JH_OK = 0, JH_UNSUPPORTED = 1, JH_TOO_SMALL = 2, JH_CORRUPT = 3 };
+enum { COLSUM_LIMIT = 2850 };
 
 /* zigzag position -> natural index; positions 64..79 (a run that overshoots the block: an irregular stream, detected after the block)
  * land in a spare row of the local block buffer */
@@ -308,6 +316,8 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                             for (int h = 0; h < k->h; ++h) {
                                 int16_t* out = coef + k->offset + ((int64_t)(my * k->v + v) * k->blocks_w + (mx * k->h + h)) * 64;
                                 int16_t* blk = local;
+                                const uint16_t* qn = hd->quant[c];
+                                int colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                                 for (int z = 0; z < 8; ++z) _mm_store_si128((__m128i*)local + z, _mm_setzero_si128());
                                 refill(&br);
                                 int s = huff_decode(&br, hdc);
@@ -315,6 +325,7 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                                 if (s) pred[c] += receive_extend(&br, s);
                                 if (pred[c] < -32768 || pred[c] > 32767) return JH_CORRUPT;
                                 blk[0] = (int16_t)pred[c];
+                                colsum[0] = (pred[c] < 0 ? -pred[c] : pred[c]) * qn[0];
                                 int kk = 1;
                                 while (kk < 64) {
                                     refill(&br);
@@ -323,7 +334,9 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                                         kk += (f >> 4) & 15;
                                         br.bits <<= (f & 15);
                                         br.nbits -= (f & 15);
-                                        blk[ZIGZAG[kk++]] = (int16_t)(f >> 8);
+                                        const int nat = ZIGZAG[kk++], v = f >> 8;
+                                        blk[nat] = (int16_t)v;
+                                        colsum[nat & 7] += (v < 0 ? -v : v) * qn[nat & 63];
                                         continue;
                                     }
                                     const int rs = huff_decode(&br, hac);
@@ -336,12 +349,21 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                                         continue;
                                     }
                                     kk += r;
-                                    blk[ZIGZAG[kk]] = (int16_t)receive_extend(&br, s);
+                                    const int nat = ZIGZAG[kk], v = receive_extend(&br, s);
+                                    blk[nat] = (int16_t)v;
+                                    colsum[nat & 7] += (v < 0 ? -v : v) * qn[nat & 63];
                                     ++kk;
                                 }
                                 /* a run that overshoots position 63 (kk <= 79: the spare row took any store).  libjpeg reads on
                                  * silently; here the file goes to Pillow, i.e. to libjpeg itself */
                                 if (kk > 64) return JH_CORRUPT;
+                                {
+                                    int m01 = colsum[0] > colsum[1] ? colsum[0] : colsum[1], m23 = colsum[2] > colsum[3] ? colsum[2] : colsum[3];
+                                    int m45 = colsum[4] > colsum[5] ? colsum[4] : colsum[5], m67 = colsum[6] > colsum[7] ? colsum[6] : colsum[7];
+                                    m01 = m01 > m23 ? m01 : m23;
+                                    m45 = m45 > m67 ? m45 : m67;
+                                    if ((m01 > m45 ? m01 : m45) > COLSUM_LIMIT) return JH_CORRUPT; /* beyond any 8-bit image: Pillow's business */
+                                }
                                 for (int z = 0; z < 8; ++z) _mm_stream_si128((__m128i*)out + z, _mm_load_si128((const __m128i*)local + z));
                             }
                     }

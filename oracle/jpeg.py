@@ -71,9 +71,10 @@ def _idct_1d(d, shift):
 
 
 def _range_limit(x):
-    """sample_range_limit + CENTERJSAMPLE indexed with x & RANGE_MASK (jdmaster.c prepare_range_limit_table)."""
-    i = x & 1023
-    return np.where(i < 128, i + 128, np.where(i < 512, 255, np.where(i < 896, 0, i - 896))).astype(np.uint8)
+    """+ CENTERJSAMPLE, limited to 0..255: the saturating form of libjpeg-turbo's SIMD code (what Pillow runs); jidctint.c's
+    sample_range_limit[x & RANGE_MASK] agrees for |x| < 512, and the host half (csrc/jpeg_host.c COLSUM_LIMIT) lets no block through whose
+    values come near either limit or near the 16-bit lanes of the SIMD passes."""
+    return np.clip(x + 128, 0, 255).astype(np.uint8)
 
 
 def idct_islow(coef: np.ndarray, quant: np.ndarray) -> np.ndarray:

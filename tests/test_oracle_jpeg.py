@@ -110,3 +110,82 @@ def test_files_outside_the_fast_path_are_refused():
     i = broken.index(b"\xff\xd3")
     broken[i + 1] = 0xD5                                                                            # restart markers out of sequence
     assert entropy_decode(lib, bytes(broken), slot_bytes=lib.hipts_jpeg_slot_bytes(160, 120))[0] == 3
+
+
+def test_mutated_files_never_crash_the_entropy_decoder():
+    """Byte flips, truncations and spliced garbage: the host half returns one of its four statuses and writes inside its slot (a guard
+    band behind the slot stays untouched).  Run in a child process so that a crash would be a test failure, not the end of the run."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, io, sys
+import numpy as np
+sys.path.insert(0, %r)
+from test_oracle_jpeg import host_lib, synth_image, jpeg_bytes
+lib = host_lib()
+rng = np.random.default_rng(11)
+seeds = [jpeg_bytes(synth_image(rng, 120, 152), quality=q, subsampling=s, **kw) for q, s, kw in
+         [(85, 2, {}), (60, 1, {}), (95, 0, {"optimize": True}), (80, 2, {"restart_marker_blocks": 3})]]
+nb = int(lib.hipts_jpeg_slot_bytes(152, 120))
+guard = 4096
+buf = np.zeros(nb + guard, dtype=np.uint8)
+counts = {0: 0, 1: 0, 2: 0, 3: 0}
+for it in range(3000):
+    d = bytearray(seeds[it %% len(seeds)])
+    kind = it %% 5
+    if kind == 0:
+        for _ in range(int(rng.integers(1, 6))):
+            d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
+    elif kind == 1:
+        d = d[:int(rng.integers(4, len(d)))]
+    elif kind == 2:
+        i = int(rng.integers(2, len(d)))
+        d[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+    elif kind == 3:
+        i = int(rng.integers(2, len(d) - 8))
+        del d[i:i + int(rng.integers(1, 8))]
+    else:
+        i = int(rng.integers(2, len(d) - 2))
+        d[i] = 0xFF
+        d[i + 1] = int(rng.integers(0xC0, 0xFF))
+    buf[nb:] = 0xA5
+    src = np.frombuffer(bytes(d), dtype=np.uint8)
+    st = lib.hipts_jpeg_entropy_decode(src.ctypes.data, len(src), buf.ctypes.data, nb)
+    assert st in counts, st
+    counts[st] += 1
+    assert (buf[nb:] == 0xA5).all(), "wrote behind the slot"
+print(counts)
+assert counts[0] > 0 and counts[3] > 0
+''' % os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_every_accepted_mutated_stream_still_equals_pillow():
+    """Flipped bytes inside the entropy-coded segment often leave a stream that parses: what the host half ACCEPTS must still decode to
+    Pillow's bytes.  libjpeg-turbo's SIMD inverse DCT (16-bit lanes) and 32-bit arithmetic part ways on coefficients no real image has;
+    the host half refuses such blocks (COLSUM_LIMIT), the rest of the corrupted-but-plausible streams must match exactly."""
+    import warnings
+    from oracle import jpeg as oj
+    lib = host_lib()
+    rng = np.random.default_rng(12)
+    seeds = [jpeg_bytes(synth_image(rng, 120, 152), quality=q, subsampling=s, **kw) for q, s, kw in
+             [(85, 2, {}), (60, 1, {}), (95, 0, {"optimize": True}), (80, 2, {"restart_marker_blocks": 3})]]
+    nb = int(lib.hipts_jpeg_slot_bytes(152, 120))
+    accepted = refused = 0
+    for it in range(1200):
+        d = bytearray(seeds[it % 4])
+        start = d.index(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 4))):
+            d[int(rng.integers(start, len(d) - 2))] = int(rng.integers(0, 256))
+        data = bytes(d)
+        st, slot = entropy_decode(lib, data, slot_bytes=nb)
+        if st != 0:
+            refused += 1
+            continue
+        accepted += 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        assert np.array_equal(oj.decode_slot(slot), want), it
+    assert accepted > 200 and refused > 200, (accepted, refused)
