@@ -597,6 +597,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                             const f32x4 bj = cvec[256 + j * 4 + lq];
                             if constexpr (fold) acc[i2 + u][j] = xv[cur][u][j] + (acc[i2 + u][j] * st.x + (bj - cvec[512 + j * 4 + lq] * st.y));
                             else acc[i2 + u][j] = xv[cur][u][j] + (acc[i2 + u][j] + bj);
+                            // (non-temporal loads / loads and stores of this stream, __builtin_nontemporal_*: 5277 / 5256-5294 images/s against
+                            // 5294-5324 with the default policy on one box -- no gain, not kept)
                             *reinterpret_cast<f32x4*>(base + (size_t)(i2 + u) * 16 * ld + lane_off + j * 16) = acc[i2 + u][j];
                         }
                     }
