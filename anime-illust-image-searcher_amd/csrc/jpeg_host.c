@@ -1,12 +1,13 @@
-/* Host half of the hybrid JPEG decode (see jpeg_slot.h): marker parsing and Huffman entropy decoding of a baseline or
- * extended-sequential 8-bit JPEG into quantised DCT coefficient blocks.  Plain C, no GPU runtime: built into libhipts_jpeg_host.so,
- * which the decode worker processes of hiptagsearch/pipeline.py load (a worker must never initialise the GPU).
+/* Host half of the hybrid JPEG decode (see jpeg_slot.h): marker parsing and Huffman entropy decoding of a baseline, extended-sequential
+ * or progressive 8-bit JPEG into quantised DCT coefficient blocks.  Plain C, no GPU runtime: built into libhipts_jpeg_host.so, which the
+ * decode worker processes of hiptagsearch/pipeline.py load (a worker must never initialise the GPU).
  *
- * What it follows: ITU-T T.81 (markers B.2, Huffman procedures F.2.2 / Annex C) -- the same stream libjpeg-turbo's jdmarker.c /
- * jdhuff.c read when the reference calls PIL's Image.open (tagging.py:234-252).  Anything this file does not handle -- progressive or
- * arithmetic coding, 12-bit samples, CMYK / RGB-coded files, sampling other than 4:4:4 / 4:2:2 / 4:2:0, several scans, tiny images --
- * and any irregularity in the stream is reported (status 1 or 3) and the caller decodes that file with Pillow as before: the fast
- * path never has to guess what libjpeg's error recovery would have produced.
+ * What it follows: ITU-T T.81 (markers B.2, Huffman procedures F.2.2 / Annex C, progressive mode Annex G) -- the same stream
+ * libjpeg-turbo's jdmarker.c / jdhuff.c / jdphuff.c read when the reference calls PIL's Image.open (tagging.py:234-252).  Anything this
+ * file does not handle -- arithmetic coding, progressions that leave a coefficient out or below full precision, 12-bit samples,
+ * CMYK / RGB-coded files, sampling other than 4:4:4 / 4:2:2 / 4:2:0, sequential files in several scans, tiny images -- and any
+ * irregularity in the stream is reported (status 1 or 3) and the caller decodes that file with Pillow as before: the fast path never
+ * has to guess what libjpeg's error recovery would have produced.
  *
  * That includes streams that parse but carry coefficients no 8-bit image produces (flipped bits): libjpeg-turbo's SIMD inverse DCT works on
  * 16-bit lanes (wrapping products and sums, saturating packs) where the C code and the device kernel compute in 32 bits, so beyond the
@@ -154,6 +155,216 @@ static inline int receive_extend(BitReader* b, int s) {
 
 static inline unsigned be16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
 
+/* n raw bits (1..16); the caller has refilled */
+static inline int receive(BitReader* b, int n) {
+    const int v = (int)(b->bits >> (64 - n));
+    b->bits <<= n;
+    b->nbits -= n;
+    return v;
+}
+
+/* The bits of an interval are used up (but for the padding of its last byte) and marker 0xFF `want` follows (want < 0: any marker: the
+ * reader is left ON it).  The reader stays on a marker's 0xFF once it has met it; before that it points at the next unread byte. */
+static int at_marker(BitReader* br, int want) {
+    if (br->fake > br->nbits) return JH_CORRUPT;          /* read past the end of the data */
+    if ((br->nbits - br->fake) >= 8) return JH_CORRUPT;   /* whole unread data bytes in front of the marker */
+    const uint8_t* q = br->p;
+    if (q + 2 > br->end || q[0] != 0xFF) return JH_CORRUPT;
+    while (q + 1 < br->end && q[1] == 0xFF) ++q;
+    if (q + 2 > br->end) return JH_CORRUPT;
+    if (want >= 0) {
+        if (q[1] != want) return JH_CORRUPT;
+        br->p = q + 2;
+    } else {
+        if (q[1] == 0) return JH_CORRUPT;
+        br->p = q;
+    }
+    br->bits = 0;
+    br->nbits = 0;
+    br->fake = 0;
+    return JH_OK;
+}
+
+/* ---- progressive mode (T.81 Annex G; the procedures of libjpeg's jdphuff.c): one scan = one band of coefficients (Ss..Se) at one
+ * precision (successive approximation Ah -> Al) of one component, or the DC coefficients of several.  The scans accumulate into the same
+ * coefficient blocks the baseline path fills; when every coefficient of every component has arrived at full precision the blocks are what
+ * a baseline file of the same image would carry, and libjpeg applies no block smoothing (jdcoefct.c smoothing_ok). */
+typedef struct {
+    const hipts_jpeg_header* hd;
+    int16_t* coef;
+    int restart;
+    int coef_bits[3][64]; /* -1: not seen yet; else the Al of the last scan that carried the coefficient */
+} Prog;
+
+static inline int getbit(BitReader* br) {
+    refill(br);
+    return receive(br, 1);
+}
+
+static int prog_scan(Prog* P, BitReader* br, int ns, const int* sc, const Huff* const* hdc, const Huff* const* hac, int Ss, int Se, int Ah, int Al) {
+    const hipts_jpeg_header* hd = P->hd;
+    /* jdphuff.c start_pass_phuff_decoder: what a legal progression may ask for */
+    if (Ss == 0) {
+        if (Se != 0) return JH_CORRUPT;
+    } else {
+        if (ns != 1 || Se < Ss || Se > 63) return JH_CORRUPT;
+    }
+    if (Al > 13 || (Ah != 0 && Ah != Al + 1)) return JH_CORRUPT;
+    for (int i = 0; i < ns; ++i) {
+        int* cb = P->coef_bits[sc[i]];
+        if (Ss > 0 && cb[0] < 0) return JH_CORRUPT; /* AC before DC */
+        for (int k = Ss; k <= Se; ++k) {
+            const int expected = cb[k] < 0 ? 0 : cb[k];
+            if (Ah != expected) return JH_CORRUPT; /* libjpeg warns and decodes on; here: Pillow's business */
+            cb[k] = Al;
+        }
+        if (Ss == 0 ? !hdc[i] && Ah == 0 : !hac[i]) return JH_CORRUPT;
+    }
+    const int hmax = hd->hmax, vmax = hd->vmax;
+    int nx, ny; /* MCUs of the scan */
+    if (ns == 1) {
+        nx = (hd->comp[sc[0]].dw + 7) / 8;
+        ny = (hd->comp[sc[0]].dh + 7) / 8;
+    } else {
+        nx = (hd->width + 8 * hmax - 1) / (8 * hmax);
+        ny = (hd->height + 8 * vmax - 1) / (8 * vmax);
+    }
+    int pred[3] = {0, 0, 0}, eobrun = 0, until_restart = P->restart, next_rst = 0;
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    for (int my = 0; my < ny; ++my)
+        for (int mx = 0; mx < nx; ++mx) {
+            if (P->restart && until_restart == 0) {
+                if (at_marker(br, 0xD0 + next_rst) != JH_OK) return JH_CORRUPT;
+                next_rst = (next_rst + 1) & 7;
+                pred[0] = pred[1] = pred[2] = 0;
+                eobrun = 0;
+                until_restart = P->restart;
+            }
+            for (int i = 0; i < ns; ++i) {
+                const hipts_jpeg_component* k = &hd->comp[sc[i]];
+                const int bh = ns == 1 ? 1 : k->h, bv = ns == 1 ? 1 : k->v;
+                for (int v = 0; v < bv; ++v)
+                    for (int h = 0; h < bh; ++h) {
+                        int16_t* blk = P->coef + k->offset + ((int64_t)(my * bv + v) * k->blocks_w + (mx * bh + h)) * 64;
+                        if (Ss == 0) {
+                            if (Ah == 0) { /* DC, first pass */
+                                refill(br);
+                                const int s = huff_decode(br, hdc[i]);
+                                if (s < 0 || s > 15) return JH_CORRUPT;
+                                if (s) pred[i] += receive_extend(br, s);
+                                const int val = pred[i] * p1;
+                                if (val < -32768 || val > 32767) return JH_CORRUPT;
+                                blk[0] = (int16_t)val;
+                            } else if (getbit(br)) { /* DC, one more bit */
+                                blk[0] = (int16_t)(blk[0] | p1);
+                            }
+                        } else if (Ah == 0) { /* AC band, first pass */
+                            if (eobrun > 0) {
+                                --eobrun;
+                                continue;
+                            }
+                            for (int kk = Ss; kk <= Se; ++kk) {
+                                refill(br);
+                                const int f = hac[i]->fast[br->bits >> (64 - LOOK)];
+                                if (f) { /* run, code and magnitude bits in one lookup (as in the sequential path) */
+                                    kk += (f >> 4) & 15;
+                                    if (kk > Se) return JH_CORRUPT;
+                                    br->bits <<= (f & 15);
+                                    br->nbits -= (f & 15);
+                                    const int val = (f >> 8) * p1;
+                                    if (val < -32768 || val > 32767) return JH_CORRUPT;
+                                    blk[ZIGZAG[kk]] = (int16_t)val;
+                                    continue;
+                                }
+                                const int rs = huff_decode(br, hac[i]);
+                                if (rs < 0) return JH_CORRUPT;
+                                const int r = rs >> 4, s = rs & 15;
+                                if (s) {
+                                    kk += r;
+                                    if (kk > Se) return JH_CORRUPT;
+                                    const int val = receive_extend(br, s) * p1;
+                                    if (val < -32768 || val > 32767) return JH_CORRUPT;
+                                    blk[ZIGZAG[kk]] = (int16_t)val;
+                                } else if (r == 15) {
+                                    kk += 15;
+                                } else {
+                                    eobrun = 1 << r;
+                                    if (r) eobrun += receive(br, r);
+                                    --eobrun; /* this block is the first of the run */
+                                    break;
+                                }
+                            }
+                        } else { /* AC band, refinement (jdphuff.c decode_mcu_AC_refine) */
+                            int kk = Ss;
+                            if (eobrun == 0) {
+                                for (; kk <= Se; ++kk) {
+                                    refill(br);
+                                    const int rs = huff_decode(br, hac[i]);
+                                    if (rs < 0) return JH_CORRUPT;
+                                    int r = rs >> 4, s = rs & 15;
+                                    if (s) {
+                                        if (s != 1) return JH_CORRUPT;
+                                        s = getbit(br) ? p1 : m1;
+                                    } else if (r != 15) {
+                                        eobrun = 1 << r;
+                                        if (r) {
+                                            refill(br);
+                                            eobrun += receive(br, r);
+                                        }
+                                        break; /* the rest of the band is handled below */
+                                    }
+                                    /* past r still-zero coefficients, correcting the non-zero ones on the way */
+                                    do {
+                                        int16_t* c = blk + ZIGZAG[kk];
+                                        if (*c != 0) {
+                                            if (getbit(br) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                                        } else if (--r < 0) {
+                                            break;
+                                        }
+                                        ++kk;
+                                    } while (kk <= Se);
+                                    if (s) {
+                                        if (kk > Se) return JH_CORRUPT;
+                                        blk[ZIGZAG[kk]] = (int16_t)s;
+                                    }
+                                }
+                            }
+                            if (eobrun > 0) {
+                                for (; kk <= Se; ++kk) {
+                                    int16_t* c = blk + ZIGZAG[kk];
+                                    if (*c != 0 && getbit(br) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                                }
+                                --eobrun;
+                            }
+                        }
+                    }
+            }
+            if (br->fake > br->nbits) return JH_CORRUPT;
+            if (P->restart) --until_restart;
+        }
+    return at_marker(br, -1); /* the next marker follows the scan's last byte */
+}
+
+/* every block's per-column sum of |coefficient x quantiser| against COLSUM_LIMIT (the baseline path checks while it decodes) */
+static int prog_check_range(const hipts_jpeg_header* hd, const int16_t* coef) {
+    for (int c = 0; c < hd->ncomp; ++c) {
+        const hipts_jpeg_component* k = &hd->comp[c];
+        const uint16_t* q = hd->quant[c];
+        const int16_t* b = coef + k->offset;
+        for (int64_t i = 0, nb = (int64_t)k->blocks_w * k->blocks_h; i < nb; ++i, b += 64) {
+            int cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < 8; ++r)
+                for (int x = 0; x < 8; ++x) {
+                    const int v = b[r * 8 + x];
+                    cs[x] += (v < 0 ? -v : v) * q[r * 8 + x];
+                }
+            for (int x = 0; x < 8; ++x)
+                if (cs[x] > COLSUM_LIMIT) return JH_CORRUPT;
+        }
+    }
+    return JH_OK;
+}
+
 int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_t slot_bytes) {
     if (!data || !slot || n < 4 || slot_bytes < HIPTS_JPEG_HEADER_BYTES) return JH_TOO_SMALL;
     if (data[0] != 0xFF || data[1] != 0xD8) return JH_UNSUPPORTED;
@@ -162,15 +373,25 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
     static _Thread_local Huff dc[4], ac[4];
     for (int i = 0; i < 4; ++i) dc[i].present = ac[i].present = 0;
     int width = 0, height = 0, ncomp = 0, have_sof = 0, restart = 0, saw_jfif = 0, saw_adobe = 0, adobe_transform = 0;
+    int progressive = 0, prog_started = 0;
+    static _Thread_local Prog P;
     int cid[3] = {0, 0, 0}, ch[3] = {1, 1, 1}, cv[3] = {1, 1, 1}, ctq[3] = {0, 0, 0};
     int64_t pos = 2;
     for (;;) {
-        if (pos + 4 > n) return JH_CORRUPT;
+        if (pos + 2 > n) return JH_CORRUPT;
         if (data[pos] != 0xFF) return JH_CORRUPT;
         while (pos < n && data[pos] == 0xFF) ++pos; /* fill bytes */
         if (pos >= n) return JH_CORRUPT;
         const int m = data[pos++];
         if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD9 && progressive && prog_started) {
+            /* end of a progressive file: complete only if every coefficient of every component arrived at full precision -- otherwise
+             * libjpeg smooths the blocks with what it has (jdcoefct.c decompress_smooth_data): Pillow's business */
+            for (int c = 0; c < ncomp; ++c)
+                for (int k = 0; k < 64; ++k)
+                    if (P.coef_bits[c][k] != 0) return JH_UNSUPPORTED;
+            return prog_check_range(P.hd, P.coef);
+        }
         if (m == 0xD8 || m == 0xD9 || m == 0x00) return JH_CORRUPT;
         if (pos + 2 > n) return JH_CORRUPT;
         const int len = (int)be16(data + pos);
@@ -186,8 +407,9 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                 seg += 1 + 64 * (pq + 1);
                 sl -= 1 + 64 * (pq + 1);
             }
-        } else if (m == 0xC0 || m == 0xC1) {
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             if (have_sof || sl < 6) return JH_CORRUPT;
+            progressive = m == 0xC2;
             if (seg[0] != 8) return JH_UNSUPPORTED;
             height = (int)be16(seg + 1);
             width = (int)be16(seg + 3);
@@ -202,8 +424,8 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                 if (ctq[c] > 3 || ch[c] < 1 || cv[c] < 1) return JH_CORRUPT;
             }
             have_sof = 1;
-        } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            return JH_UNSUPPORTED; /* progressive, lossless, arithmetic, hierarchical */
+        } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return JH_UNSUPPORTED; /* lossless, arithmetic, hierarchical */
         } else if (m == 0xCC) {
             return JH_UNSUPPORTED;
         } else if (m == 0xC4) {
@@ -230,18 +452,40 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
         } else if (m == 0xDA) {
             if (!have_sof || sl < 1) return JH_CORRUPT;
             const int ns = seg[0];
-            if (ns != ncomp) return JH_UNSUPPORTED; /* several scans */
+            if (ns < 1 || ns > ncomp) return progressive ? JH_CORRUPT : JH_UNSUPPORTED;
+            if (!progressive && ns != ncomp) return JH_UNSUPPORTED; /* a sequential file in several scans */
             if (sl < 1 + 2 * ns + 3) return JH_CORRUPT;
-            int tdc[3], tac[3];
+            int tdc[3], tac[3], sc[3];
             for (int c = 0; c < ns; ++c) {
-                if (seg[1 + 2 * c] != cid[c]) return JH_UNSUPPORTED;
+                sc[c] = -1;
+                for (int j = 0; j < ncomp; ++j)
+                    if (seg[1 + 2 * c] == cid[j]) sc[c] = j;
+                if (sc[c] < 0 || (c > 0 && sc[c] <= sc[c - 1])) return JH_CORRUPT; /* T.81 B.2.3: in frame order */
+                if (!progressive && sc[c] != c) return JH_UNSUPPORTED;
                 tdc[c] = seg[2 + 2 * c] >> 4;
                 tac[c] = seg[2 + 2 * c] & 15;
-                if (tdc[c] > 3 || tac[c] > 3 || !dc[tdc[c]].present || !ac[tac[c]].present) return JH_CORRUPT;
-                if (!qt_present[ctq[c]]) return JH_CORRUPT;
+                if (tdc[c] > 3 || tac[c] > 3) return JH_CORRUPT;
+                if (!progressive && (!dc[tdc[c]].present || !ac[tac[c]].present)) return JH_CORRUPT;
+                if (!qt_present[ctq[sc[c]]]) return JH_CORRUPT;
             }
-            if (seg[1 + 2 * ns] != 0 || seg[2 + 2 * ns] != 63 || seg[3 + 2 * ns] != 0) return JH_UNSUPPORTED;
+            const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
+            if (!progressive && (Ss != 0 || Se != 63 || Ah != 0 || Al != 0)) return JH_UNSUPPORTED;
             pos += len;
+            if (progressive && prog_started) {
+                /* a further scan of a progressive file */
+                const Huff* hdcp[3];
+                const Huff* hacp[3];
+                for (int c = 0; c < ns; ++c) {
+                    hdcp[c] = dc[tdc[c]].present ? &dc[tdc[c]] : 0;
+                    hacp[c] = ac[tac[c]].present ? &ac[tac[c]] : 0;
+                }
+                P.restart = restart;
+                BitReader pbr = {data + pos, data + n, 0, 0, 0};
+                const int st = prog_scan(&P, &pbr, ns, sc, hdcp, hacp, Ss, Se, Ah, Al);
+                if (st != JH_OK) return st;
+                pos = pbr.p - data;
+                continue;
+            }
             /* ---- colour model and sampling, by libjpeg's rules (jdapimin.c default_decompress_parms) */
             if (width < 16 || height < 16) return JH_UNSUPPORTED; /* (jdsample.c leaves the fancy upsampling below 3 chroma columns) */
             if (ncomp == 3) {
@@ -283,6 +527,27 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
             hd->total_bytes = HIPTS_JPEG_HEADER_BYTES + off * 2;
             if (hd->total_bytes > slot_bytes) return JH_TOO_SMALL;
             int16_t* coef = (int16_t*)((char*)slot + HIPTS_JPEG_HEADER_BYTES);
+            if (progressive) {
+                /* the first scan of a progressive file: the blocks accumulate over the scans, so they start from zero */
+                memset(coef, 0, (size_t)off * 2);
+                P.hd = hd;
+                P.coef = coef;
+                P.restart = restart;
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 64; ++k) P.coef_bits[c][k] = -1;
+                prog_started = 1;
+                const Huff* hdcp[3];
+                const Huff* hacp[3];
+                for (int c = 0; c < ns; ++c) {
+                    hdcp[c] = dc[tdc[c]].present ? &dc[tdc[c]] : 0;
+                    hacp[c] = ac[tac[c]].present ? &ac[tac[c]] : 0;
+                }
+                BitReader pbr = {data + pos, data + n, 0, 0, 0};
+                const int st = prog_scan(&P, &pbr, ns, sc, hdcp, hacp, Ss, Se, Ah, Al);
+                if (st != JH_OK) return st;
+                pos = pbr.p - data;
+                continue;
+            }
             /* every block is decoded into a local buffer and leaves as eight non-temporal 16-byte stores: the slot (megabytes of a
              * shared-memory ring, not in any cache) is neither cleared first nor read for ownership */
             _Alignas(16) int16_t local[80];
@@ -293,17 +558,7 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
             for (int my = 0; my < mcuy; ++my)
                 for (int mx = 0; mx < mcux; ++mx) {
                     if (restart && until_restart == 0) {
-                        /* the interval's bits are used up (but for the padding of its last byte): the marker follows */
-                        if (br.fake > br.nbits) return JH_CORRUPT;
-                        if ((br.nbits - br.fake) >= 8) return JH_CORRUPT; /* whole unread data bytes in front of the marker */
-                        const uint8_t* q = br.p; /* the reader stays on a marker's 0xFF; if it has not met it yet, the next unread byte */
-                        if (q + 2 > br.end || q[0] != 0xFF) return JH_CORRUPT;
-                        while (q + 1 < br.end && q[1] == 0xFF) ++q;
-                        if (q + 2 > br.end || q[1] != 0xD0 + next_rst) return JH_CORRUPT;
-                        br.p = q + 2;
-                        br.bits = 0;
-                        br.nbits = 0;
-                        br.fake = 0;
+                        if (at_marker(&br, 0xD0 + next_rst) != JH_OK) return JH_CORRUPT;
                         next_rst = (next_rst + 1) & 7;
                         pred[0] = pred[1] = pred[2] = 0;
                         until_restart = restart;

@@ -1,7 +1,7 @@
 // The hand-over between the host half and the device half of the hybrid JPEG decode (round 4; SURVEY.md §8 f4, "or GPU decode").
 //
 //   host   (jpeg_host.c -> libhipts_jpeg_host.so, plain C: loaded by the decode worker PROCESSES, which must not touch the GPU)
-//          parses a baseline / extended-sequential Huffman JPEG and entropy-decodes it into quantised DCT coefficients -- the part of
+//          parses a baseline / extended-sequential / progressive Huffman JPEG and entropy-decodes it into quantised DCT coefficients -- the part of
 //          libjpeg's decoder that is a serial bit stream;
 //   device (jpeg.hip, in libhip_tagsearch.so) dequantises, runs libjpeg's accurate integer inverse DCT (jidctint.c, JDCT_ISLOW: Pillow's
 //          default), the "fancy" chroma upsampling (jdsample.c) and the YCbCr -> RGB conversion (jdcolor.c), then the tagger's pad +

@@ -19,11 +19,11 @@ resize on the host, which the reference does on 8 threads inside the GIL (taggin
                  `input_pipeline`), so N workers feed ~3.5x the images; the ring is registered as pinned memory so the copies
                  are asynchronous DMA.  Images larger than a slot (`max_pixels`) are resized by the worker as before.
 
-  DecodePool(device_resize=True, device_jpeg=True)   (round 4) hybrid JPEG decode: for a baseline JPEG the worker runs only the serial half
+  DecodePool(device_resize=True, device_jpeg=True)   (round 4) hybrid JPEG decode: for a baseline or progressive JPEG the worker runs only the serial half
                  of libjpeg -- markers and Huffman decoding (csrc/jpeg_host.c in libhipts_jpeg_host.so, a library without any GPU runtime
                  behind it) -- and leaves quantised DCT coefficients in its ring slot; inverse DCT, chroma upsampling and YCbCr -> RGB
                  (libjpeg-turbo's arithmetic byte for byte: csrc/jpeg.hip) run on the device in front of the pad + resize
-                 (`hipts_jpeg_batch_u8`).  Files that path does not take (PNG, progressive or CMYK JPEGs, alpha, anything irregular) are
+                 (`hipts_jpeg_batch_u8`).  Files that path does not take (PNG, CMYK JPEGs, alpha, anything irregular) are
                  decoded by Pillow in the same worker as before; the two kinds mix freely inside a batch.
 
 Workers are started with the `forkserver` method so that no child is forked from a process that holds a GPU

@@ -231,9 +231,10 @@ int hipts_resize_batch_u8(const uint8_t* src_base, int src_memspace, int64_t slo
  *
  * hipts_jpeg_entropy_decode (HOST ONLY: also exported by libhipts_jpeg_host.so, which has no GPU runtime behind it -- the library the
  * worker processes load): file bytes -> a "slot" = hipts_jpeg_header (csrc/jpeg_slot.h) + int16 coefficient blocks.
- * Returns 0; 1: not a file the fast path takes (progressive / arithmetic / 12-bit / CMYK / RGB-coded / sampling other than 4:4:4, 4:2:2,
- * 4:2:0 / several scans / smaller than 16 x 16 / not a JPEG); 2: the slot is too small; 3: the stream is irregular (truncated, bad codes,
- * restart markers out of order).  On 1..3 the caller decodes the file with Pillow as before.  hipts_jpeg_slot_bytes: an upper bound of the
+ * Baseline, extended-sequential and progressive Huffman files.  Returns 0; 1: not a file the fast path takes (arithmetic coding / a
+ * progression that leaves coefficients out or below full precision / 12-bit / CMYK / RGB-coded / sampling other than 4:4:4, 4:2:2,
+ * 4:2:0 / a sequential file in several scans / smaller than 16 x 16 / not a JPEG); 2: the slot is too small; 3: the stream is irregular (truncated, bad codes,
+ * restart markers out of order, coefficients beyond what an 8-bit image can produce).  On 1..3 the caller decodes the file with Pillow as before.  hipts_jpeg_slot_bytes: an upper bound of the
  * slot a width x height image needs. */
 int hipts_jpeg_entropy_decode(const uint8_t* file_bytes, int64_t n, void* slot, int64_t slot_bytes);
 int64_t hipts_jpeg_slot_bytes(int width, int height);

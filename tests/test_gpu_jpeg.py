@@ -61,8 +61,9 @@ def test_batch_of_coefficient_and_decoded_slots(mode):
     files = []
     for (h, w), sub, q in [((768, 1024), 2, 90), ((500, 333), 1, 80), ((97, 211), 0, 95), ((1200, 900), 2, 85), ((64, 64), 2, 50)]:
         files.append(jpeg_bytes(synth_image(rng, h, w), quality=q, subsampling=sub))
-    files.append(jpeg_bytes(synth_image(rng, 300, 400), quality=85, progressive=True))       # refused by the fast path: decoded slot
+    files.append(jpeg_bytes(synth_image(rng, 300, 400).convert("CMYK"), quality=85))       # refused by the fast path: decoded slot
     files.append(jpeg_bytes(synth_image(rng, 240, 320, grey=True), quality=85))
+    files.append(jpeg_bytes(synth_image(rng, 333, 222), quality=80, subsampling=2, progressive=True))
     stride = 1200 * 900 * 4
     slots = np.zeros((len(files), stride), dtype=np.uint8)
     ref = np.zeros((len(files), stride), dtype=np.uint8)
@@ -79,7 +80,7 @@ def test_batch_of_coefficient_and_decoded_slots(mode):
             slots[i, :img.size] = img.reshape(-1)
             kinds.append(0)
         hw.append((h, w))
-    assert kinds == [1, 1, 1, 1, 1, 0, 1]
+    assert kinds == [1, 1, 1, 1, 1, 0, 1, 1]
     kinds = np.asarray(kinds, dtype=np.int32)
     hw = np.ascontiguousarray(np.asarray(hw, dtype=np.int32))
     pad, filt = (1, 3) if mode == "tagger" else (0, 2)
@@ -123,6 +124,9 @@ def test_decode_pool_with_device_jpeg_equals_pillow_workers(tmp_path):
     p = str(tmp_path / "progressive.jpg")
     synth_image(rng, 300, 200).save(p, quality=85, progressive=True)
     paths.insert(20, p)
+    p = str(tmp_path / "cmyk.jpg")
+    synth_image(rng, 150, 210).convert("CMYK").save(p, quality=85)
+    paths.insert(25, p)
     p = str(tmp_path / "truncated.jpg")
     data = jpeg_bytes(synth_image(rng, 300, 200), quality=85)
     open(p, "wb").write(data[:len(data) // 2])

@@ -2,7 +2,7 @@
 the oracle's restatement of libjpeg's inverse DCT / fancy upsampling / colour conversion (oracle/jpeg.py) gives the bytes of
 PIL.Image.open(file).convert('RGB') -- the decode the reference performs (tagging.py:234-252) -- on files Pillow writes here: three chroma
 samplings, odd sizes, qualities 30..100 (quality 100: all-ones quantisation tables, long codes), optimised Huffman tables, restart
-markers, greyscale.  Files the fast path does not take (progressive, CMYK, tiny, truncated) are refused with a status, never decoded
+markers, greyscale, progressive mode.  Files the fast path does not take (incomplete progressions, CMYK, tiny, truncated) are refused with a status, never decoded
 wrongly.  This pins oracle/jpeg.py (the checker of the GPU kernels, tests/test_gpu_jpeg.py) against libjpeg-turbo itself."""
 import ctypes
 import io
@@ -54,6 +54,13 @@ def cases():
     out.append(((301, 203), False, dict(quality=85, subsampling=2, restart_marker_blocks=7)))
     out.append(((301, 203), False, dict(quality=75, subsampling=1, restart_marker_rows=1)))
     out.append(((64, 48), False, dict(quality=95, subsampling=0, optimize=True, restart_marker_blocks=1)))
+    # progressive mode (Pillow's libjpeg writes the standard ten-scan script: spectral selection and successive approximation)
+    for (h, w) in [(120, 160), (101, 77), (33, 250), (480, 641)]:
+        for sub in (0, 1, 2):
+            out.append(((h, w), False, dict(quality=85, subsampling=sub, progressive=True)))
+    out.append(((300, 200), True, dict(quality=85, progressive=True)))
+    out.append(((96, 128), False, dict(quality=30, subsampling=2, progressive=True, optimize=True)))
+    out.append(((96, 128), False, dict(quality=100, subsampling=1, progressive=True, restart_marker_blocks=5)))
     return out
 
 
@@ -94,7 +101,11 @@ def test_files_outside_the_fast_path_are_refused():
     lib = host_lib()
     rng = np.random.default_rng(1)
     im = synth_image(rng, 120, 160)
-    assert entropy_decode(lib, jpeg_bytes(im, quality=80, progressive=True))[0] == 1                # progressive
+    prog = jpeg_bytes(im, quality=80, progressive=True)
+    last = prog.rindex(b"\xff\xda")
+    assert entropy_decode(lib, prog)[0] == 0
+    # a progression that stops short (the last refinement scan cut away): libjpeg would smooth the blocks -- refused
+    assert entropy_decode(lib, prog[:last] + b"\xff\xd9", slot_bytes=lib.hipts_jpeg_slot_bytes(160, 120))[0] == 1
     assert entropy_decode(lib, jpeg_bytes(im.convert("CMYK"), quality=80))[0] == 1                  # four components
     assert entropy_decode(lib, jpeg_bytes(synth_image(rng, 12, 12), quality=80))[0] == 1            # below 16 x 16
     buf = io.BytesIO()
@@ -125,7 +136,8 @@ from test_oracle_jpeg import host_lib, synth_image, jpeg_bytes
 lib = host_lib()
 rng = np.random.default_rng(11)
 seeds = [jpeg_bytes(synth_image(rng, 120, 152), quality=q, subsampling=s, **kw) for q, s, kw in
-         [(85, 2, {}), (60, 1, {}), (95, 0, {"optimize": True}), (80, 2, {"restart_marker_blocks": 3})]]
+         [(85, 2, {}), (60, 1, {}), (95, 0, {"optimize": True}), (80, 2, {"restart_marker_blocks": 3}), (85, 2, {"progressive": True}),
+          (70, 0, {"progressive": True, "restart_marker_blocks": 4})]]
 nb = int(lib.hipts_jpeg_slot_bytes(152, 120))
 guard = 4096
 buf = np.zeros(nb + guard, dtype=np.uint8)
@@ -170,11 +182,12 @@ def test_every_accepted_mutated_stream_still_equals_pillow():
     lib = host_lib()
     rng = np.random.default_rng(12)
     seeds = [jpeg_bytes(synth_image(rng, 120, 152), quality=q, subsampling=s, **kw) for q, s, kw in
-             [(85, 2, {}), (60, 1, {}), (95, 0, {"optimize": True}), (80, 2, {"restart_marker_blocks": 3})]]
+             [(85, 2, {}), (60, 1, {}), (95, 0, {"optimize": True}), (80, 2, {"restart_marker_blocks": 3}), (85, 2, {"progressive": True}),
+              (70, 1, {"progressive": True})]]
     nb = int(lib.hipts_jpeg_slot_bytes(152, 120))
     accepted = refused = 0
-    for it in range(1200):
-        d = bytearray(seeds[it % 4])
+    for it in range(1800):
+        d = bytearray(seeds[it % 6])
         start = d.index(b"\xff\xda") + 14
         for _ in range(int(rng.integers(1, 4))):
             d[int(rng.integers(start, len(d) - 2))] = int(rng.integers(0, 256))
