@@ -38,6 +38,9 @@ struct hipts_bm25 {
     std::vector<double> h_idf;
     DevBuf d_ptr, d_term, d_tf, d_dl, d_idf;   // int64[D+1], int32[nnz], int32[nnz], int32[D], double[V]
     DevBuf d_tptr, d_tdoc, d_ttf;              // term-major postings: int64[V+1], int32[nnz], int32[nnz]
+    DevBuf d_tslice;                           // int64[V][BM25_SLICES + 1]: a term's postings cut at fixed document boundaries (bm25_postings_sliced_kernel)
+    DevBuf ws_maxpart;                         // [queries][slices] partial row maxima of that kernel
+    int64_t slice_docs = 0;                    // documents per slice (a multiple of 8); 0: the index is too small to be sliced
     DevBuf ws_q, ws_scores, ws_sims, ws_max, ws_final, ws_mark, ws_out, ws_parts;
     PinBuf pin_in, pin_out;                    // hipts_search: one H2D of the packed queries, one D2H of the packed results
     // hipts_search_submit / _collect (round 4): two batches in flight -- the host packs and launches batch i + 1 while the device runs batch i.
@@ -287,6 +290,156 @@ __global__ __launch_bounds__(1024) void bm25_postings_kernel(const int64_t* __re
             max_out[q] = m;
         }
     }
+}
+
+// The same walk with the document range cut into slices (round 4).  One workgroup per query is one workgroup per CU for a batch of 256:
+// 16 waves that clear, scatter into and re-read an 800 KB row at ~15 GB/s -- the kernel took 166 us for 620 MB, most of it latency.  A
+// document's float64 additions only have to keep the QUERY'S TERM ORDER, and documents are independent, so a workgroup may take any
+// document range: grid (query, part), each workgroup the postings of its range -- found through a table of every term's posting offsets
+// at BM25_SLICES fixed document boundaries, built with the index -- and a partial row maximum; four 512-thread workgroups share a CU.
+// Same instructions per document as bm25_postings_kernel: the same bits.
+constexpr int BM25_SLICES = 8;
+__global__ __launch_bounds__(512) void bm25_postings_sliced_kernel(const int64_t* __restrict__ tslice, const int32_t* __restrict__ tdoc,
+                                                                   const int32_t* __restrict__ ttf, const int32_t* __restrict__ dl,
+                                                                   const double* __restrict__ idf, int32_t V, double avgdl, int64_t D, int64_t slice_docs,
+                                                                   int per_part, const int32_t* __restrict__ q_terms,
+                                                                   const double* __restrict__ q_weights, const int32_t* __restrict__ q_ptr,
+                                                                   double* __restrict__ out, uint8_t* __restrict__ mark_all, double* __restrict__ max_part) {
+    constexpr int NT = 512;
+    const int q = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const int s0 = part * per_part, s1 = s0 + per_part;                       // fixed slices [s0, s1)
+    const int64_t lo = (int64_t)s0 * slice_docs, hi = s1 == BM25_SLICES ? D : (int64_t)s1 * slice_docs;      // lo, hi multiples of 8 (D % 8 == 0)
+    const int qb = q_ptr[q], qe = q_ptr[q + 1];
+    double* __restrict__ scores = out + (int64_t)q * D;
+    uint8_t* __restrict__ mark = mark_all + (int64_t)q * D;
+    int n_required = 0;
+    bool masking = false;
+    for (int j = qb; j < qe; ++j) {
+        const double w = q_weights[j];
+        if (w > REQUIRE_MAGIC) ++n_required;
+        if (w > REQUIRE_MAGIC || w < 0.0) masking = true;
+    }
+    constexpr int TPRE = 8;
+    int64_t t_b[TPRE], t_e[TPRE];
+    double t_idf[TPRE];
+#pragma unroll
+    for (int u = 0; u < TPRE; ++u) {
+        const int j = qb + u;
+        const int32_t t = j < qe ? q_terms[j] : -1;
+        const bool ok = t >= 0 && t < V;
+        t_b[u] = ok ? tslice[(int64_t)t * (BM25_SLICES + 1) + s0] : 0;
+        t_e[u] = ok ? tslice[(int64_t)t * (BM25_SLICES + 1) + s1] : 0;
+        t_idf[u] = ok ? idf[t] : 0.0;
+    }
+    {
+        const double2 z2 = make_double2(0.0, 0.0);
+        for (int64_t g = (lo >> 1) + tid; g < (hi >> 1); g += NT) reinterpret_cast<double2*>(scores)[g] = z2;
+        if (masking)
+            for (int64_t g = (lo >> 3) + tid; g < (hi >> 3); g += NT) reinterpret_cast<uint64_t*>(mark)[g] = 0ull;
+    }
+    __syncthreads();
+    for (int j = qb; j < qe; ++j) {
+        const int32_t t = q_terms[j];
+        const double w = q_weights[j];
+        if (t >= 0 && t < V) {
+            double idf_t;
+            int64_t b, e;
+            const int u = j - qb;
+            if (u < TPRE) {                       // uniform
+                idf_t = t_idf[0]; b = t_b[0]; e = t_e[0];
+#pragma unroll
+                for (int x = 1; x < TPRE; ++x)
+                    if (u == x) { idf_t = t_idf[x]; b = t_b[x]; e = t_e[x]; }
+            } else {
+                idf_t = idf[t]; b = tslice[(int64_t)t * (BM25_SLICES + 1) + s0]; e = tslice[(int64_t)t * (BM25_SLICES + 1) + s1];
+            }
+            constexpr int PU = 8;
+            const bool req = w > REQUIRE_MAGIC;
+            const double ww = req ? (w - REQUIRE_MAGIC) : w;
+            for (int64_t i0 = b + tid; i0 < e; i0 += (int64_t)PU * NT) {
+                int32_t dd[PU];
+                double tfd[PU];
+#pragma unroll
+                for (int u2 = 0; u2 < PU; ++u2) {
+                    const int64_t i = i0 + (int64_t)u2 * NT;
+                    dd[u2] = i < e ? tdoc[i] : -1;
+                    tfd[u2] = i < e ? (double)ttf[i] : 0.0;
+                }
+                if (w < 0.0) {
+#pragma unroll
+                    for (int u2 = 0; u2 < PU; ++u2)
+                        if (dd[u2] >= 0) mark[dd[u2]] |= 0x80;
+                } else {
+                    double dlv[PU], sv[PU];
+                    uint8_t mk[PU];
+#pragma unroll
+                    for (int u2 = 0; u2 < PU; ++u2) {
+                        dlv[u2] = dd[u2] >= 0 ? (double)dl[dd[u2]] : 0.0;
+                        sv[u2] = dd[u2] >= 0 ? scores[dd[u2]] : 0.0;
+                        mk[u2] = (req && dd[u2] >= 0) ? mark[dd[u2]] : (uint8_t)0;
+                    }
+#pragma unroll
+                    for (int u2 = 0; u2 < PU; ++u2) {
+                        if (dd[u2] < 0) continue;
+                        const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv[u2] / avgdl));
+                        const double sc = idf_t * ((tfd[u2] * (BM25_K1 + 1.0)) / (tfd[u2] + nrm));
+                        scores[dd[u2]] = sv[u2] + ww * sc;
+                        if (req) mark[dd[u2]] = (uint8_t)(mk[u2] + 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double mx = -INFINITY;
+    const int64_t p0 = lo >> 1, p1 = hi >> 1;
+    if (masking) {
+        for (int64_t g0 = p0 + tid; g0 < p1; g0 += 4 * NT) {
+            double2 v[4];
+            uint32_t m2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * NT;
+                v[u] = g < p1 ? reinterpret_cast<const double2*>(scores)[g] : make_double2(-INFINITY, -INFINITY);
+                m2[u] = g < p1 ? reinterpret_cast<const uint16_t*>(mark)[g] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + u * NT;
+                if (g >= p1) continue;
+                const uint32_t ma = m2[u] & 0xffu, mb_ = m2[u] >> 8;
+                const bool ka = (ma & 0x80u) || (int)(ma & 0x7fu) != n_required, kb = (mb_ & 0x80u) || (int)(mb_ & 0x7fu) != n_required;
+                if (ka) v[u].x = -INFINITY;
+                if (kb) v[u].y = -INFINITY;
+                if (ka || kb) reinterpret_cast<double2*>(scores)[g] = v[u];
+                mx = fmax(mx, fmax(v[u].x, v[u].y));
+            }
+        }
+    } else if (max_part) {
+#pragma unroll 4
+        for (int64_t g = p0 + tid; g < p1; g += NT) {
+            const double2 a0 = reinterpret_cast<const double2*>(scores)[g];
+            mx = fmax(mx, fmax(a0.x, a0.y));
+        }
+    }
+    if (max_part) {
+        __shared__ double part_s[NT / 64];
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) part_s[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            double m = part_s[0];
+            for (int w = 1; w < NT / 64; ++w) m = fmax(m, part_s[w]);
+            max_part[(int64_t)q * gridDim.y + part] = m;
+        }
+    }
+}
+__global__ void bm25_max_reduce_kernel(const double* __restrict__ parts, int nparts, double* __restrict__ max_out, int nq) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    double m = parts[(int64_t)q * nparts];
+    for (int p = 1; p < nparts; ++p) m = fmax(m, parts[(int64_t)q * nparts + p]);
+    max_out[q] = m;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1929,6 +2082,24 @@ int launch_sim(const float* index, const float* tiled, int64_t D, int K, const f
 int launch_bm25(hipts_bm25* h, const int32_t* qt_dev, const double* qw_dev, const int32_t* qp_dev, int nq, double* out_dev,
                 hipStream_t s, double* max_out = nullptr) {
     static const bool scan = getenv("HIPTS_BM25") && strcmp(getenv("HIPTS_BM25"), "scan") == 0;   // A/B: document-major scan
+    // HIPTS_BM25_PARTS: workgroups per query of the sliced kernel (1 = the one-workgroup-per-query kernel; default: enough to put ~1024 on the chip)
+    static const int parts_env = getenv("HIPTS_BM25_PARTS") ? atoi(getenv("HIPTS_BM25_PARTS")) : 0;
+    if (!scan && h->slice_docs > 0 && parts_env != 1) {
+        int parts = parts_env;
+        if (parts != 2 && parts != 4 && parts != 8) parts = nq >= 256 ? 4 : 8;
+        HIPTS_TRY(h->ws_mark.reserve((size_t)nq * h->D));
+        if (max_out) HIPTS_TRY(h->ws_maxpart.reserve((size_t)nq * parts * 8));
+        bm25_postings_sliced_kernel<<<dim3(nq, parts), 512, 0, s>>>(h->d_tslice.as<int64_t>(), h->d_tdoc.as<int32_t>(), h->d_ttf.as<int32_t>(),
+                                                                     h->d_dl.as<int32_t>(), h->d_idf.as<double>(), h->V, h->avgdl, h->D, h->slice_docs,
+                                                                     BM25_SLICES / parts, qt_dev, qw_dev, qp_dev, out_dev, h->ws_mark.as<uint8_t>(),
+                                                                     max_out ? h->ws_maxpart.as<double>() : nullptr);
+        HIPTS_LAUNCH_CHECK();
+        if (max_out) {
+            bm25_max_reduce_kernel<<<ceil_div(nq, 256), 256, 0, s>>>(h->ws_maxpart.as<double>(), parts, max_out, nq);
+            HIPTS_LAUNCH_CHECK();
+        }
+        return HIPTS_OK;
+    }
     if (!scan) {
         HIPTS_TRY(h->ws_mark.reserve((size_t)nq * h->D));
         bm25_postings_kernel<<<nq, 1024, 0, s>>>(h->d_tptr.as<int64_t>(), h->d_tdoc.as<int32_t>(), h->d_ttf.as<int32_t>(),
@@ -2228,7 +2399,26 @@ int hipts_bm25_build(const int64_t* doc_ptr, const int32_t* term_ids, int64_t nu
                 ttf[pos] = h->h_tf[i];
             }
     }
+    // every term's posting offsets at BM25_SLICES fixed document boundaries (bm25_postings_sliced_kernel); the boundaries are multiples
+    // of 8 documents so that a slice of a score row starts on a 64-byte line
+    std::vector<int64_t> tslice;
+    h->slice_docs = (num_docs % 8 == 0 && num_docs >= 8192) ? (num_docs / 8 / BM25_SLICES) * 8 : 0;
+    if (h->slice_docs > 0) {
+        tslice.resize((size_t)vocab * (BM25_SLICES + 1));
+        for (int32_t t = 0; t < vocab; ++t) {
+            const int32_t* first = tdoc.data() + tptr[t];
+            const int32_t* last = tdoc.data() + tptr[t + 1];
+            for (int sl = 0; sl <= BM25_SLICES; ++sl) {
+                const int64_t bound = sl == BM25_SLICES ? num_docs : (int64_t)sl * h->slice_docs;
+                tslice[(size_t)t * (BM25_SLICES + 1) + sl] = tptr[t] + (std::lower_bound(first, last, (int32_t)std::min<int64_t>(bound, INT32_MAX)) - first);
+            }
+        }
+    }
     int st = HIPTS_OK;
+    if (h->slice_docs > 0 && ((st = h->d_tslice.alloc(tslice.size() * 8)) || (st = upload(h->d_tslice.p, tslice.data(), tslice.size() * 8)))) {
+        delete h;
+        return st;
+    }
     if ((st = h->d_ptr.alloc((size_t)(num_docs + 1) * 8)) || (st = h->d_term.alloc((size_t)h->nnz * 4)) ||
         (st = h->d_tf.alloc((size_t)h->nnz * 4)) || (st = h->d_dl.alloc((size_t)num_docs * 4)) ||
         (st = h->d_idf.alloc((size_t)vocab * 8)) || (st = upload(h->d_ptr.p, h->h_ptr.data(), (size_t)(num_docs + 1) * 8)) ||
