@@ -1144,7 +1144,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // the default kernels' code is untouched.
 template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false, bool SK = false, bool INT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
-    static_assert(!INT || ((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) && MR == 8 && !OP8 && !SK), "INT: the residual epilogues' interior form");
+    static_assert(!INT || (EPI == EPI_RESID_XG && MR == 8 && !OP8 && !SK), "INT: the residual epilogue's interior form");
     static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
     static_assert(!SK || (!OP8 && MR == 8), "split-K: 16-bit operands, full tiles");
     constexpr int TBM = 2 * MR * 16;
@@ -2197,8 +2197,10 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
                     }
                 }
             }
-            if constexpr (EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI) {
-                // every tile inside the matrix: the instantiation without per-lane predication (HIPTS_RESID_GENERAL=1: the general one, A/B)
+            if constexpr (EPI == EPI_RESID_XG) {
+                // every tile inside the matrix: the instantiation without per-lane predication (HIPTS_RESID_GENERAL=1: the general one, A/B).
+                // (Not instantiated for RESID_XGI: its only user, EVA02, has 1025 tokens per image -- no launch of whole tiles -- and with the
+                // input fold's extra column vector the interior form compiled to 60 spilled registers.)
                 if (mr == 8 && a.M % 256 == 0 && a.N % 256 == 0 && a.N <= 1024 && !a.pos && a.out_bf16 && a.stat_part && !resid_general) {
                     static bool attr_int = false;
                     if (!attr_int) {
