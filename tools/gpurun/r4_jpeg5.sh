@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 4: the end-to-end rate over a corpus of PROGRESSIVE JPEGs (Pillow workers against entropy-decode workers)
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
+mkdir -p gpurun_out/r04
+E2E_PROGRESSIVE=1 E2E_MODES=3,4 timeout -k 10 400 python tools/pipeline_e2e.py 8192 16 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04/pipeline_e2e_progressive.txt

@@ -17,7 +17,8 @@ def make(args):
     rng = np.random.default_rng(i)
     small = Image.fromarray(rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)).resize((1024, 768), Image.BICUBIC)
     a = np.asarray(small, dtype=np.int16) + rng.integers(-6, 7, (768, 1024, 3), dtype=np.int16)
-    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(os.path.join(d, "img%05d.jpg" % i), quality=90)
+    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(os.path.join(d, "img%05d.jpg" % i), quality=90,
+                                                               progressive=bool(int(os.environ.get("E2E_PROGRESSIVE", "0"))))
 
 
 with tempfile.TemporaryDirectory() as tmp:
@@ -26,7 +27,7 @@ with tempfile.TemporaryDirectory() as tmp:
     t0 = time.perf_counter()
     with concurrent.futures.ProcessPoolExecutor(W) as ex:
         list(ex.map(make, [(d, i) for i in range(N)], chunksize=16))
-    print("%d JPEGs 1024x768 q90 written in %.1f s (%d processes)" % (N, time.perf_counter() - t0, W), flush=True)
+    print("%d %sJPEGs 1024x768 q90 written in %.1f s (%d processes)" % (N, "progressive " if int(os.environ.get("E2E_PROGRESSIVE", "0")) else "", time.perf_counter() - t0, W), flush=True)
     ref = None
     only = os.environ.get("E2E_MODES")          # e.g. "3,4": run only those rows (0-based)
     for mode_i, (name, extra) in enumerate([("8 threads, host resize (the reference's structure)", []), ("8 threads, device resize", ["--gpu-resize"]),
