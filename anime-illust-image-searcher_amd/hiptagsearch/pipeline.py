@@ -158,12 +158,15 @@ class DecodePool:
             raise ValueError("device_jpeg needs device_resize: the decoded image only exists on the device")
         self.workers = max(1, workers or (os.cpu_count() or 1))
         self.size, self.batch, self.mode = size, batch, mode
-        self.slots = 2 * batch
+        # ring parts: two batches (one being decoded, one being consumed); with the device resize three -- two batches at the workers, so
+        # that they never idle at a batch boundary waiting for the stragglers of the batch or for the device to copy a part out
+        self.parts = 3 if device_resize else 2
+        self.slots = self.parts * batch
         self.raw = max(int(max_pixels), size * size) if device_resize else 0
         self.device = device
         self.jpeg = bool(device_jpeg)
         self._pinned = False
-        self._events = [None, None]
+        self._events = [None] * 3
         slot_bytes = _raw_slot_bytes(self.raw, size, self.jpeg) if self.raw else size * size * 3
         self._shm = shared_memory.SharedMemory(create=True, size=self.slots * slot_bytes)
         if self.raw:
@@ -231,11 +234,16 @@ class DecodePool:
         import torch
         q: "queue.Queue" = queue.Queue(maxsize=2)
         stop = threading.Event()
+        timing = os.environ.get("HIPTS_PIPELINE_TIMING")          # development aid: where the producer and the consumer wait (printed at the end)
+        import time as _t
+        T = {"wait_workers": 0.0, "submit": 0.0, "to_device": 0.0, "put": 0.0, "consumer_wait": 0.0, "consumer_busy": 0.0, "batches": 0}
+
+        P = self.parts
 
         def submit(k: int):
-            base = (k & 1) * self.batch
-            if self._events[k & 1] is not None:
-                self._events[k & 1].synchronize()       # the copies out of this half of the ring (batch k - 2) are done
+            base = (k % P) * self.batch
+            if self._events[k % P] is not None:
+                self._events[k % P].synchronize()       # the copies out of this part of the ring (batch k - P) are done
             return self._pool.map_async(_worker_decode, [(base + i, p) for i, p in enumerate(chunks[k])],
                                         chunksize=max(1, len(chunks[k]) // (4 * self.workers)))
 
@@ -243,17 +251,23 @@ class DecodePool:
             try:
                 with torch.cuda.device(self.device):
                     side = torch.cuda.Stream()
-                    pending = submit(0)
+                    ahead = P - 1                           # batches at the workers
+                    pend = {j: submit(j) for j in range(min(ahead, len(chunks)))}
                     for k, chunk in enumerate(chunks):
-                        res = pending.get()
-                        if k + 1 < len(chunks):
-                            pending = submit(k + 1)
+                        t0 = _t.perf_counter()
+                        res = pend.pop(k).get()
+                        t1 = _t.perf_counter()
+                        if k + ahead < len(chunks):
+                            pend[k + ahead] = submit(k + ahead)
+                        t2 = _t.perf_counter()
+                        T["wait_workers"] += t1 - t0
+                        T["submit"] += t2 - t1
                         if stop.is_set():
                             return
                         keep = [i for i, r in enumerate(res) if r is not False]
                         if not keep:
                             continue
-                        base = (k & 1) * self.batch
+                        base = (k % P) * self.batch
                         with torch.cuda.stream(side):
                             if len(keep) == len(chunk):
                                 out = self._to_device(base, res, side)
@@ -261,8 +275,12 @@ class DecodePool:
                                 out = torch.cat([self._to_device(base + i, [res[i]], side) for i in keep])
                             ev = torch.cuda.Event()
                             ev.record(side)
-                        self._events[k & 1] = ev
+                        self._events[k % P] = ev
+                        t3 = _t.perf_counter()
                         q.put(([chunk[i] for i in keep], out, ev))
+                        T["to_device"] += t3 - t2
+                        T["put"] += _t.perf_counter() - t3
+                        T["batches"] += 1
                 q.put(None)
             except BaseException as e:      # hand the error to the consumer
                 q.put(e)
@@ -271,7 +289,9 @@ class DecodePool:
         th.start()
         try:
             while True:
+                t0 = _t.perf_counter()
                 item = q.get()
+                T["consumer_wait"] += _t.perf_counter() - t0
                 if item is None:
                     break
                 if isinstance(item, BaseException):
@@ -280,8 +300,15 @@ class DecodePool:
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(ev)
                 out.record_stream(cur)
+                t0 = _t.perf_counter()
                 yield kept, out
+                T["consumer_busy"] += _t.perf_counter() - t0
         finally:
+            if timing and T["batches"]:
+                n = T["batches"]
+                print("pipeline timing per batch (ms): producer waits for the workers %.2f, submits the next batch %.2f, copies + decodes + resizes "
+                      "(host side of the calls) %.2f, waits for a free queue place %.2f | consumer waits for a batch %.2f, works on it %.2f"
+                      % tuple(1e3 * T[k] / n for k in ("wait_workers", "submit", "to_device", "put", "consumer_wait", "consumer_busy")), flush=True)
             stop.set()
             while th.is_alive():            # unblock a producer that waits on a full queue
                 try:

@@ -198,16 +198,27 @@ class TagSelector:
 
 def format_lines(names: Sequence[str], counts: np.ndarray, ids: np.ndarray) -> List[str]:
     """tagging.py:210-225: general tags then character tags, ' ' -> '_', joined by ','."""
+    names_us = _underscored(names)
     out = []
     for r in range(len(counts)):
         ng, nc = int(counts[r, 0]), int(counts[r, 1])
-        g = [names[i].replace(' ', '_') for i in ids[r, :ng]]
-        s = ",".join(g)
-        if nc > 0:
-            s += ","
-            s += ",".join(names[i].replace(' ', '_') for i in ids[r, ng:ng + nc])
-        out.append(s)
+        row = ids[r, :ng + nc].tolist()         # general tags, then character tags (hipts_tagsel_run's row layout)
+        line = ",".join([names_us[i] for i in row])
+        out.append("," + line if ng == 0 and nc > 0 else line)      # (tagging.py:212-225 appends "," + characters to an empty general string too)
     return out
+
+
+_US_CACHE: Dict[int, Tuple[Sequence[str], List[str]]] = {}
+
+
+def _underscored(names: Sequence[str]) -> List[str]:
+    """names with ' ' -> '_' (tagging.py:212,219), computed once per label table: the per-tag str.replace was a third of the formatting time."""
+    hit = _US_CACHE.get(id(names))
+    if hit is None or hit[0] is not names:
+        hit = (names, [n.replace(' ', '_') for n in names])
+        _US_CACHE.clear()
+        _US_CACHE[id(names)] = hit
+    return hit[1]
 
 
 class Predictor:
@@ -541,19 +552,51 @@ class Predictor:
             # predict() in two halves: while one thread selects, formats and writes the lines of batch k (the reference does that part on
             # the CPU too, tagging.py:185-232), this one is already in the forward of batch k + 1 -- one worker, so the file keeps its order
             post = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            # the formatting thread is pure Python: with the interpreter's default 5 ms switch interval the main thread, back from the
+            # forward, waited that long for the GIL before it could launch the next one
+            import sys
+            old_switch = sys.getswitchinterval()
+            sys.setswitchinterval(2e-4)
 
-            def finish(kept, probs_list):
-                for p, line in zip(kept, self._select_lines(probs_list, 0.3, True, 0.3, True)):
+            def finish(kept, probs_list, ev=None):
+                if ev is not None:
+                    # device-resident probabilities of a forward that may still be running: the selection kernel is ordered behind it on
+                    # this thread's own stream, nothing here holds up the main thread's next launch
+                    import torch
+                    with torch.cuda.device(self.device), torch.cuda.stream(post_stream[0]):
+                        post_stream[0].wait_event(ev)
+                        lines = self._select_lines(probs_list, 0.3, True, 0.3, True)
+                else:
+                    lines = self._select_lines(probs_list, 0.3, True, 0.3, True)
+                for p, line in zip(kept, lines):
                     self.write_to_file(p + ',' + line)
                 self.f.flush()
             pending = None
+            post_stream = [None]
+            dev_probs = []          # two device buffers: batch k + 1's forward is launched while batch k's probabilities are being read
+            step = 0
             try:
                 for kept, images in source:
-                    probs_list = self._forward_probs(images)
-                    fut = post.submit(finish, list(kept), probs_list)
+                    on_device = hasattr(images, "is_cuda") and images.is_cuda and len(images) <= self.max_batch
+                    if on_device:
+                        # the forward is only LAUNCHED here (outputs stay on the device): the next iteration launches the next one at once,
+                        # so the device never waits for this thread between batches
+                        import torch
+                        if post_stream[0] is None:
+                            post_stream[0] = torch.cuda.Stream(device=self.device)
+                            dev_probs = [torch.empty((self.max_batch, self.tagger_model.num_classes), dtype=torch.float32, device=images.device)
+                                         for _ in range(2)]
+                        pr = dev_probs[step & 1][:len(images)]       # last read by the finish of batch step - 2, which was awaited one iteration ago
+                        self.tagger_model.forward_u8(images, probs=pr, want="probs")
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.device))
+                        fut = post.submit(finish, list(kept), [pr], ev)
+                    else:
+                        fut = post.submit(finish, list(kept), self._forward_probs(images))
                     if pending is not None:
                         pending.result()
                     pending = fut
+                    step += 1
                     done += len(kept)
                     if done - last >= PROGRESS_INTERVAL:
                         diff = time.perf_counter() - start
@@ -563,6 +606,7 @@ class Predictor:
                     pending.result()
             finally:
                 post.shutdown(wait=True)
+                sys.setswitchinterval(old_switch)
                 if pool is not None:
                     pool.close()
             self.f.close()

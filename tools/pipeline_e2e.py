@@ -47,6 +47,9 @@ with tempfile.TemporaryDirectory() as tmp:
         lines = r.stdout.splitlines()
         el = [float(l.split()[0]) for l in lines if l.endswith("seconds elapsed")]
         cnt = [int(l.split()[0]) for l in lines if l.endswith("files processed")]
+        for l in lines:
+            if l.startswith("pipeline timing"):
+                print("    " + l, flush=True)
         text = open(out, encoding="utf-8").read()
         same = ref is None or text == ref
         ref = ref or text
