@@ -89,10 +89,10 @@ __device__ __forceinline__ unsigned range_limit(int x) {
 
 // 32 blocks per workgroup, eight lanes per block: lane c runs column c of pass 1, then row c of pass 2 (the workspace goes through LDS,
 // rows padded to nine words).  A wave reads 8 x 128 B of coefficients as whole lines and stores 8 B per lane.
-__global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegImage im) {
+__device__ __forceinline__ void jpeg_idct_body(const JpegImage& im, int block_x) {
     __shared__ int ws[32][72];
     const int t = threadIdx.x, lb = t >> 3, l8 = t & 7;
-    const int blk = blockIdx.x * 32 + lb;
+    const int blk = block_x * 32 + lb;
     const bool valid = blk < im.first_block[im.ncomp];
     const int c = !valid ? 0 : (blk >= im.first_block[1] && im.ncomp > 1) + (blk >= im.first_block[2] && im.ncomp > 2);
     int d[8];
@@ -115,6 +115,20 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegImage im) {
     const int local = blk - im.first_block[c];
     const int by = local / im.blocks_w[c], bx = local - by * im.blocks_w[c];
     *reinterpret_cast<uint2*>(im.plane[c] + (size_t)(by * 8 + l8) * (im.blocks_w[c] * 8) + bx * 8) = make_uint2(lo, hi);
+}
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const JpegImage im) { jpeg_idct_body(im, blockIdx.x); }
+
+// Up to JPEG_CHUNK images per launch (blockIdx.y = image, the descriptors in the kernel arguments): 64 images were 128 launches of ~5 us
+// that ran one after the other beside the forward's kernels.
+constexpr int JPEG_CHUNK = 16;
+struct JpegBatch {
+    JpegImage im[JPEG_CHUNK];
+    uint8_t* rgb[JPEG_CHUNK];
+};
+__global__ __launch_bounds__(256) void jpeg_idct_batch_kernel(const JpegBatch b) {
+    const JpegImage& im = b.im[blockIdx.y];
+    if ((int)blockIdx.x * 32 >= im.first_block[im.ncomp]) return;      // (uniform per workgroup: the barrier inside is not reached by anybody)
+    jpeg_idct_body(im, blockIdx.x);
 }
 
 // chroma sample of output pixel (x, y): jdsample.c h2v2_fancy_upsample / h2v1_fancy_upsample / fullsize
@@ -139,9 +153,9 @@ __device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, int pw, 
 __device__ __forceinline__ int clamp8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 
 // a thread per pixel pair (x even): 6 bytes of RGB
-__global__ __launch_bounds__(256) void jpeg_rgb_kernel(const JpegImage im, uint8_t* __restrict__ rgb) {
+__device__ __forceinline__ void jpeg_rgb_body(const JpegImage& im, uint8_t* __restrict__ rgb, int block_x) {
     const int pairs = (im.width + 1) >> 1;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = block_x * 256 + threadIdx.x;
     if (idx >= pairs * im.height) return;
     const int y = idx / pairs, x0 = (idx - y * pairs) * 2;
     const int pw0 = im.blocks_w[0] * 8;
@@ -163,6 +177,9 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(const JpegImage im, uint8
         o[2] = (uint8_t)clamp8(Y + ((116130 * cb + 32768) >> 16));
     }
 }
+
+__global__ __launch_bounds__(256) void jpeg_rgb_kernel(const JpegImage im, uint8_t* __restrict__ rgb) { jpeg_rgb_body(im, rgb, blockIdx.x); }
+__global__ __launch_bounds__(256) void jpeg_rgb_batch_kernel(const JpegBatch b) { jpeg_rgb_body(b.im[blockIdx.y], b.rgb[blockIdx.y], blockIdx.x); }
 
 struct JpegState {
     std::mutex mu;
@@ -219,8 +236,8 @@ int describe(const hipts_jpeg_header* hd, int64_t slot_bytes, JpegImage* im, siz
     return HIPTS_OK;
 }
 
-// copy of the slot at `dev_slot`, planes at `planes`: the two kernels
-int launch_decode(JpegImage im, const uint8_t* dev_slot, uint8_t* planes, uint8_t* rgb, hipStream_t s) {
+// the descriptor's device pointers: copy of the slot at `dev_slot`, planes at `planes`
+void bind(JpegImage& im, const uint8_t* dev_slot, uint8_t* planes) {
     im.coef = reinterpret_cast<const int16_t*>(dev_slot + HIPTS_JPEG_HEADER_BYTES);
     im.quant = reinterpret_cast<const uint16_t*>(dev_slot + offsetof(hipts_jpeg_header, quant));
     size_t off = 0;
@@ -228,6 +245,11 @@ int launch_decode(JpegImage im, const uint8_t* dev_slot, uint8_t* planes, uint8_
         im.plane[c] = planes + off;
         off += align256((size_t)im.blocks_w[c] * im.blocks_h[c] * 64);
     }
+}
+
+// one image: the two kernels
+int launch_decode(JpegImage im, const uint8_t* dev_slot, uint8_t* planes, uint8_t* rgb, hipStream_t s) {
+    bind(im, dev_slot, planes);
     const int blocks = im.first_block[im.ncomp];
     jpeg_idct_kernel<<<(blocks + 31) / 32, 256, 0, s>>>(im);
     HIPTS_LAUNCH_CHECK();
@@ -317,10 +339,33 @@ extern "C" int hipts_jpeg_batch_u8(const uint8_t* slots, int64_t slot_stride, co
                 const hipts_jpeg_header* hd = reinterpret_cast<const hipts_jpeg_header*>(sp);
                 uint8_t* d = st.stage[device].as<uint8_t>() + stage_off[i];
                 HIPTS_HIP(hipMemcpyAsync(d, sp, (size_t)hd->total_bytes, hipMemcpyHostToDevice, s));
-                HIPTS_TRY(launch_decode(ims[i], d, st.planes[device].as<uint8_t>() + plane_off[i], rgb + (size_t)i * rgb_stride, s));
+                bind(ims[i], d, st.planes[device].as<uint8_t>() + plane_off[i]);
             } else {
                 HIPTS_HIP(hipMemcpyAsync(rgb + (size_t)i * rgb_stride, sp, (size_t)hw[2 * i] * hw[2 * i + 1] * 3, hipMemcpyHostToDevice, s));
             }
+        }
+        // the coefficient slots, JPEG_CHUNK images per launch
+        {
+            JpegBatch b{};
+            int nb = 0, max_blocks = 0, max_work = 0;
+            auto flush = [&]() -> int {
+                if (nb == 0) return HIPTS_OK;
+                jpeg_idct_batch_kernel<<<dim3((max_blocks + 31) / 32, nb), 256, 0, s>>>(b);
+                HIPTS_LAUNCH_CHECK();
+                jpeg_rgb_batch_kernel<<<dim3((max_work + 255) / 256, nb), 256, 0, s>>>(b);
+                HIPTS_LAUNCH_CHECK();
+                nb = max_blocks = max_work = 0;
+                return HIPTS_OK;
+            };
+            for (int i = 0; i < n; ++i) {
+                if (kinds[i] != 1) continue;
+                b.im[nb] = ims[i];
+                b.rgb[nb] = rgb + (size_t)i * rgb_stride;
+                max_blocks = std::max(max_blocks, ims[i].first_block[ims[i].ncomp]);
+                max_work = std::max(max_work, ((ims[i].width + 1) / 2) * ims[i].height);
+                if (++nb == JPEG_CHUNK) HIPTS_TRY(flush());
+            }
+            HIPTS_TRY(flush());
         }
         // pad + resize of the decoded images (resize.hip; same stream, so ordered behind the kernels above)
         const int rs = hipts_resize_batch_u8(rgb, HIPTS_DEVICE, (int64_t)rgb_stride, hw, n, pad_square, dst_device, size, filter, device, stream);

@@ -7,6 +7,7 @@
 // needs, then the vertical pass; each output byte = clip8((2^21 + sum pixel * coeff) >> 22).  The coefficient tables are computed on the
 // host with Pillow's own expressions in Pillow's order (this file is built with -ffp-contract=off, and Pillow's wheels carry no fused
 // multiply-adds), cached per (source size, output size, filter) and handed to two small kernels: the decode workers then only decode.
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -159,6 +160,64 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restri
     o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
 }
 
+// Batched forms (round 4): one launch for up to RESIZE_CHUNK images of different sizes, blockIdx.y = image, the per-image parameters in
+// the kernel arguments.  A batch of 64 decoded images was 128 launches of 5-13 us each; beside the forward's kernels they ran one after
+// the other and cost the pipeline their summed duration (tools/jpeg_overlap_bench.py).
+constexpr int RESIZE_CHUNK = 32;
+struct ResizeJob {
+    const uint8_t* src;       // image, [img_h][img_w][3]
+    uint8_t* tmp;             // horizontal pass output, [rows][size][3]
+    uint8_t* dst;             // [size][size][3]
+    const int* hb;            // horizontal coefficient table (bounds, weights) and its row length
+    const int* hk;
+    const int* vb;
+    const int* vk;
+    int img_h, img_w, top, left, y0, rows, hks, vks;
+};
+struct ResizeJobs {
+    ResizeJob j[RESIZE_CHUNK];
+};
+__global__ __launch_bounds__(256) void resample_h_pad_batch_kernel(const ResizeJobs jobs, int out_w) {
+    const ResizeJob& J = jobs.j[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= J.rows * out_w) return;
+    const int y = i / out_w, xx = i - y * out_w;
+    const int xmin = J.hb[2 * xx], n = J.hb[2 * xx + 1];
+    const int* k = J.hk + (size_t)xx * J.hks;
+    const int sy = J.y0 + y - J.top;
+    const bool row_in = sy >= 0 && sy < J.img_h;
+    const uint8_t* p = J.src + (size_t)(row_in ? sy : 0) * J.img_w * 3;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < n; ++x) {
+        const int w = k[x];
+        const int sx = xmin + x - J.left;
+        const bool in = row_in && sx >= 0 && sx < J.img_w;
+        s0 += (in ? p[3 * sx] : 255) * w;
+        s1 += (in ? p[3 * sx + 1] : 255) * w;
+        s2 += (in ? p[3 * sx + 2] : 255) * w;
+    }
+    uint8_t* o = J.tmp + (size_t)i * 3;
+    o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+}
+__global__ __launch_bounds__(256) void resample_v_batch_kernel(const ResizeJobs jobs, int size) {
+    const ResizeJob& J = jobs.j[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= size * size) return;
+    const int yy = i / size, x = i - yy * size;
+    const int ymin = J.vb[2 * yy] - J.y0, n = J.vb[2 * yy + 1];
+    const int* k = J.vk + (size_t)yy * J.vks;
+    const uint8_t* p = J.tmp + ((size_t)ymin * size + x) * 3;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int y = 0; y < n; ++y) {
+        const int wgt = k[y];
+        s0 += p[(size_t)y * size * 3] * wgt;
+        s1 += p[(size_t)y * size * 3 + 1] * wgt;
+        s2 += p[(size_t)y * size * 3 + 2] * wgt;
+    }
+    uint8_t* o = J.dst + (size_t)i * 3;
+    o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+}
+
 struct ResizeState {
     std::mutex mu;
     std::map<std::tuple<int, int, int, int>, DevCoeffs*> cache;      // (device, in, out, filter)
@@ -278,41 +337,54 @@ extern "C" int hipts_resize_batch_u8(const uint8_t* src_base, int src_memspace, 
     else HIPTS_HIP(hipEventCreateWithFlags(&st.last[device], hipEventDisableTiming));
     const bool host = src_memspace != HIPTS_DEVICE;
     if (host) HIPTS_TRY(st.bstage[device].reserve(total));
-    {   // the temporary of the tallest canvas, reserved once (growing it between launches would free memory that kernels in flight still read)
-        int max_ch = 1;
-        for (int i = 0; i < n; ++i) {
-            const int h = hw[2 * i], w = hw[2 * i + 1];
-            const int ch = pad_square ? (h > w ? h : w) : h;
-            max_ch = ch > max_ch ? ch : max_ch;
-        }
-        HIPTS_TRY(st.tmp[device].reserve((size_t)max_ch * size * 3));
-    }
-    size_t off = 0;
+    // the horizontal pass of every image keeps its own temporary: the launches below cover many images at once
+    std::vector<size_t> tmp_off((size_t)n);
+    size_t tmp_total = 0;
+    std::vector<DevCoeffs*> chs((size_t)n), cvs((size_t)n);
     for (int i = 0; i < n; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
-        const size_t bytes = (size_t)h * w * 3;
-        const uint8_t* sp = src_base + (size_t)i * slot_stride;
-        if (host) {
-            uint8_t* d = st.bstage[device].as<uint8_t>() + off;
-            HIPTS_HIP(hipMemcpyAsync(d, sp, bytes, hipMemcpyHostToDevice, s));
-            sp = d;
-            off += (bytes + 255) / 256 * 256;
-        }
         const int m = pad_square ? (h > w ? h : w) : 0;
         const int ch = pad_square ? m : h, cw = pad_square ? m : w;                 // canvas
-        const int top = pad_square ? (m - h) / 2 : 0, left = pad_square ? (m - w) / 2 : 0;
-        DevCoeffs *chz = nullptr, *cvt = nullptr;
-        HIPTS_TRY(get_coeffs(device, cw, size, filter, &chz));
-        HIPTS_TRY(get_coeffs(device, ch, size, filter, &cvt));
-        const int y0 = cvt->first, y1 = cvt->last;
-        uint8_t* t = st.tmp[device].as<uint8_t>();
-        const int total_h = (y1 - y0) * size;
-        resample_h_pad_kernel<<<(total_h + 255) / 256, 256, 0, s>>>(sp, h, w, top, left, t, size, y0, y1 - y0, chz->bounds.as<int>(), chz->kk.as<int>(),
-                                                                    chz->ksize);
+        HIPTS_TRY(get_coeffs(device, cw, size, filter, &chs[i]));
+        HIPTS_TRY(get_coeffs(device, ch, size, filter, &cvs[i]));
+        tmp_off[i] = tmp_total;
+        tmp_total += ((size_t)(cvs[i]->last - cvs[i]->first) * size * 3 + 255) / 256 * 256;
+    }
+    HIPTS_TRY(st.tmp[device].reserve(tmp_total));      // (grow-only, before anything of this call is launched)
+    size_t off = 0;
+    std::vector<const uint8_t*> srcs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const size_t bytes = (size_t)hw[2 * i] * hw[2 * i + 1] * 3;
+        srcs[i] = src_base + (size_t)i * slot_stride;
+        if (host) {
+            uint8_t* d = st.bstage[device].as<uint8_t>() + off;
+            HIPTS_HIP(hipMemcpyAsync(d, srcs[i], bytes, hipMemcpyHostToDevice, s));
+            srcs[i] = d;
+            off += (bytes + 255) / 256 * 256;
+        }
+    }
+    for (int c0 = 0; c0 < n; c0 += RESIZE_CHUNK) {
+        const int nc = n - c0 < RESIZE_CHUNK ? n - c0 : RESIZE_CHUNK;
+        ResizeJobs jobs{};
+        int max_h_work = 0;
+        for (int u = 0; u < nc; ++u) {
+            const int i = c0 + u;
+            const int h = hw[2 * i], w = hw[2 * i + 1];
+            const int m = pad_square ? (h > w ? h : w) : 0;
+            ResizeJob& J = jobs.j[u];
+            J.src = srcs[i];
+            J.tmp = st.tmp[device].as<uint8_t>() + tmp_off[i];
+            J.dst = dst_device + (size_t)i * size * size * 3;
+            J.hb = chs[i]->bounds.as<int>(); J.hk = chs[i]->kk.as<int>(); J.hks = chs[i]->ksize;
+            J.vb = cvs[i]->bounds.as<int>(); J.vk = cvs[i]->kk.as<int>(); J.vks = cvs[i]->ksize;
+            J.img_h = h; J.img_w = w;
+            J.top = pad_square ? (m - h) / 2 : 0; J.left = pad_square ? (m - w) / 2 : 0;
+            J.y0 = cvs[i]->first; J.rows = cvs[i]->last - cvs[i]->first;
+            max_h_work = std::max(max_h_work, J.rows * size);
+        }
+        resample_h_pad_batch_kernel<<<dim3((max_h_work + 255) / 256, nc), 256, 0, s>>>(jobs, size);
         HIPTS_LAUNCH_CHECK();
-        const int total_v = size * size;
-        resample_v_kernel<<<(total_v + 255) / 256, 256, 0, s>>>(t, size, dst_device + (size_t)i * size * size * 3, size, y0, cvt->bounds.as<int>(),
-                                                                cvt->kk.as<int>(), cvt->ksize);
+        resample_v_batch_kernel<<<dim3((size * size + 255) / 256, nc), 256, 0, s>>>(jobs, size);
         HIPTS_LAUNCH_CHECK();
     }
     HIPTS_HIP(hipEventRecord(st.last[device], s));

@@ -260,8 +260,10 @@ class DecodePool:
                         if k + ahead < len(chunks):
                             pend[k + ahead] = submit(k + ahead)
                         t2 = _t.perf_counter()
-                        T["wait_workers"] += t1 - t0
-                        T["submit"] += t2 - t1
+                        warm = k >= 8                        # (timing aid: the first batches carry pool start-up and first-use allocations)
+                        if warm:
+                            T["wait_workers"] += t1 - t0
+                            T["submit"] += t2 - t1
                         if stop.is_set():
                             return
                         keep = [i for i, r in enumerate(res) if r is not False]
@@ -278,9 +280,10 @@ class DecodePool:
                         self._events[k % P] = ev
                         t3 = _t.perf_counter()
                         q.put(([chunk[i] for i in keep], out, ev))
-                        T["to_device"] += t3 - t2
-                        T["put"] += _t.perf_counter() - t3
-                        T["batches"] += 1
+                        if warm:
+                            T["to_device"] += t3 - t2
+                            T["put"] += _t.perf_counter() - t3
+                            T["batches"] += 1
                 q.put(None)
             except BaseException as e:      # hand the error to the consumer
                 q.put(e)
@@ -288,10 +291,13 @@ class DecodePool:
         th = threading.Thread(target=produce, name="hipts-decode-producer", daemon=True)
         th.start()
         try:
+            seen = 0
             while True:
                 t0 = _t.perf_counter()
                 item = q.get()
-                T["consumer_wait"] += _t.perf_counter() - t0
+                seen += 1
+                if seen > 8:
+                    T["consumer_wait"] += _t.perf_counter() - t0
                 if item is None:
                     break
                 if isinstance(item, BaseException):
@@ -302,7 +308,8 @@ class DecodePool:
                 out.record_stream(cur)
                 t0 = _t.perf_counter()
                 yield kept, out
-                T["consumer_busy"] += _t.perf_counter() - t0
+                if seen > 8:
+                    T["consumer_busy"] += _t.perf_counter() - t0
         finally:
             if timing and T["batches"]:
                 n = T["batches"]

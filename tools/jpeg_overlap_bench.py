@@ -21,7 +21,15 @@ Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=9
 data = buf.getvalue()
 lib = _lib.load()
 stride = int(lib.hipts_jpeg_slot_bytes(1024, 768))
-slots = torch.empty((N, stride), dtype=torch.uint8).pin_memory()
+REGISTERED = len(sys.argv) > 1 and sys.argv[1] == "registered"      # the pipeline's ring: shared memory pinned with hipHostRegister
+if REGISTERED:
+    from multiprocessing import shared_memory
+    shm = shared_memory.SharedMemory(create=True, size=N * stride)
+    slots_np = np.ndarray((N, stride), dtype=np.uint8, buffer=shm.buf)
+    assert int(torch.cuda.cudart().cudaHostRegister(slots_np.ctypes.data, slots_np.nbytes, 0)) == 0
+    slots = torch.from_numpy(slots_np)
+else:
+    slots = torch.empty((N, stride), dtype=torch.uint8).pin_memory()
 src = np.frombuffer(data, dtype=np.uint8)
 for i in range(N):
     assert lib.hipts_jpeg_entropy_decode(src.ctypes.data, len(data), slots[i].numpy().ctypes.data, stride) == 0
@@ -56,4 +64,10 @@ def run(steps, with_decode):
 
 run(5, True)
 for name, wd in (("forward alone", False), ("forward + decode of the next batch beside it", True), ("forward alone", False), ("forward + decode of the next batch beside it", True)):
-    print("%-46s %.0f images/s" % (name, run(30, wd)), flush=True)
+    print("%-46s %.0f images/s%s" % (name, run(30, wd), " (ring pinned with hipHostRegister)" if REGISTERED else ""), flush=True)
+if REGISTERED:
+    torch.cuda.synchronize()
+    torch.cuda.cudart().cudaHostUnregister(slots_np.ctypes.data)
+    del slots, slots_np
+    shm.close()
+    shm.unlink()
