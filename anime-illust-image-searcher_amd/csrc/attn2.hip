@@ -25,6 +25,14 @@
 
 #include "vit_internal.h"
 
+// Head room of the half-operand fast path's reference exponent (round 4): m_ref = (the row's maximum over its first 32 keys) + this many
+// bits, so P = 2^(S - m_ref) overflows half only when a later score exceeds that maximum by 15 + MARGIN bits, and the row sum's window is
+// [2^(-1 - MARGIN), 2^15); keys more than 14 - MARGIN bits below the reference become half subnormals (their P keeps an absolute
+// precision of 2^-24, against a row sum of at least 2^-MARGIN).  With 0 a padded picture (prepare_image's white bars are the first keys of every row, tagging.py:100-120) sent most
+// query blocks through the fast pass AND the classic one: 4.6 k images/s where noise runs at 5.3 k (tools/vit_content_bench.py).
+#ifndef HIPTS_ATTN_REF_MARGIN
+#define HIPTS_ATTN_REF_MARGIN 8      // measured: 0 / 4 / 8 -> 4667 / 4979 / 5266 images/s on a padded picture, 5390-5412 on noise either way (tools/gpurun/r4_margin.sh)
+#endif
 namespace hipts {
 namespace {
 
@@ -241,7 +249,7 @@ __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t
                     for (int g = 0; g < GH; ++g)
 #pragma unroll
                         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[qb][g][i]);
-                    m_ref[qb] = fmaxf(mx, __shfl_xor(mx, 32));      // finite: tile 0 holds at least one unmasked key
+                    m_ref[qb] = fmaxf(mx, __shfl_xor(mx, 32)) + (float)HIPTS_ATTN_REF_MARGIN;      // finite: tile 0 holds at least one unmasked key
                 }
                 float ls0 = 0.f, ls1 = 0.f;
 #pragma unroll
@@ -308,7 +316,7 @@ __device__ __forceinline__ bool attn2_body(char* __restrict__ smem, const bf16_t
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
         {   // 0.5 <= l < 2^15 (half) / 2^-100 <= l < 2^100 (bf16) on the bit pattern: a NaN or a negative value fails whatever -fno-honor-nans assumes
             const uint32_t lb = __float_as_uint(l_tot);
-            constexpr uint32_t LO = F16 ? 0x3f000000u : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
+            constexpr uint32_t LO = F16 ? 0x3f000000u - ((uint32_t)HIPTS_ATTN_REF_MARGIN << 23) : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
             if (!(lb >= LO && lb < HI)) bad = true;
         }
         l_run[qb] = 1.0f / l_tot;
@@ -436,7 +444,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
             float mx = sacc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
-            m_ref = fmaxf(mx, __shfl_xor(mx, 32));
+            m_ref = fmaxf(mx, __shfl_xor(mx, 32)) + (float)HIPTS_ATTN_REF_MARGIN;
         }
         float ls0 = 0.f, ls1 = 0.f;
 #pragma unroll
@@ -532,7 +540,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     bool bad;
     {
         const uint32_t lb = __float_as_uint(l_tot);
-        constexpr uint32_t LO = F16 ? 0x3f000000u : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
+        constexpr uint32_t LO = F16 ? 0x3f000000u - ((uint32_t)HIPTS_ATTN_REF_MARGIN << 23) : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
         bad = !(lb >= LO && lb < HI);
     }
 #ifndef HIPTS_X_NOFALLBACK

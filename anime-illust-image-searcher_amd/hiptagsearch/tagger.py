@@ -349,8 +349,12 @@ class Predictor:
         """tagging.py:185-227: MCut thresholds, selection and the tag strings of predict."""
         out: List[str] = []
         for probs in probs_list:
+            # 512 label ids per image come back first (128 KB per batch of 64 instead of the 2.8 MB of full-width rows, whose read-back
+            # into pageable memory was the largest transfer of a batch); a batch in which an image selects more is read again in full
             counts, ids, _ = self.selector.run(probs, general_thresh, general_mcut_enabled, character_thresh,
-                                               character_mcut_enabled)
+                                               character_mcut_enabled, row_cap=min(512, self.selector.num_classes))
+            if int(counts.sum(axis=1).max()) > ids.shape[1]:
+                counts, ids, _ = self.selector.run(probs, general_thresh, general_mcut_enabled, character_thresh, character_mcut_enabled)
             out.extend(format_lines(self.tag_names, counts, ids))
         return out
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Development aid (gpurun only): does the ViT forward's rate depend on what the images show?  The attention kernel takes its fast path
+(softmax against a fixed reference exponent) per workgroup and repeats a query block with the classic per-tile maximum when a row sum
+leaves the window -- so the answer can be yes.  Trained-like checkpoint, batch 64, per kind of image content."""
+import io, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
+import numpy as np
+import torch
+from PIL import Image
+from hiptagsearch import synth
+from hiptagsearch.tagger import ViTTagger
+
+N = 64
+cfg = dict(synth.VIT_B16_448)
+tl = os.environ.get("TRAINED_LIKE", "1") == "1"
+model = ViTTagger(cfg, synth.vit_weights(cfg, seed=0, trained_like=tl), max_batch=N)
+rng = np.random.default_rng(3)
+sets = {"uniform noise (bench.py)": synth.images_u8(N, 448, seed=5)}
+st = synth.structured_images_u8(448, seed=77)
+for i, kind in enumerate(synth.STRUCTURED_KINDS):
+    sets[kind + " x64"] = np.repeat(st[i:i + 1], N, axis=0)
+sets["the six structured kinds mixed"] = np.concatenate([st] * 11)[:N]
+small = Image.fromarray(rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)).resize((1024, 768), Image.BICUBIC)
+a = np.asarray(small, dtype=np.int16) + rng.integers(-6, 7, (768, 1024, 3), dtype=np.int16)
+photo = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
+sq = Image.new("RGB", (1024, 1024), (255, 255, 255)); sq.paste(photo, (0, 128))
+sets["pipeline_e2e.py's picture (smooth + noise, padded) x64"] = np.repeat(np.asarray(sq.resize((448, 448), Image.BICUBIC))[None], N, axis=0)
+probs = torch.empty((N, cfg["num_classes"]), dtype=torch.float32, device="cuda")
+print("trained-like checkpoint" if tl else "random-init checkpoint")
+for name, imgs in sets.items():
+    d = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+    for _ in range(3):
+        model.forward_u8(d, probs=probs, want="probs")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        model.forward_u8(d, probs=probs, want="probs")
+    torch.cuda.synchronize()
+    print("%-58s %6.0f images/s" % (name, N * 20 / (time.perf_counter() - t0)), flush=True)
