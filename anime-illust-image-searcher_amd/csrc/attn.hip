@@ -19,6 +19,11 @@
 // are zero (buffers are cleared once and the epilogues never write there).
 #include "vit_internal.h"
 
+// head room of the half-operand reference exponent: see attn2.hip (a row's first key tile is not representative of the row -- padding,
+// background -- and a workgroup that leaves the window runs both passes)
+#ifndef HIPTS_ATTN_REF_MARGIN
+#define HIPTS_ATTN_REF_MARGIN 8
+#endif
 namespace hipts {
 namespace {
 
@@ -146,7 +151,7 @@ __device__ __forceinline__ void softmax_first(const f32x16 (&sacc)[2], bf16x8 (&
         for (int g = 0; g < GH; ++g)
 #pragma unroll
             for (int i = (g == 0 ? 1 : 0); i < 16; ++i) mx = fmaxf(mx, sacc[g][i]);
-        m_ref = fmaxf(mx, __shfl_xor(mx, 32));          // finite: tile 0 holds at least one unmasked key
+        m_ref = fmaxf(mx, __shfl_xor(mx, 32)) + (float)HIPTS_ATTN_REF_MARGIN;          // finite: tile 0 holds at least one unmasked key
     }
     float lsum0 = 0.f, lsum1 = 0.f;
 #pragma unroll
@@ -337,7 +342,7 @@ __device__ __forceinline__ bool attn_body(char* __restrict__ smem, const bf16_t*
         // 0.5 <= l < 2^15 (half) / 2^-100 <= l < 2^100 (bf16), tested on the bit pattern: positive floats order like their bits, a
         // negative value or a NaN (>= 0x7f800001, or sign bit set) falls outside whatever the compiler assumes about NaNs
         const uint32_t lb = __float_as_uint(l_tot);
-        constexpr uint32_t LO = F16 ? 0x3f000000u : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
+        constexpr uint32_t LO = F16 ? 0x3f000000u - ((uint32_t)HIPTS_ATTN_REF_MARGIN << 23) : 0x0d800000u, HI = F16 ? 0x47000000u : 0x71800000u;
         if (!(lb >= LO && lb < HI)) return true;
     }
     if (qi < tokens) {
