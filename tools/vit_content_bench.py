@@ -26,6 +26,22 @@ a = np.asarray(small, dtype=np.int16) + rng.integers(-6, 7, (768, 1024, 3), dtyp
 photo = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
 sq = Image.new("RGB", (1024, 1024), (255, 255, 255)); sq.paste(photo, (0, 128))
 sets["pipeline_e2e.py's picture (smooth + noise, padded) x64"] = np.repeat(np.asarray(sq.resize((448, 448), Image.BICUBIC))[None], N, axis=0)
+def padded(w, h, noise=6, bg=None):
+    small = Image.fromarray(rng.integers(0, 256, (max(2, h // 32), max(2, w // 32), 3), dtype=np.uint8)).resize((w, h), Image.BICUBIC)
+    a = np.asarray(small, dtype=np.int16) + rng.integers(-noise, noise + 1, (h, w, 3), dtype=np.int16)
+    im = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
+    m = max(w, h)
+    sq = Image.new("RGB", (m, m), (255, 255, 255))
+    sq.paste(im, ((m - w) // 2, (m - h) // 2))
+    return np.asarray(sq.resize((448, 448), Image.BICUBIC))
+
+
+sets["portrait picture 600 x 1000, padded x64"] = np.repeat(padded(600, 1000)[None], N, axis=0)
+sets["wide picture 1600 x 500, padded x64"] = np.repeat(padded(1600, 500)[None], N, axis=0)
+obj = np.full((448, 448, 3), 245, np.uint8)
+obj[150:300, 180:330] = padded(150, 150)[:150, :150]
+sets["small object on a flat background x64"] = np.repeat(obj[None], N, axis=0)
+sets["64 different padded pictures"] = np.stack([padded(int(rng.integers(400, 1600)), int(rng.integers(400, 1600))) for _ in range(N)])
 probs = torch.empty((N, cfg["num_classes"]), dtype=torch.float32, device="cuda")
 print("trained-like checkpoint" if tl else "random-init checkpoint")
 for name, imgs in sets.items():
