@@ -11,16 +11,23 @@ from PIL import Image
 from hiptagsearch import synth
 from hiptagsearch.tagger import ViTTagger
 
-N = 64
-cfg = dict(synth.VIT_B16_448)
+EVA = os.environ.get("MODEL") == "eva"          # MODEL=eva: EVA02-L/14 at the reference's batch of 10 x 2
+N = 20 if EVA else 64
 tl = os.environ.get("TRAINED_LIKE", "1") == "1"
-model = ViTTagger(cfg, synth.vit_weights(cfg, seed=0, trained_like=tl), max_batch=N)
+if EVA:
+    from hiptagsearch.tagger import EvaTagger
+    cfg = dict(synth.EVA02_L14_448)
+    model = EvaTagger(cfg, synth.eva_weights(cfg, 0, trained_like=tl), max_batch=N)
+else:
+    cfg = dict(synth.VIT_B16_448)
+    model = ViTTagger(cfg, synth.vit_weights(cfg, seed=0, trained_like=tl), max_batch=N)
 rng = np.random.default_rng(3)
 sets = {"uniform noise (bench.py)": synth.images_u8(N, 448, seed=5)}
 st = synth.structured_images_u8(448, seed=77)
 for i, kind in enumerate(synth.STRUCTURED_KINDS):
     sets[kind + " x64"] = np.repeat(st[i:i + 1], N, axis=0)
 sets["the six structured kinds mixed"] = np.concatenate([st] * 11)[:N]
+sets = {k: v[:N] for k, v in sets.items()}
 small = Image.fromarray(rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)).resize((1024, 768), Image.BICUBIC)
 a = np.asarray(small, dtype=np.int16) + rng.integers(-6, 7, (768, 1024, 3), dtype=np.int16)
 photo = Image.fromarray(np.clip(a, 0, 255).astype(np.uint8))
@@ -50,7 +57,8 @@ for name, imgs in sets.items():
         model.forward_u8(d, probs=probs, want="probs")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(20):
+    REP = 6 if EVA else 20
+    for _ in range(REP):
         model.forward_u8(d, probs=probs, want="probs")
     torch.cuda.synchronize()
-    print("%-58s %6.0f images/s" % (name, N * 20 / (time.perf_counter() - t0)), flush=True)
+    print("%-58s %6.0f images/s" % (name, N * REP / (time.perf_counter() - t0)), flush=True)
