@@ -121,3 +121,45 @@ def test_gen_cfeatures_cli_builds_and_extends_the_feature_index(tmp_path, monkey
         np.testing.assert_allclose(m4[21 + p4[21:].index(p)], m[i], atol=1e-5)
     r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--after", "not-a-date"], capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid date format" in r.stdout
+
+
+def test_clis_with_gpu_jpeg_write_the_same_files(tmp_path, monkeypatch):
+    """tagging.py / gen_cfeatures.py with --workers N --gpu-jpeg (entropy decoding in the workers, the rest of the JPEG decode on the
+    device): the tag file and the feature rows of the plain runs, over baseline and progressive JPEGs of three samplings, a greyscale
+    one, a PNG and a file that is not an image."""
+    from PIL import Image
+    from hiptagsearch.index import Similarity
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("imgs/sub")
+    rng = np.random.default_rng(5)
+    for i in range(14):
+        h, w = int(rng.integers(40, 400)), int(rng.integers(40, 500))
+        small = Image.fromarray(rng.integers(0, 256, (max(2, h // 16), max(2, w // 16), 3), dtype=np.uint8)).resize((w, h), Image.BICUBIC)
+        if i == 5:
+            small = small.convert("L")
+        kw = {} if i == 5 else {"subsampling": i % 3}
+        small.save("imgs/%s%02d.jpg" % ("sub/" if i % 2 else "", i), quality=70 + i, progressive=(i % 4 == 1), **kw)
+    Image.fromarray(rng.integers(0, 256, (60, 80, 4), dtype=np.uint8), "RGBA").save("imgs/alpha.png")
+    open("imgs/broken.jpg", "wb").write(b"\xff\xd8 not a jpeg")
+    tag_cli, feat_cli = os.path.join(PKG, "tagging.py"), os.path.join(PKG, "gen_cfeatures.py")
+    outs = []
+    for extra in ([], ["--workers", "2", "--gpu-resize"], ["--workers", "2", "--gpu-resize", "--gpu-jpeg"]):
+        if os.path.exists("tags-wd-tagger.txt"):
+            os.remove("tags-wd-tagger.txt")
+        r = subprocess.run([sys.executable, tag_cli, "--dir", "imgs", "--batch", "8", "--model", "vit-tiny"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(sorted(open("tags-wd-tagger.txt", encoding="utf-8").read().splitlines()))
+    assert len(outs[0]) == 15 and outs[0] == outs[1] == outs[2]
+    feats = []
+    for k, extra in enumerate(([], ["--workers", "2", "--gpu-jpeg"])):
+        for f in os.listdir("."):
+            if f.startswith("charactor-featues-idx"):
+                os.remove(f)
+        r = subprocess.run([sys.executable, feat_cli, "--dir", "imgs", "--batch", "8", "--arch", "tiny"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        paths = open("charactor-featues-idx.csv", encoding="utf-8").read().splitlines()
+        m = Similarity.load("charactor-featues-idx").matrix()
+        feats.append({p: m[i] for i, p in enumerate(paths)})
+    assert sorted(feats[0]) == sorted(feats[1]) and len(feats[0]) == 15
+    for p in feats[0]:
+        np.testing.assert_allclose(feats[1][p], feats[0][p], atol=1e-5)
