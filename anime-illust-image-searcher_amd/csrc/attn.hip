@@ -22,7 +22,7 @@
 // head room of the half-operand reference exponent: see attn2.hip (a row's first key tile is not representative of the row -- padding,
 // background -- and a workgroup that leaves the window runs both passes)
 #ifndef HIPTS_ATTN_REF_MARGIN
-#define HIPTS_ATTN_REF_MARGIN 8
+#define HIPTS_ATTN_REF_MARGIN 10
 #endif
 namespace hipts {
 namespace {
