@@ -101,6 +101,27 @@ def test_tagging_cli_vit_b16_shards_two_ranks(tmp_path):
     assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
 
 
+def test_tagging_cli_two_ranks_with_hybrid_jpeg_decode(tmp_path):
+    """Two ranks, each with its own pool of entropy-decode workers and the device half of the JPEG decode on its GPU (--gpu-jpeg): the file of
+    the single-process run with the reference's structure (8 threads, Pillow)."""
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    os.makedirs(tmp_path / "imgs" / "sub")
+    for i in range(19):
+        h, w = int(rng.integers(40, 300)), int(rng.integers(40, 360))
+        im = Image.fromarray(rng.integers(0, 256, (max(2, h // 16), max(2, w // 16), 3), dtype=np.uint8)).resize((w, h), Image.BICUBIC)
+        im.save(tmp_path / "imgs" / ("%s%03d.jpg" % ("sub/" if i % 4 == 1 else "", i)), quality=60 + 2 * i, subsampling=i % 3, progressive=(i % 5 == 2))
+    Image.fromarray(rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)).save(tmp_path / "imgs" / "plain.png")
+    cli = os.path.join(PKG, "tagging.py")
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--batch", "8", "--model", "vit-tiny"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    single = open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read()
+    assert len(single.splitlines()) == 20
+    os.remove(tmp_path / "tags-wd-tagger.txt")
+    _torchrun(2, "tagging.py", ["--dir", "imgs", "--workers", "2", "--batch", "8", "--model", "vit-tiny", "--gpu-resize", "--gpu-jpeg"], tmp_path)
+    assert open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read() == single
+
+
 def test_tagging_cli_synthetic_corpus_and_wide_rows(tmp_path):
     """--synthetic N: every rank generates its block of the benchmark corpus on its GPU (hipts_synth_images_u8, keyed by the global
     image index), so 1, 2 and 3 ranks write the same file.  With the tiny model's 200-class random-init... the trained-like head keeps
