@@ -114,30 +114,25 @@ def _worker_init(shm_name: str, slots: int, size: int, mode: str, raw_max_pixels
     _W["mode"] = mode
     _W["raw"] = raw_max_pixels
     _W["jpeg"] = load_jpeg_host_lib() if jpeg else None
-    _W["fake"] = {} if os.environ.get("HIPTS_PIPELINE_FAKE") else None
 
 
 def _worker_decode(task: Tuple[int, str]):
     """-> False (decode failed), True (model-input image in the slot), (h, w) (raw mode: the composited image at its own size) or
     (h, w, 1) (raw mode with device_jpeg: the slot holds the JPEG's coefficient blocks, csrc/jpeg_slot.h)."""
     slot, path = task
-    if _W.get("fake") is not None:      # development aid (HIPTS_PIPELINE_FAKE=1: wrong results by design): a slot is decoded once and then re-used as it is
-        hit = _W["fake"].get(slot)
-        if hit is not None:
-            return hit
     if _W.get("jpeg") is not None:
         try:
             with open(path, "rb") as f:
-                data = f.read()
+                data = f.read(2)
+                if data == b"\xff\xd8":            # a JPEG by its first marker: the whole file; anything else is left to Pillow unread
+                    data += f.read()
         except OSError:
             data = b""
-        if len(data) > 4 and data[0] == 0xFF and data[1] == 0xD8:
+        if len(data) > 4:
             row = _W["ring"][slot]
             src = np.frombuffer(data, dtype=np.uint8)
             if _W["jpeg"].hipts_jpeg_entropy_decode(src.ctypes.data, len(data), row.ctypes.data, row.nbytes) == 0:
                 hd = row[:16].view(np.int32)
-                if _W.get("fake") is not None:
-                    _W["fake"][slot] = (int(hd[3]), int(hd[2]), 1)
                 return (int(hd[3]), int(hd[2]), 1)
         # everything else -- and every file the fast path refused -- goes the way it always went
     a = decode_image(path, _W["size"], _W["mode"], _W["raw"])
@@ -234,8 +229,9 @@ class DecodePool:
                     yield [chunk[i] for i in keep], np.ascontiguousarray(view[keep])
 
     def _batches_raw(self, chunks):
-        """decode (worker processes, batch k + 2)  ||  copy + pad + resize (this producer thread, its own stream, batch k + 1)  ||  the
-        consumer's forward (caller's stream, batch k).  The hand-over is a queue of (paths, tensor, event)."""
+        """decode (worker processes, batches k + 2 and k + 3: the ring has three parts)  ||  copy + JPEG device half + pad + resize (this
+        producer thread, its own stream, batch k + 1)  ||  the consumer's forward (caller's stream, batch k).  The hand-over is a queue of
+        (paths, tensor, event)."""
         import queue
         import threading
         import torch
