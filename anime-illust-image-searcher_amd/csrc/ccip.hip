@@ -34,6 +34,7 @@ struct Block {
     DevBuf n1, n2;                 // LayerNorm gammas (no beta)
     DevBuf w_in, w_out;            // SepConv: pwconv1 [2C,C], pwconv2 [C,2C]; attention: qkv [3C,C], proj [C,C]
     DevBuf dw;                     // SepConv: depthwise weights as [49][2C] float32
+    DevBuf dwz;                    // ... and as the lane images of their Toeplitz operands, [2C][7][64] u32 (dwconv7_mfma_kernel)
     DevBuf fc1, fc2;               // [4C,C], [C,4C]
     DevBuf rs1, rs2;               // optional res_scale vectors
     bool has_rs1 = false, has_rs2 = false;
@@ -309,6 +310,257 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const bf16_t* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same depthwise 7x7 on the matrix cores (round 4; IEEE-half operands, spatial side >= 16).
+//
+// For ONE channel and ONE kernel row ky, 16 output rows x 16 output columns are a matrix product:
+//     out[y][x] += sum_k in[y + ky - 3][x0 - 4 + k] * T_ky[k][x],   T_ky[k][x] = w[ky][k - x - 1] (zero unless 0 <= k - x - 1 < 7)
+// -- a banded Toeplitz matrix of the 7 weights of that kernel row, K = 32 input columns (23 of them under the band).  Seven
+// v_mfma_f32_16x16x32_f16 per (channel, 16 x 16 outputs): 224 multiply-adds issued per output instead of 49, on units 32 times as
+// fast as the fp32 FMAs the VALU kernel is bound by (229 us per stage-0 launch at batch 32 against 55 us of bytes).
+//   * a workgroup owns CS channels and walks `tpw` tiles of 16 x 16 XT outputs.  The Toeplitz operands of its channels are built ONCE,
+//     into registers: lane (x, q) needs w[ky][8 q + i - x - 1], i = 0..7 -- a window of the zero-padded weight row whose offset depends
+//     on the lane only.  The padded row lies across the lanes of one register per (channel, ky), once with even and once with odd
+//     alignment (table built at upload, 256 B per (channel, ky)), and four ds_bpermute_b32 gather a lane's window.  (Built per tile, the
+//     gathers took as much of the LDS pipeline as the operand reads: 125 us per stage-0 launch.)
+//   * input tile: 22 rows x (16 XT + 8) columns x CS channels, staged CHANNEL-MAJOR in LDS (a plane of [row][column] halves per
+//     channel; global memory is pixel-major), two pixels of one channel per 32-bit write.  The loads of the NEXT tile are requested
+//     before the products of this one and land in registers meanwhile.  Row pitch 96 / 160 bytes: the lane groups of a ds_read_b128
+//     (MI355X_MICROARCH.md, LDS) fall on disjoint banks; the columns the band never reaches hold zeros (finite);
+//   * the input operand of (channel, x-tile t, ky): lane (m, q) reads the 8 halves at row m + ky, column 16 t + 8 q -- one ds_read_b128;
+//   * fp32 accumulators leave through LDS (the planes are dead by then) as pixel-major rows, 16-byte stores;
+//   * workgroup ids equal mod 8 share an XCD and its L2: each XCD walks a contiguous eighth of (tile group, channel slab), so the
+//     channel slabs that split a pixel's 128-byte lines and the tiles that share halo rows meet in ONE L2.
+// The weights are rounded to half (the VALU kernel multiplies by the float32 weights): tests/test_gpu_ccip.py bounds the feature error of
+// the whole encoder and checks this kernel alone against a float64 convolution; operand_f16 = 0 (bf16) keeps the VALU kernel.
+// ---------------------------------------------------------------------------------------------
+#ifndef HIPTS_DW_PREFETCH
+#define HIPTS_DW_PREFETCH 0
+#endif
+// -DHIPTS_DW_STAMPS=<workgroup>: that workgroup's first wave leaves 100 MHz time stamps of its phases (tools/dwconv_stamps.py)
+__device__ unsigned long long dw_stamps[32];
+#ifdef HIPTS_DW_STAMPS
+#define DW_STAMP(i) do { if (blockIdx.x == HIPTS_DW_STAMPS && threadIdx.x == 0 && (i) < 32) dw_stamps[i] = wall_clock64(); } while (0)
+#else
+#define DW_STAMP(i) do { } while (0)
+#endif
+template <int XT, int CS>
+struct DwMfma {
+    static constexpr int ROWS = 22;
+    static constexpr int PB = XT == 3 ? 160 : 96;            // bytes per row of a channel plane (>= (16 XT + 16) halves)
+    static constexpr int PLANE = ROWS * PB + 16;             // + 16: the eight-channel groups of the staging writes start on different banks
+    static constexpr int PAIRS = 8 * XT + 4;                 // real column pairs per row (columns x0 - 4 .. x0 + 16 XT + 3)
+    static constexpr int NP = PAIRS + 4;                     // + the zero columns the last x-tile's K range ends in
+    static constexpr int OP = CS * 2 + 16;                   // pixel pitch of the output image
+    static constexpr int LDS = CS * PLANE;
+    static_assert(XT >= 1 && XT <= 3 && (16 * XT + 16) * 2 <= PB, "row pitch");
+    static_assert(256 * XT * OP <= LDS, "the output image reuses the planes");
+};
+
+template <int XT, int CS>
+__global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const bf16_t* __restrict__ in, const uint32_t* __restrict__ tz,
+                                                           bf16_t* __restrict__ out, int H, int C, int tiles_x, int tiles_y, int ntiles,
+                                                           int tpw, int xcd_chunk) {
+    using L = DwMfma<XT, CS>;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slabs = C / CS;
+    int bid = blockIdx.x;
+    if (xcd_chunk) bid = (bid & 7) * xcd_chunk + (bid >> 3);
+    const int c0 = (bid % slabs) * CS;
+    const int t_begin = (bid / slabs) * tpw, t_end = min(t_begin + tpw, ntiles);
+    constexpr int CW = CS / 4;                               // channels of a wave
+    constexpr int G = CS / 8;                                // 16-byte channel groups of a pixel
+    constexpr int ITEMS = L::ROWS * L::NP * G, NIT = (ITEMS + 255) / 256;
+    const int m = lane & 15, kq = lane >> 4;
+
+    DW_STAMP(0);
+    // ---- Toeplitz operands of this wave's channels
+    f16x8 band[CW][7];
+    {
+        const int shift = 8 * kq - m + 15;                       // first half of this lane's window in the padded weight row (0 .. 39)
+        const int baddr = 4 * ((shift & 1) * 32 + (shift >> 1)); // lanes 0..23: even alignment, lanes 32..55: odd alignment
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc)
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const uint32_t sv = tz[((size_t)(c0 + wave * CW + cc) * 7 + ky) * 64 + lane];
+                u32x4 d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr + 4 * j, (int)sv);
+                band[cc][ky] = __builtin_bit_cast(f16x8, d);
+            }
+    }
+
+    // ---- staging: item = (row r, column pair pr, channel group g); every load of a tile is requested in one go, with clamped
+    // addresses and no branches (a predicated load is a basic block of its own and the compiler drains the queue in front of it)
+    uint4 v0[NIT], v1[NIT];
+    uint32_t okmask = 0;
+    auto request = [&](int tile) {
+        const int tx = tile % tiles_x, q = tile / tiles_x;
+        const int y0 = (q % tiles_y) * 16, x0 = tx * 16 * XT;
+        const bf16_t* img = in + ((int64_t)(q / tiles_y) * H * H) * C + c0;
+        okmask = 0;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int it = tid + u * 256;
+            const int g = it % G, pr = (it / G) % L::NP, r = it / (G * L::NP);
+            const int iy = y0 - 3 + r, ix = x0 - 4 + 2 * pr;
+            const bool rowok = it < ITEMS && pr < L::PAIRS && iy >= 0 && iy < H;
+            const bool ok0 = rowok && ix >= 0 && ix < H, ok1 = rowok && ix + 1 >= 0 && ix + 1 < H;
+            const int iyc = min(max(iy, 0), H - 1), ix0 = min(max(ix, 0), H - 1), ix1 = min(max(ix + 1, 0), H - 1);
+            v0[u] = *reinterpret_cast<const uint4*>(img + ((int64_t)iyc * H + ix0) * C + g * 8);
+            v1[u] = *reinterpret_cast<const uint4*>(img + ((int64_t)iyc * H + ix1) * C + g * 8);
+            okmask |= ((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)) << (2 * u);
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int it = tid + u * 256;
+            if (it >= ITEMS) break;
+            const int g = it % G, pr = (it / G) % L::NP, r = it / (G * L::NP);
+            char* dst = smem + (g * 8) * L::PLANE + r * L::PB + pr * 4;
+            const uint32_t k0 = (okmask >> (2 * u)) & 1u ? 0xffffffffu : 0u, k1 = (okmask >> (2 * u + 1)) & 1u ? 0xffffffffu : 0u;
+            const uint32_t a[4] = {v0[u].x & k0, v0[u].y & k0, v0[u].z & k0, v0[u].w & k0};
+            const uint32_t b[4] = {v1[u].x & k1, v1[u].y & k1, v1[u].z & k1, v1[u].w & k1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<uint32_t*>(dst + (2 * k) * L::PLANE) = (a[k] & 0xffffu) | (b[k] << 16);
+                *reinterpret_cast<uint32_t*>(dst + (2 * k + 1) * L::PLANE) = (a[k] >> 16) | (b[k] & 0xffff0000u);
+            }
+        }
+    };
+
+#if HIPTS_DW_PREFETCH
+    if (t_begin < t_end) request(t_begin);
+#endif
+    DW_STAMP(1);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int sb = 2 + 8 * (tile - t_begin);     // stamps of this tile
+        DW_STAMP(sb);
+#if !HIPTS_DW_PREFETCH
+        request(tile);      // (requested a tile ahead the registers do not fit two waves per SIMD: 75 spilled; the other workgroup of the CU fills the wait)
+#endif
+        DW_STAMP(sb + 1);
+        deposit();
+        DW_STAMP(sb + 2);
+        __syncthreads();
+        DW_STAMP(sb + 3);
+        // products: the seven operand reads of the NEXT (channel, x-tile) are in flight under the seven MFMAs of this one (read one at a
+        // time in front of its MFMA, every MFMA waited ~100 cycles for the LDS: 10.7 us per tile)
+        f32x4 acc[CW][XT];
+        f16x8 abuf[2][7];
+        const char* plane0 = smem + (wave * CW) * L::PLANE + m * L::PB + kq * 16;
+        auto fetch = [&](int buf, int idx) {
+            const char* p = plane0 + (idx / XT) * L::PLANE + (idx % XT) * 32;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) abuf[buf][ky] = *reinterpret_cast<const f16x8*>(p + ky * L::PB);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int idx = 0; idx < CW * XT; ++idx) {
+            if (idx + 1 < CW * XT) fetch((idx + 1) & 1, idx + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+                v = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[idx & 1][ky], band[idx / XT][ky], v, 0, 0, 0);      // rows 4 kq + i = output row, lane & 15 = output column
+            acc[idx / XT][idx % XT] = v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if HIPTS_DW_PREFETCH
+        if (tile + 1 < t_end) request(tile + 1);                  // lands while this tile's results leave
+#endif
+        DW_STAMP(sb + 4);
+        __syncthreads();                                          // every wave is done with the planes
+        DW_STAMP(sb + 5);
+#pragma unroll
+        for (int cp = 0; cp < CW / 2; ++cp)
+#pragma unroll
+            for (int t = 0; t < XT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pixel = (4 * kq + i) * (16 * XT) + 16 * t + m;
+                    const uint32_t lo = __builtin_bit_cast(uint16_t, (_Float16)acc[2 * cp][t][i]), hi = __builtin_bit_cast(uint16_t, (_Float16)acc[2 * cp + 1][t][i]);
+                    *reinterpret_cast<uint32_t*>(smem + pixel * L::OP + (wave * CW + 2 * cp) * 2) = lo | (hi << 16);
+                }
+        __syncthreads();
+        DW_STAMP(sb + 6);
+        {
+            const int tx = tile % tiles_x, q = tile / tiles_x;
+            const int y0 = (q % tiles_y) * 16, x0 = tx * 16 * XT;
+            bf16_t* img = out + ((int64_t)(q / tiles_y) * H * H) * C + c0;
+            static_assert((256 * XT * G) % 256 == 0, "whole passes");
+            if (y0 + 16 <= H && x0 + 16 * XT <= H) {              // uniform: a tile inside the image stores without predicates
+#pragma unroll
+                for (int u = 0; u < XT * G; ++u) {
+                    const int it = tid + u * 256;
+                    const int g = it % G, pixel = it / G;
+                    const int oy = y0 + pixel / (16 * XT), ox = x0 + pixel % (16 * XT);
+                    *reinterpret_cast<uint4*>(img + ((int64_t)oy * H + ox) * C + g * 8) = *reinterpret_cast<const uint4*>(smem + pixel * L::OP + g * 16);
+                }
+            } else {
+                for (int it = tid; it < 256 * XT * G; it += 256) {
+                    const int g = it % G, pixel = it / G;
+                    const int oy = y0 + pixel / (16 * XT), ox = x0 + pixel % (16 * XT);
+                    if (oy < H && ox < H)
+                        *reinterpret_cast<uint4*>(img + ((int64_t)oy * H + ox) * C + g * 8) = *reinterpret_cast<const uint4*>(smem + pixel * L::OP + g * 16);
+                }
+            }
+        }
+        DW_STAMP(sb + 7);
+        __syncthreads();                                          // the image is rewritten by the next tile's planes
+    }
+    DW_STAMP(31);
+}
+
+template <int XT, int CS>
+int launch_dwconv7_mfma_as(const bf16_t* in, const uint32_t* tz, bf16_t* out, int batch, int H, int C, hipStream_t s) {
+    using L = DwMfma<XT, CS>;
+    static bool once = false;
+    if (!once) {
+        HIPTS_HIP(hipFuncSetAttribute((const void*)dwconv7_mfma_kernel<XT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS));
+        once = true;
+    }
+    const int tiles_x = (H + 16 * XT - 1) / (16 * XT), tiles_y = (H + 15) / 16;
+    const int ntiles = batch * tiles_y * tiles_x, slabs = C / CS;
+    // tiles per workgroup: about four workgroups per CU over the launch, at most 8 tiles each (the Toeplitz operands are built per workgroup)
+    static const int tpw_env = getenv("HIPTS_CCIP_DW_TPW") ? atoi(getenv("HIPTS_CCIP_DW_TPW")) : 0;
+    const int tpw = tpw_env > 0 ? tpw_env : std::min(8, std::max(1, (int)(((int64_t)ntiles * slabs + 512) / 1024)));
+    const int grid = ((ntiles + tpw - 1) / tpw) * slabs;
+    static const bool plain_order = getenv("HIPTS_CCIP_DW_PLAIN_ORDER") != nullptr;
+    dwconv7_mfma_kernel<XT, CS><<<grid, 256, L::LDS, s>>>(in, tz, out, H, C, tiles_x, tiles_y, ntiles, tpw, (grid % 8 == 0 && !plain_order) ? grid / 8 : 0);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
+// mode 1: 48-column tiles where they waste no more of the side than 32-column ones; 2 / 3: forced
+int launch_dwconv7_mfma(const bf16_t* in, const uint32_t* tz, bf16_t* out, int batch, int H, int C, int mode, hipStream_t s) {
+    HIPTS_REQUIRE(C % 16 == 0, "depthwise 7x7 (matrix cores): %d channels, must be a multiple of 16", C);
+    const int waste32 = (H + 31) / 32 * 32 - H, waste48 = (H + 47) / 48 * 48 - H;
+    const bool wide = mode == 3 || (mode != 2 && waste48 <= waste32);
+    return wide ? launch_dwconv7_mfma_as<3, 16>(in, tz, out, batch, H, C, s) : launch_dwconv7_mfma_as<2, 16>(in, tz, out, batch, H, C, s);
+}
+
+// The Toeplitz operands of dwconv7_mfma_kernel from weights [channels][49]: per (channel, kernel row) the weight row rounded to half inside
+// 48 zero halves, Z[16 + kx] = w[ky][kx], as 32-bit pairs across 64 lanes -- lane L < 24: (Z[2L], Z[2L+1]); lane 32 + L, L < 24: (Z[2L+1], Z[2L+2])
+std::vector<uint32_t> dw_toeplitz_lanes(const float* w, int channels) {
+    std::vector<uint32_t> tzv((size_t)channels * 7 * 64, 0u);
+    for (int cc = 0; cc < channels; ++cc)
+        for (int ky = 0; ky < 7; ++ky) {
+            uint16_t Z[50] = {};
+            for (int kx = 0; kx < 7; ++kx) Z[16 + kx] = f32_to_f16_rne(w[(size_t)cc * 49 + ky * 7 + kx]);
+            uint32_t* row = tzv.data() + ((size_t)cc * 7 + ky) * 64;
+            for (int l = 0; l < 24; ++l) {
+                row[l] = (uint32_t)Z[2 * l] | ((uint32_t)Z[2 * l + 1] << 16);
+                row[32 + l] = (uint32_t)Z[2 * l + 1] | ((uint32_t)Z[2 * l + 2] << 16);
+            }
+        }
+    return tzv;
+}
+
 // Downsampling patch matrix: col[m'][(ky*3 + kx)*C + c] = xn[b][2 oy - 1 + ky][2 ox - 1 + kx][c] (zero outside).
 // One thread = one 16 B chunk.
 __global__ __launch_bounds__(256) void ds_im2col_kernel(const bf16_t* __restrict__ xn, bf16_t* __restrict__ col, int batch, int H,
@@ -415,6 +667,8 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     // (The e4m3 operand mode of rounds 1-3 -- operand_f16 = 2, BASELINE.json configs[4]'s "fp8 MFMA" -- was withdrawn in round 4:
     // hipts_ccip_create refuses it.  DESIGN.md section 6 has the numbers: cosine 0.968 against the float32 oracle, 1 % slower than half
     // operands, and no scaling scheme the MFMA offers lifts e4m3's three mantissa bits above 0.995 through 36 blocks.)
+    // depthwise 7x7: 0 = the VALU kernel, 1 = matrix cores with the tile shape chosen by the spatial side, 2 / 3 = 32- / 48-column tiles forced
+    static const int dw_mfma = getenv("HIPTS_CCIP_DW_MFMA") ? atoi(getenv("HIPTS_CCIP_DW_MFMA")) : 1;
     auto layernorm_xn = [&](const float* gamma, int64_t rows, int D) -> int {
         return launch_layernorm(x, gamma, nullptr, xn, rows, D, c.ln_eps, f16, s);
     };
@@ -502,7 +756,8 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 HIPTS_TRY(gemm(EPI_STAR, g, s));
                 const int tiles_x = ceil_div(H, DW_TW), tiles_y = ceil_div(H, DW_TH);
                 const int dw_grid = batch * tiles_y * tiles_x * (2 * C / DW_CS);
-                if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
+                if (f16 && H >= 16 && dw_mfma && B.dwz.p) HIPTS_TRY(launch_dwconv7_mfma(h1, B.dwz.as<uint32_t>(), h2, batch, H, 2 * C, dw_mfma, s));
+                else if (f16) dwconv7_kernel<true><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
                 else dwconv7_kernel<false><<<dw_grid, 256, DW_LDS_BYTES, s>>>(h1, B.dw.as<float>(), h2, H, 2 * C, tiles_x, tiles_y);
                 HIPTS_LAUNCH_CHECK();
                 g = GemmArgs{};
@@ -804,6 +1059,10 @@ int hipts_ccip_set_tensor(hipts_ccip_t* h, const char* key_c, const float* data,
                 for (int cc = 0; cc < 2 * C; ++cc)
                     for (int tp = 0; tp < 49; ++tp) w2[(size_t)tp * 2 * C + cc] = data[(size_t)cc * 49 + tp];
                 st = upload_f32(B.dw, w2.data(), w2.size());
+                if (st == HIPTS_OK && f16) {
+                    const std::vector<uint32_t> tzv = dw_toeplitz_lanes(data, 2 * C);
+                    st = upload_f32(B.dwz, reinterpret_cast<const float*>(tzv.data()), tzv.size());
+                }
             }
             else if (B.attn && t == "token_mixer.qkv.weight") {
                 EXPECT((int64_t)3 * C * C);
@@ -835,6 +1094,53 @@ int hipts_ccip_forward_f32(hipts_ccip_t* h, const float* x, int x_memspace, int 
 int hipts_ccip_flops_per_image(const hipts_ccip_t* h, double* flops) {
     HIPTS_REQUIRE(h && flops, "null argument");
     *flops = h->flops_per_image;
+    return HIPTS_OK;
+}
+
+// Debug / test entry (include/hip_tagsearch_debug.h): the depthwise 7x7 of a SepConv block on its own.
+int hiptsdbg_dwconv7(const uint16_t* in_f16, const float* w, uint16_t* out_f16, int batch, int H, int C, int mode, int iters, float* ms_out) {
+    HIPTS_REQUIRE(in_f16 && w && out_f16 && batch >= 1 && H >= 1 && C >= 64 && C % 64 == 0 && mode >= 0 && mode <= 3, "hiptsdbg_dwconv7: bad argument");
+    HIPTS_REQUIRE(mode == 0 || H >= 16, "hiptsdbg_dwconv7: the matrix-core kernel needs a side of 16 or more");
+    const size_t n = (size_t)batch * H * H * C;
+    DevBuf in, out, wv, tz;
+    HIPTS_TRY(in.alloc(n * 2));
+    HIPTS_TRY(out.alloc(n * 2));
+    HIPTS_TRY(upload(in.p, in_f16, n * 2));
+    std::vector<float> w2((size_t)49 * C);
+    for (int cc = 0; cc < C; ++cc)
+        for (int tp = 0; tp < 49; ++tp) w2[(size_t)tp * C + cc] = w[(size_t)cc * 49 + tp];
+    HIPTS_TRY(upload_f32(wv, w2.data(), w2.size()));
+    const std::vector<uint32_t> tzv = dw_toeplitz_lanes(w, C);
+    HIPTS_TRY(upload_f32(tz, reinterpret_cast<const float*>(tzv.data()), tzv.size()));
+    hipEvent_t e0, e1;
+    HIPTS_HIP(hipEventCreate(&e0));
+    HIPTS_HIP(hipEventCreate(&e1));
+    const int tiles_x = ceil_div(H, DW_TW), tiles_y = ceil_div(H, DW_TH);
+    for (int it = 0; it <= iters; ++it) {
+        if (it == 1) HIPTS_HIP(hipEventRecord(e0, nullptr));
+        if (mode == 0) {
+            dwconv7_kernel<true><<<batch * tiles_y * tiles_x * (C / DW_CS), 256, DW_LDS_BYTES, nullptr>>>(in.as<bf16_t>(), wv.as<float>(), out.as<bf16_t>(), H, C, tiles_x, tiles_y);
+            HIPTS_LAUNCH_CHECK();
+        } else {
+            HIPTS_TRY(launch_dwconv7_mfma(in.as<bf16_t>(), tz.as<uint32_t>(), out.as<bf16_t>(), batch, H, C, mode, nullptr));
+        }
+    }
+    HIPTS_HIP(hipEventRecord(e1, nullptr));
+    HIPTS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    if (iters > 0) HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = iters > 0 ? ms / iters : 0.f;
+    HIPTS_HIP(hipEventDestroy(e0));
+    HIPTS_HIP(hipEventDestroy(e1));
+    HIPTS_HIP(hipMemcpy(out_f16, out.p, n * 2, hipMemcpyDeviceToHost));
+    return HIPTS_OK;
+}
+
+// the stamps of a -DHIPTS_DW_STAMPS build (zeros otherwise): [0] start, [1] operands built, then per tile 8 stamps from [2]: start, loads
+// requested, planes written, barrier, products done, barrier, results in LDS + barrier, stores issued; [31] end
+int hiptsdbg_dwconv7_stamps(unsigned long long* host, int n) {
+    HIPTS_REQUIRE(host && n >= 1 && n <= 32, "hiptsdbg_dwconv7_stamps: bad argument");
+    HIPTS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(dw_stamps), (size_t)n * 8));
     return HIPTS_OK;
 }
 

@@ -24,6 +24,13 @@ int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out);
 int hiptsdbg_gemm_clock(int M, int N, int K, int epi, int iters, float* ms_out, float* loop_ghz);
 /* y_host[i] = the GELU of the fc1 epilogue (csrc/gemm.hip gelu_f4) of x_host[i]; n % 4 == 0; tanh_form as hipts_vit_config::gelu_tanh. */
 int hiptsdbg_gelu(const float* x_host, int n, int tanh_form, float* y_host);
+/* The depthwise 7 x 7 (padding 3) of the CCIP encoder's SepConv blocks on its own: in / out IEEE-half bit patterns [batch][H][H][C] (host),
+ * w float32 [C][49]; mode 0: the float32-FMA kernel, 1: the matrix-core kernel with its tile chosen by H, 2 / 3: its 32- / 48-column tile;
+ * ms_out: average device time of `iters` launches after one untimed launch. */
+int hiptsdbg_dwconv7(const uint16_t* in_f16, const float* w, uint16_t* out_f16, int batch, int H, int C, int mode, int iters, float* ms_out);
+/* Phase time stamps (100 MHz) of one workgroup of the matrix-core kernel's last launch; zeros unless csrc/ccip.hip was built with
+ * -DHIPTS_DW_STAMPS=<workgroup> (tools/dwconv_stamps.py). */
+int hiptsdbg_dwconv7_stamps(unsigned long long* host, int n);
 /* out_host float32 [M][N] = A W^T for bf16 bit patterns a_bf16 [M][K], w_bf16 [N][K] (plain epilogue). */
 int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host);
 /* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in

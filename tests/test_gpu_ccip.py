@@ -114,3 +114,51 @@ def test_ccip_two_sub_batch_streams_match_single_stream():
     np.testing.assert_array_equal(enc.forward_u8(imgs), got)
     small = CCIPEncoder(cfg, w, max_batch=8)                      # batches of 8: one stream
     np.testing.assert_array_equal(small.forward_u8(imgs), got)
+
+
+def _dwconv7_f64(x_f16, w, half_weights):
+    """out[b][y][x][c] = sum_{ky,kx} in[b][y+ky-3][x+kx-3][c] * w[c][ky*7+kx] in float64 (the timm SepConv's depthwise conv,
+    MetaFormer `SepConv.dwconv`: padding 3, no bias); half_weights: the weights as the matrix-core kernel holds them."""
+    x = x_f16.astype(np.float64)
+    wk = (w.astype(np.float16) if half_weights else w).astype(np.float64)
+    B, H, _, C = x.shape
+    xp = np.zeros((B, H + 6, H + 6, C))
+    xp[:, 3:H + 3, 3:H + 3] = x
+    out = np.zeros_like(x)
+    for ky in range(7):
+        for kx in range(7):
+            out += xp[:, ky:ky + H, kx:kx + H] * wk[:, ky * 7 + kx]
+    return out
+
+
+@pytest.mark.parametrize("H,C,mode", [(16, 64, 1), (24, 128, 2), (48, 64, 3), (50, 64, 2), (50, 64, 3), (96, 64, 1), (33, 64, 1), (9, 64, 0), (24, 128, 0)])
+def test_dwconv7_kernels_against_float64(H, C, mode):
+    """The depthwise 7x7 on its own (hiptsdbg_dwconv7): the float32-FMA kernel (mode 0) and the matrix-core kernel (Toeplitz operands,
+    32- and 48-column tiles; sides that are not multiples of the tile, borders inside the first and last tile) against a float64
+    convolution of the same half inputs -- with the weights rounded to half for the matrix-core kernel, which is its only deviation.
+    The half outputs may differ from the rounded float64 sums by one unit in the last place (float32 accumulation order)."""
+    import ctypes, os, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
+    from hiptagsearch import _lib
+    lib = _lib.load()
+    f = lib.hiptsdbg_dwconv7
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    rng = np.random.default_rng(H * 1000 + C + mode)
+    B = 3
+    x = rng.standard_normal((B, H, H, C)).astype(np.float16)
+    x[0, 0, 0, :] = 7.0                                  # corners: a wrong halo shows here first
+    x[1, H - 1, H - 1, :] = -5.0
+    w = (rng.standard_normal((C, 49)) * 0.2).astype(np.float32)
+    out = np.empty_like(x)
+    st = f(x.ctypes.data, w.ctypes.data, out.ctypes.data, B, H, C, mode, 0, None)
+    assert st == 0, _lib.last_error()
+    want = _dwconv7_f64(x, w, half_weights=mode != 0)
+    ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float64)
+    err = np.abs(out.astype(np.float64) - want)
+    assert np.isfinite(out).all()
+    assert (err <= 0.5 * ulp + 2e-6 * np.abs(want) + 1e-6).all(), (err.max(), np.unravel_index(err.argmax(), err.shape))
+    if mode != 0:      # and the two kernels agree to the weight rounding: |dw| <= 2^-12 |w| per tap
+        ref = np.empty_like(x)
+        assert f(x.ctypes.data, w.ctypes.data, ref.ctypes.data, B, H, C, 0, 0, None) == 0
+        assert np.abs(out.astype(np.float64) - ref.astype(np.float64)).max() <= 2e-2
