@@ -36,6 +36,8 @@ struct Block {
     DevBuf dw;                     // SepConv: depthwise weights as [49][2C] float32
     DevBuf dwz;                    // ... and as the lane images of their Toeplitz operands, [2C][7][64] u32 (dwconv7_mfma_kernel)
     DevBuf fc1, fc2;               // [4C,C], [C,4C]
+    DevBuf mlp_img;                // the two as the chunk images of the fused MLP kernel (mlp.hip; widths 128 / 256, half operands)
+    std::vector<float> fc1_host, fc2_host;      // host copies (stages 0-1: 15 MB in all): the image is rebuilt whenever either tensor is set again
     DevBuf rs1, rs2;               // optional res_scale vectors
     bool has_rs1 = false, has_rs2 = false;
     float s1 = 1.f, b1 = 0.f;      // token-mixer StarReLU
@@ -669,6 +671,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     // operands, and no scaling scheme the MFMA offers lifts e4m3's three mantissa bits above 0.995 through 36 blocks.)
     // depthwise 7x7: 0 = the VALU kernel, 1 = matrix cores with the tile shape chosen by the spatial side, 2 / 3 = 32- / 48-column tiles forced
     static const int dw_mfma = getenv("HIPTS_CCIP_DW_MFMA") ? atoi(getenv("HIPTS_CCIP_DW_MFMA")) : 1;
+    static const bool fused_mlp = !(getenv("HIPTS_CCIP_FUSED_MLP") && atoi(getenv("HIPTS_CCIP_FUSED_MLP")) == 0);      // A/B: 0 = fc1 and fc2 as two GEMM launches
     auto layernorm_xn = [&](const float* gamma, int64_t rows, int D) -> int {
         return launch_layernorm(x, gamma, nullptr, xn, rows, D, c.ln_eps, f16, s);
     };
@@ -792,6 +795,13 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
             }
             // MLP: fc1 + StarReLU, fc2 + residual
             if (!fuse_ln) HIPTS_TRY(layernorm_xn(B.n2.as<float>(), M, C));
+            if (fused_mlp && fuse_ln && f16 && B.mlp_img.p) {
+                // stages 0-1 (rows of <= 256 columns): one kernel, the hidden tensor stays in registers (mlp.hip)
+                const bool fuse_next = next_gamma != nullptr;
+                HIPTS_TRY(launch_mlp_fused(xn, B.mlp_img.p, x, B.has_rs2 ? B.rs2.as<float>() : nullptr, next_gamma, xn, M, C, B.s2, B.b2, c.ln_eps, s));
+                xn_ready = fuse_next;
+                continue;
+            }
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
@@ -1045,8 +1055,19 @@ int hipts_ccip_set_tensor(hipts_ccip_t* h, const char* key_c, const float* data,
             else if (t == "norm2.weight") { EXPECT(C); st = upload_f32(B.n2, data, C); }
             else if (t == "res_scale1.scale") { EXPECT(C); st = upload_f32(B.rs1, data, C); B.has_rs1 = true; }
             else if (t == "res_scale2.scale") { EXPECT(C); st = upload_f32(B.rs2, data, C); B.has_rs2 = true; }
-            else if (t == "mlp.fc1.weight") { EXPECT((int64_t)4 * C * C); st = up(B.fc1, 4 * C, C, round_up(4 * C, 256)); }
-            else if (t == "mlp.fc2.weight") { EXPECT((int64_t)4 * C * C); st = up(B.fc2, C, 4 * C, round_up(C, 256)); }
+            else if (t == "mlp.fc1.weight" || t == "mlp.fc2.weight") {
+                EXPECT((int64_t)4 * C * C);
+                const bool first = t == "mlp.fc1.weight";
+                st = first ? up(B.fc1, 4 * C, C, round_up(4 * C, 256)) : up(B.fc2, C, 4 * C, round_up(C, 256));
+                if (st == HIPTS_OK && f16 && mlp_fused_supports(C)) {
+                    (first ? B.fc1_host : B.fc2_host).assign(data, data + (size_t)4 * C * C);
+                    if (!B.fc1_host.empty() && !B.fc2_host.empty()) {
+                        const std::vector<uint16_t> img = mlp_weight_image(B.fc1_host.data(), B.fc2_host.data(), C);
+                        st = B.mlp_img.alloc(img.size() * 2);
+                        if (st == HIPTS_OK) st = upload(B.mlp_img.p, img.data(), img.size() * 2);
+                    }
+                }
+            }
             else if (t == "mlp.act.scale") { EXPECT(1); B.s2 = data[0]; }
             else if (t == "mlp.act.bias") { EXPECT(1); B.b2 = data[0]; }
             else if (!B.attn && t == "token_mixer.pwconv1.weight") { EXPECT((int64_t)2 * C * C); st = upload_matrix16(B.w_in, data, 2 * C, C, round_up(2 * C, 256), f16); }

@@ -308,6 +308,11 @@ int launch_rowstat(const float* part, float* rowstat, int M, int stride, int blo
 // u[n] = sum_k W[n][k] gamma[k], c[n] = sum_k W[n][k] beta[k] + bias[n] (beta / bias may be null) from the uploaded 16-bit W
 int launch_fold_ln(const bf16_t* W, bool f16, const float* gamma, const float* beta, const float* bias, float* u, float* c, int N, int K,
                    hipStream_t s);
+// mlp.hip: fc1 -> StarReLU -> fc2 -> scaled residual -> LayerNorm of a CAFormer block in one kernel (C = 128 / 256, hidden 4 C; xn_out may be xn)
+std::vector<uint16_t> mlp_weight_image(const float* w1, const float* w2, int C);
+bool mlp_fused_supports(int C);
+int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* res_scale, const float* gamma, bf16_t* xn_out, int M, int C,
+                     float star_s, float star_b, float eps, hipStream_t s);
 // the same with e4m3 output bytes (the A operand of an op8 GEMM)
 int launch_layernorm8(const float* x, const float* g, const float* b, uint8_t* out, int64_t rows, int D, float eps, hipStream_t s);
 

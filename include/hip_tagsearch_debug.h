@@ -31,6 +31,11 @@ int hiptsdbg_dwconv7(const uint16_t* in_f16, const float* w, uint16_t* out_f16, 
 /* Phase time stamps (100 MHz) of one workgroup of the matrix-core kernel's last launch; zeros unless csrc/ccip.hip was built with
  * -DHIPTS_DW_STAMPS=<workgroup> (tools/dwconv_stamps.py). */
 int hiptsdbg_dwconv7_stamps(unsigned long long* host, int n);
+/* The fused MLP of the CCIP encoder's stages 0-1 on its own (csrc/mlp.hip): x[m] = rs * x[m] + StarReLU(xn[m] W1^T) W2^T, xn_out[m] = LayerNorm(x[m]) * gamma.
+ * Host arrays: xn / xn_out IEEE-half bits [M][C], w1 [4C][C], w2 [C][4C], x [M][C] in / out, res_scale / gamma [C] or null; C = 128 or 256;
+ * ms_out: average device time of iters - 1 launches (iters >= 2). */
+int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const float* w2, float* x, const float* res_scale, const float* gamma, uint16_t* xn_out,
+                       int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out);
 /* out_host float32 [M][N] = A W^T for bf16 bit patterns a_bf16 [M][K], w_bf16 [N][K] (plain epilogue). */
 int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host);
 /* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in

@@ -162,3 +162,45 @@ def test_dwconv7_kernels_against_float64(H, C, mode):
         ref = np.empty_like(x)
         assert f(x.ctypes.data, w.ctypes.data, ref.ctypes.data, B, H, C, 0, 0, None) == 0
         assert np.abs(out.astype(np.float64) - ref.astype(np.float64)).max() <= 2e-2
+
+
+@pytest.mark.parametrize("M,C,with_rs,with_ln", [(300, 128, True, True), (512, 256, True, True), (37, 256, False, True), (256, 128, False, False), (1000, 256, True, False)])
+def test_mlp_fused_against_float64(M, C, with_rs, with_ln):
+    """The fused MLP kernel alone (csrc/mlp.hip through hiptsdbg_mlp_fused; the MetaFormer `Mlp` + scaled residual + next LayerNorm):
+    x = rs * x + StarReLU(xn W1^T) W2^T against float64 with the kernel's roundings (half weights, hidden activations rounded to half),
+    row counts that are no multiple of a wave's 32 or a workgroup's 256 rows."""
+    import ctypes, os, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
+    from hiptagsearch import _lib
+    lib = _lib.load()
+    f = lib.hiptsdbg_mlp_fused
+    f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    rng = np.random.default_rng(M + C)
+    xn = rng.standard_normal((M, C)).astype(np.float16)
+    w1 = (rng.standard_normal((4 * C, C)) / np.sqrt(C)).astype(np.float32)
+    w2 = (rng.standard_normal((C, 4 * C)) / np.sqrt(4 * C)).astype(np.float32)
+    x = rng.standard_normal((M, C)).astype(np.float32) * 2
+    rs = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    g = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    s, b, eps = 0.8944, -0.4472, 1e-6
+    S = (xn.astype(np.float64) @ w1.astype(np.float16).astype(np.float64).T).astype(np.float32)
+    r = np.maximum(S, np.float32(0))
+    P = (r * r * np.float32(s) + np.float32(b)).astype(np.float16)
+    O = P.astype(np.float64) @ w2.astype(np.float16).astype(np.float64).T
+    want = (x.astype(np.float64) * rs if with_rs else x.astype(np.float64)) + O
+    got = x.copy()
+    xo = np.zeros((M, C), dtype=np.float16)
+    st = f(xn.ctypes.data, w1.ctypes.data, w2.ctypes.data, got.ctypes.data, rs.ctypes.data if with_rs else None, g.ctypes.data if with_ln else None,
+           xo.ctypes.data, M, C, s, b, eps, 0, None)
+    assert st == 0, _lib.last_error()
+    # a hidden value that lands on a rounding boundary of half may round the other way under another summation order: 2^-11 relative on one
+    # of 4C terms -- far below the bound
+    err = np.abs(got - want).max()
+    print("fused MLP M=%d C=%d: max |dx| = %.3e (|x| ~ %.2f)" % (M, C, err, np.abs(want).mean()))
+    assert err <= 2e-3, err
+    if with_ln:
+        mu = want.mean(1, keepdims=True)
+        ln = (want - mu) / np.sqrt(((want - mu) ** 2).mean(1, keepdims=True) + eps) * g
+        e2 = np.abs(xo.astype(np.float64) - ln).max()
+        assert e2 <= 4e-3, e2
