@@ -14,8 +14,9 @@
 //     the eight K-elements of the second operand of  O^T += W2[:, chunk] . P^T.  W2's hidden index is permuted at upload to the order
 //     in which the accumulator hands them over (within a chunk: position 8 q + e <-> hidden 16 (e >> 2) + 4 q + (e & 3));
 //   * the weights of a chunk are one contiguous, LDS-shaped image in global memory (row pitches 2 C + 32 and 96 bytes: conflict-free
-//     ds_read_b128), copied by LDS-DMA two chunks deep; one barrier per chunk for the eight waves (256 rows) of a workgroup;
-//   * epilogue: residual read-modify-write of the fp32 stream, LayerNorm within the four lanes that hold a row.
+//     ds_read_b128), copied by LDS-DMA into a ring of four buffers, a piece at a time between the MFMAs, two chunks ahead of its barrier; one barrier per chunk for the eight waves (256 rows) of a workgroup;
+//   * the accumulators START as rs * x (the wave's rows of the fp32 stream, requested at kernel start); epilogue: store them, LayerNorm
+//     within the four lanes that hold a row.
 // Numerics: the same roundings as the two launches (half P, fp32 accumulation; the hidden units are summed in another order).
 #include <cstdlib>
 #include <type_traits>
@@ -39,6 +40,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// -DHIPTS_MLP_STAMPS=<workgroup>: wave 0 of that workgroup leaves 100 MHz time stamps of chunk 8's phases (tools/mlp_stamps.py)
+__device__ unsigned long long mlp_stamps[16];
+#ifdef HIPTS_MLP_STAMPS
+#define MLP_STAMP(i) do { if (blockIdx.x == HIPTS_MLP_STAMPS && threadIdx.x == 0 && j == 8) mlp_stamps[i] = wall_clock64(); } while (0)
+#define MLP_STAMP_AT(i) do { if (blockIdx.x == HIPTS_MLP_STAMPS && threadIdx.x == 0) mlp_stamps[i] = wall_clock64(); } while (0)
+#else
+#define MLP_STAMP(i) do { } while (0)
+#define MLP_STAMP_AT(i) do { } while (0)
+#endif
 template <int OFF>
 __device__ __forceinline__ void lds_read16(f16x8& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
@@ -53,9 +63,9 @@ template <int C>
 struct MlpImg {
     static constexpr int HC = 32;                          // hidden units per chunk
     static constexpr int P1 = 2 * C + 32;                  // bytes per W1 row (C halves) in the image
-    static constexpr int P2 = 96;                          // bytes per W2 row (32 halves)
+    static constexpr int P2 = 80;                          // bytes per W2 row (32 halves): two-way conflicts on 16 reads per chunk, and FOUR chunk buffers fit (96: none, three)
     static constexpr int W2_OFF = HC * P1;
-    static constexpr int BYTES = HC * P1 + C * P2;         // 21 504 (C = 128) / 41 984 (C = 256): whole KiB
+    static constexpr int BYTES = HC * P1 + C * P2;         // 19 456 (C = 128) / 37 888 (C = 256): whole KiB
     static_assert(BYTES % 1024 == 0, "the image is copied in 1 KiB pieces");
 };
 
@@ -76,12 +86,18 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
     static_assert(RF == 2, "the issue fences below name two accumulators");
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    auto copy_chunk = [&](int j) {          // wave w copies the 1 KiB pieces w, w + 8, ...
-        const char* src = wimg + (size_t)j * I::BYTES;
-        char* dst = smem + (j & 1) * I::BYTES;
-        for (int p = wave; p < I::BYTES / 1024; p += 8) glds16(src + p * 1024 + lane * 16, dst + p * 1024);
+    MLP_STAMP_AT(8);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // in a scalar register: no divergent control flow around the copies
+    constexpr int NBUF = 4, NP = I::BYTES / 1024, PER = (NP + 7) / 8;
+    // piece i of this wave for chunk j: the 1 KiB pieces w, w + 8, ...; every wave issues PER of them (the last ones twice: the same bytes),
+    // so that "PER copies outstanding" means the same in every wave
+    auto copy_piece = [&](int j, int slot, int i) {
+        const int p = min(wave_u + 8 * i, NP - 1);
+        glds16(wimg + (size_t)j * I::BYTES + p * 1024 + lane * 16, smem + slot * I::BYTES + p * 1024);
     };
-    copy_chunk(0);
+    for (int j = 0; j < 3 && j < chunks; ++j)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) copy_piece(j, j, i);
 
     // the wave's rows as second operands: lane (m, q) holds xn[row][32 ks + 8 q ..+7]
     f16x8 xf[RF][KS];
@@ -91,39 +107,53 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[rf][ks] = *reinterpret_cast<const f16x8*>(xn + (size_t)row * C + ks * 32 + kq * 8);
     }
+    // the accumulators start as the wave's rows of the residual stream (requested now, needed at the first second product): read in the
+    // epilogue, every workgroup of the chip asked for its 256 KB at the same moment and waited 28 us for them (stage 1)
     f32x4 O[CF][RF];
 #pragma unroll
-    for (int cf = 0; cf < CF; ++cf)
+    for (int rf = 0; rf < RF; ++rf) {
+        const float* xr = x + (size_t)min(row0 + rf * 16 + lr, M - 1) * C + 4 * kq;
 #pragma unroll
-        for (int rf = 0; rf < RF; ++rf) O[cf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cf = 0; cf < CF; ++cf) O[cf][rf] = *reinterpret_cast<const f32x4*>(xr + cf * 16);
+    }
 
-    for (int j = 0; j < chunks; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of chunk j (and, the first time, its rows)
-        __syncthreads();                                           // everybody's pieces; everybody is done with chunk j - 1's buffer
-        if (j + 1 < chunks) copy_chunk(j + 1);
-        // Operand reads run RING - 1 fragments ahead of the MFMAs that use them, through inline asm with counted waits: written as plain
-        // loads the compiler put s_waitcnt lgkmcnt(0) in front of every second or fourth pair of MFMAs (420 TFLOP/s).  Step t < 2 KS:
-        // W1 fragment (hf = t & 1, ks = t >> 1); step 2 KS + cf: W2 fragment cf; slot t % RING.  Nothing else in the loop touches
-        // LGKM (no scalar loads, no other LDS operation), so "RING - 1 younger reads outstanding" is exact.
-        constexpr int RING = HIPTS_MLP_RING, T = 2 * KS + CF;
-        const uint32_t a1 = lds_base + (j & 1) * I::BYTES + lr * I::P1 + kq * 16;
-        const uint32_t a2 = lds_base + (j & 1) * I::BYTES + I::W2_OFF + lr * I::P2 + kq * 16;
-        f16x8 w[RING];
+    // Operand reads run RING - 1 fragments ahead of the MFMAs that use them, through inline asm with counted waits: written as plain
+    // loads the compiler put s_waitcnt lgkmcnt(0) in front of every second or fourth pair of MFMAs (420 TFLOP/s).  Step t < 2 KS: W1
+    // fragment (hf = t & 1, ks = t >> 1); step 2 KS + cf: W2 fragment cf; slot t % RING; steps past T are the first of the NEXT chunk --
+    // four chunk buffers, and the barrier that ends chunk j has every wave's pieces of chunk j + 2, so the ring never drains between
+    // chunks.  Nothing else in the loop touches LGKM (no scalar loads, no other LDS operation): "RING - 1 younger reads outstanding" is exact.
+    constexpr int RING = HIPTS_MLP_RING, T = 2 * KS + CF;
+    static_assert(T % RING == 0 && RING <= 2 * KS && PER <= KS, "ring slots continue across chunks; the copies fit the first product");
+    const uint32_t lane_w1 = lr * I::P1 + kq * 16, lane_w2 = I::W2_OFF + lr * I::P2 + kq * 16;
+    f16x8 w[RING];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of chunks 0 .. 2, and its rows
+    __builtin_amdgcn_s_barrier();
+    static_for<0, RING>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        lds_read16<(t & 1) * 16 * I::P1 + (t >> 1) * 64>(w[t], lds_base + lane_w1);
+    });
+    auto chunk = [&](auto first_tag, auto last_tag, int j, int slot) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        const int slot1 = (slot + 1) & (NBUF - 1), slot3 = (slot + 3) & (NBUF - 1);
+        const bool copying = !LAST && j + 3 < chunks;          // chunk j + 3 into the buffer that held chunk j - 1 (every wave is past the barrier that ended it)
+        MLP_STAMP(0);
+        const uint32_t a1 = lds_base + slot * I::BYTES + lane_w1, a2 = lds_base + slot * I::BYTES + lane_w2, n1 = lds_base + slot1 * I::BYTES + lane_w1;
         auto read = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if constexpr (t < 2 * KS) lds_read16<(t & 1) * 16 * I::P1 + (t >> 1) * 64>(w[t % RING], a1);
             else if constexpr (t < T) lds_read16<(t - 2 * KS) * 16 * I::P2>(w[t % RING], a2);
+            else if constexpr (!LAST) lds_read16<((t - T) & 1) * 16 * I::P1 + ((t - T) >> 1) * 64>(w[t % RING], n1);
         };
-        auto wait = [&](auto tc) {          // until the read of step t has landed: min(RING - 1, T - 1 - t) younger reads may be outstanding
-            constexpr int t = decltype(tc)::value, n = (T - 1 - t) < (RING - 1) ? (T - 1 - t) : (RING - 1);
+        auto wait = [&](auto tc) {          // until the read of step t has landed
+            constexpr int t = decltype(tc)::value, n = (LAST && (T - 1 - t) < (RING - 1)) ? (T - 1 - t) : (RING - 1);
             lds_wait<n>(w[t % RING]);
         };
+        MLP_STAMP(1);
         f32x4 S[2][RF];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int rf = 0; rf < RF; ++rf) S[hf][rf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        static_for<0, RING>([&](auto tc) { read(tc); });
         static_for<0, 2 * KS>([&](auto tc) {
             constexpr int t = decltype(tc)::value, hf = t & 1, ks = t >> 1;
             wait(tc);
@@ -132,7 +162,11 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
             // the slot is rewritten by the next read: the MFMAs above must have been issued (they read their operands at issue)
             issue_fence(S[hf][0], S[hf][1]);
             read(std::integral_constant<int, t + RING>{});
+            if constexpr (!LAST && t % 2 == 1 && t / 2 < PER) {          // one piece of the copy behind every second pair of MFMAs
+                if (copying) copy_piece(j + 3, slot3, t / 2);
+            }
         });
+        MLP_STAMP(2);
         f16x8 P[RF];
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf) {
@@ -144,6 +178,17 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
                 for (int i = 0; i < 4; ++i) P[rf][hf * 4 + i] = (_Float16)v[i];
             }
         }
+        MLP_STAMP(3);
+        if constexpr (FIRST) {          // x * res_scale before the first accumulation (the compiler waits for the rows here)
+            if (res_scale) {
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+                    const f32x4 rsv = *reinterpret_cast<const f32x4*>(res_scale + cf * 16 + 4 * kq);
+#pragma unroll
+                    for (int rf = 0; rf < RF; ++rf) O[cf][rf] = O[cf][rf] * rsv;
+                }
+            }
+        }
         static_for<0, CF>([&](auto cc) {
             constexpr int cf = decltype(cc)::value, t = 2 * KS + cf;
             wait(std::integral_constant<int, t>{});
@@ -152,7 +197,24 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
             issue_fence(O[cf][0], O[cf][1]);
             read(std::integral_constant<int, t + RING>{});
         });
+        MLP_STAMP(4);
+        if constexpr (!LAST) {
+            // this wave's pieces of chunk j + 2 (requested a chunk ago); those of chunk j + 3 stay in flight
+            if (copying) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MLP_STAMP(5);
+            __builtin_amdgcn_s_barrier();                              // everybody's; and everybody is done with chunk j's buffer
+            MLP_STAMP(6);
+        }
+    };
+    chunk(std::true_type{}, std::false_type{}, 0, 0);          // chunks >= 16
+    int slot = 1;
+    for (int j = 1; j + 1 < chunks; ++j) {
+        chunk(std::false_type{}, std::false_type{}, j, slot);
+        slot = (slot + 1) & (NBUF - 1);
     }
+    chunk(std::false_type{}, std::true_type{}, chunks - 1, slot);
+    MLP_STAMP_AT(9);
 
     // ---- epilogue: lane (m = lr, q) holds columns 16 cf + 4 q ..+3 of row rf * 16 + m.  A wave whose 32 rows all exist (uniform) stores
     // without predicates: a predicated store is a basic block of its own, entered through s_waitcnt vmcnt(0)
@@ -163,17 +225,11 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
             const int row = row0 + rf * 16 + lr;
             const bool ok = FULL || row < M;
             float* xr = x + (size_t)(ok ? row : M - 1) * C + 4 * kq;
-            f32x4 xo[CF];
-#pragma unroll
-            for (int cf = 0; cf < CF; ++cf) xo[cf] = *reinterpret_cast<const f32x4*>(xr + cf * 16);
             float s1 = 0.f;
 #pragma unroll
             for (int cf = 0; cf < CF; ++cf) {
-                f32x4 v;
-                if (res_scale) v = xo[cf] * *reinterpret_cast<const f32x4*>(res_scale + cf * 16 + 4 * kq) + O[cf][rf];
-                else v = xo[cf] + O[cf][rf];
+                const f32x4 v = O[cf][rf];          // rs * x + the products
                 if (FULL || ok) *reinterpret_cast<f32x4*>(xr + cf * 16) = v;
-                O[cf][rf] = v;
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
             }
             if (gamma) {
@@ -204,13 +260,14 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
     };
     if (row0 + 32 <= M) finish(std::true_type{});
     else finish(std::false_type{});
+    MLP_STAMP_AT(10);
 }
 
 }  // namespace
 
 // The weights of a fused MLP as the kernel's chunk images (half): w1 [4C][C], w2 [C][4C] float32 on the host.
 std::vector<uint16_t> mlp_weight_image(const float* w1, const float* w2, int C) {
-    const int hid = 4 * C, P1 = 2 * C + 32, P2 = 96, bytes = 32 * P1 + C * P2;
+    const int hid = 4 * C, P1 = 2 * C + 32, P2 = 80, bytes = 32 * P1 + C * P2;
     std::vector<uint16_t> img((size_t)(hid / 32) * bytes / 2, 0);
     for (int j = 0; j < hid / 32; ++j) {
         uint16_t* base = img.data() + (size_t)j * bytes / 2;
@@ -234,12 +291,12 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
     const int grid = (M + 255) / 256, chunks = 4 * C / 32;
     static bool once = false;
     if (!once) {
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<128>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<256>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
         once = true;
     }
-    if (C == 128) mlp_fused_kernel<128><<<grid, 512, 2 * MlpImg<128>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
-    else mlp_fused_kernel<256><<<grid, 512, 2 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
+    if (C == 128) mlp_fused_kernel<128><<<grid, 512, 4 * MlpImg<128>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
+    else mlp_fused_kernel<256><<<grid, 512, 4 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
@@ -248,6 +305,14 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
 
 // Debug / test entry (include/hip_tagsearch_debug.h): the fused MLP on its own.  Host arrays: xn IEEE-half bits [M][C], w1 [4C][C], w2 [C][4C],
 // x [M][C] (in / out), res_scale [C] or null, gamma [C] or null (then xn_out is not written).
+// the stamps of a -DHIPTS_MLP_STAMPS build (zeros otherwise): [0..6] chunk 8 of wave 0: start, copy of chunk 10 requested, first product done,
+// StarReLU done, second product done, own copies landed, barrier passed; [8] kernel start, [9] last chunk done, [10] epilogue done
+extern "C" int hiptsdbg_mlp_stamps(unsigned long long* host, int n) {
+    HIPTS_REQUIRE(host && n >= 1 && n <= 16, "hiptsdbg_mlp_stamps: bad argument");
+    HIPTS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(hipts::mlp_stamps), (size_t)n * 8));
+    return HIPTS_OK;
+}
+
 extern "C" int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const float* w2, float* x, const float* res_scale, const float* gamma,
                                   uint16_t* xn_out, int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out) {
     using namespace hipts;

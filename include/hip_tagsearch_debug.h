@@ -36,6 +36,9 @@ int hiptsdbg_dwconv7_stamps(unsigned long long* host, int n);
  * ms_out: average device time of iters - 1 launches (iters >= 2). */
 int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const float* w2, float* x, const float* res_scale, const float* gamma, uint16_t* xn_out,
                        int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out);
+/* Phase time stamps (100 MHz) of one wave of the fused MLP kernel's last launch; zeros unless csrc/mlp.hip was built with
+ * -DHIPTS_MLP_STAMPS=<workgroup> (tools/mlp_stamps.py). */
+int hiptsdbg_mlp_stamps(unsigned long long* host, int n);
 /* out_host float32 [M][N] = A W^T for bf16 bit patterns a_bf16 [M][K], w_bf16 [N][K] (plain epilogue). */
 int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host);
 /* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in
