@@ -73,8 +73,8 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int C>
-__global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const char* __restrict__ wimg, float* __restrict__ x,
+template <int C, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlp_fused_kernel(const bf16_t* xn, const char* __restrict__ wimg, float* __restrict__ x,
                                                         const float* __restrict__ res_scale, const float* __restrict__ gamma,
                                                         bf16_t* xn_out, int M, int chunks, float star_s, float star_b, float eps) {
     using I = MlpImg<C>;
@@ -82,17 +82,17 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * 256 + wave * 32;
+    const int row0 = blockIdx.x * (WAVES * 32) + wave * 32;
     static_assert(RF == 2, "the issue fences below name two accumulators");
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     MLP_STAMP_AT(8);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // in a scalar register: no divergent control flow around the copies
-    constexpr int NBUF = 4, NP = I::BYTES / 1024, PER = (NP + 7) / 8;
-    // piece i of this wave for chunk j: the 1 KiB pieces w, w + 8, ...; every wave issues PER of them (the last ones twice: the same bytes),
+    constexpr int NBUF = 4, NP = I::BYTES / 1024, PER = (NP + WAVES - 1) / WAVES;
+    // piece i of this wave for chunk j: the 1 KiB pieces w, w + WAVES, ...; every wave issues PER of them (the last ones twice: the same bytes),
     // so that "PER copies outstanding" means the same in every wave
     auto copy_piece = [&](int j, int slot, int i) {
-        const int p = min(wave_u + 8 * i, NP - 1);
+        const int p = min(wave_u + WAVES * i, NP - 1);
         glds16(wimg + (size_t)j * I::BYTES + p * 1024 + lane * 16, smem + slot * I::BYTES + p * 1024);
     };
     for (int j = 0; j < 3 && j < chunks; ++j)
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
     // four chunk buffers, and the barrier that ends chunk j has every wave's pieces of chunk j + 2, so the ring never drains between
     // chunks.  Nothing else in the loop touches LGKM (no scalar loads, no other LDS operation): "RING - 1 younger reads outstanding" is exact.
     constexpr int RING = HIPTS_MLP_RING, T = 2 * KS + CF;
-    static_assert(T % RING == 0 && RING <= 2 * KS && PER <= KS, "ring slots continue across chunks; the copies fit the first product");
+    static_assert(T % RING == 0 && RING <= 2 * KS && PER <= 2 * KS, "ring slots continue across chunks; the copies fit the first product");
     const uint32_t lane_w1 = lr * I::P1 + kq * 16, lane_w2 = I::W2_OFF + lr * I::P2 + kq * 16;
     f16x8 w[RING];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of chunks 0 .. 2, and its rows
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(const bf16_t* xn, const 
             // the slot is rewritten by the next read: the MFMAs above must have been issued (they read their operands at issue)
             issue_fence(S[hf][0], S[hf][1]);
             read(std::integral_constant<int, t + RING>{});
-            if constexpr (!LAST && t % 2 == 1 && t / 2 < PER) {          // one piece of the copy behind every second pair of MFMAs
-                if (copying) copy_piece(j + 3, slot3, t / 2);
+            if constexpr (!LAST && t < PER) {          // one piece of the copy behind a pair of MFMAs
+                if (copying) copy_piece(j + 3, slot3, t);
             }
         });
         MLP_STAMP(2);
@@ -285,18 +285,39 @@ std::vector<uint16_t> mlp_weight_image(const float* w1, const float* w2, int C) 
 bool mlp_fused_supports(int C) { return C == 128 || C == 256; }
 
 int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* res_scale, const float* gamma, bf16_t* xn_out, int M, int C,
-                     float star_s, float star_b, float eps, hipStream_t s) {
+                     float star_s, float star_b, float eps, hipStream_t s, int waves) {
     HIPTS_REQUIRE(mlp_fused_supports(C), "fused MLP: width %d is not built (128, 256)", C);
     HIPTS_REQUIRE(xn && wimg && x && M >= 1 && (!gamma || xn_out), "fused MLP: bad argument");
-    const int grid = (M + 255) / 256, chunks = 4 * C / 32;
+    const int chunks = 4 * C / 32;
+    // eight waves (256 rows) per workgroup share a chunk's weights; a launch that would leave CUs without a workgroup, or whose last round
+    // is nearly empty, takes four-wave workgroups (128 rows: twice the weight traffic, half the lifetime).  HIPTS_MLP_WAVES=4 / 8 forces.
+    static const int waves_env = getenv("HIPTS_MLP_WAVES") ? atoi(getenv("HIPTS_MLP_WAVES")) : 0;
+    static int cus_of[64] = {};          // CUs per device, asked once
+    int dev = 0;
+    HIPTS_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && cus_of[dev] == 0) {
+        int n = 0;
+        HIPTS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cus_of[dev] = n > 0 ? n : 256;
+    }
+    const int cus = (dev >= 0 && dev < 64) ? cus_of[dev] : 256;
+    const int g8 = (M + 255) / 256, g4 = (M + 127) / 128;
+    const double t8 = (double)((g8 + cus - 1) / cus), t4 = 0.6 * (double)((g4 + cus - 1) / cus);      // rounds x relative lifetime (measured: 85 / 50 us at C = 256)
+    const int want = waves ? waves : waves_env;
+    const bool four = want == 4 || (want != 8 && t4 < t8);
+    const int grid = four ? g4 : g8;
     static bool once = false;
     if (!once) {
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
         once = true;
     }
-    if (C == 128) mlp_fused_kernel<128><<<grid, 512, 4 * MlpImg<128>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
-    else mlp_fused_kernel<256><<<grid, 512, 4 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
+#define HIPTS_MLP_LAUNCH(CC, WW) mlp_fused_kernel<CC, WW><<<grid, WW * 64, 4 * MlpImg<CC>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps)
+    if (C == 128) { if (four) HIPTS_MLP_LAUNCH(128, 4); else HIPTS_MLP_LAUNCH(128, 8); }
+    else { if (four) HIPTS_MLP_LAUNCH(256, 4); else HIPTS_MLP_LAUNCH(256, 8); }
+#undef HIPTS_MLP_LAUNCH
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }
@@ -314,7 +335,7 @@ extern "C" int hiptsdbg_mlp_stamps(unsigned long long* host, int n) {
 }
 
 extern "C" int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const float* w2, float* x, const float* res_scale, const float* gamma,
-                                  uint16_t* xn_out, int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out) {
+                                  uint16_t* xn_out, int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out, int waves) {
     using namespace hipts;
     HIPTS_REQUIRE(xn && w1 && w2 && x && M >= 1 && mlp_fused_supports(C), "hiptsdbg_mlp_fused: bad argument");
     const std::vector<uint16_t> img = mlp_weight_image(w1, w2, C);
@@ -341,7 +362,7 @@ extern "C" int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const flo
             HIPTS_TRY(upload(dx.p, x, n * 4));
         }
         HIPTS_TRY(launch_mlp_fused(dxn.as<bf16_t>(), dimg.p, dx.as<float>(), res_scale ? drs.as<float>() : nullptr, gamma ? dg.as<float>() : nullptr,
-                                   dout.as<bf16_t>(), M, C, star_s, star_b, eps, nullptr));
+                                   dout.as<bf16_t>(), M, C, star_s, star_b, eps, nullptr, waves));
     }
     HIPTS_HIP(hipDeviceSynchronize());
     float ms = 0.f;

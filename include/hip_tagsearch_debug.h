@@ -33,9 +33,9 @@ int hiptsdbg_dwconv7(const uint16_t* in_f16, const float* w, uint16_t* out_f16, 
 int hiptsdbg_dwconv7_stamps(unsigned long long* host, int n);
 /* The fused MLP of the CCIP encoder's stages 0-1 on its own (csrc/mlp.hip): x[m] = rs * x[m] + StarReLU(xn[m] W1^T) W2^T, xn_out[m] = LayerNorm(x[m]) * gamma.
  * Host arrays: xn / xn_out IEEE-half bits [M][C], w1 [4C][C], w2 [C][4C], x [M][C] in / out, res_scale / gamma [C] or null; C = 128 or 256;
- * ms_out: average device time of iters - 1 launches (iters >= 2). */
+ * ms_out: average device time of iters - 1 launches (iters >= 2); waves: 4 / 8 waves per workgroup, 0 = chosen by the size of the launch. */
 int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const float* w2, float* x, const float* res_scale, const float* gamma, uint16_t* xn_out,
-                       int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out);
+                       int M, int C, float star_s, float star_b, float eps, int iters, float* ms_out, int waves);
 /* Phase time stamps (100 MHz) of one wave of the fused MLP kernel's last launch; zeros unless csrc/mlp.hip was built with
  * -DHIPTS_MLP_STAMPS=<workgroup> (tools/mlp_stamps.py). */
 int hiptsdbg_mlp_stamps(unsigned long long* host, int n);

@@ -164,18 +164,19 @@ def test_dwconv7_kernels_against_float64(H, C, mode):
         assert np.abs(out.astype(np.float64) - ref.astype(np.float64)).max() <= 2e-2
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("M,C,with_rs,with_ln", [(300, 128, True, True), (512, 256, True, True), (37, 256, False, True), (256, 128, False, False), (1000, 256, True, False)])
-def test_mlp_fused_against_float64(M, C, with_rs, with_ln):
+def test_mlp_fused_against_float64(M, C, with_rs, with_ln, waves):
     """The fused MLP kernel alone (csrc/mlp.hip through hiptsdbg_mlp_fused; the MetaFormer `Mlp` + scaled residual + next LayerNorm):
     x = rs * x + StarReLU(xn W1^T) W2^T against float64 with the kernel's roundings (half weights, hidden activations rounded to half),
-    row counts that are no multiple of a wave's 32 or a workgroup's 256 rows."""
+    row counts that are no multiple of a wave's 32 or a workgroup's 128 / 256 rows, both workgroup sizes."""
     import ctypes, os, sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
     from hiptagsearch import _lib
     lib = _lib.load()
     f = lib.hiptsdbg_mlp_fused
-    f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     rng = np.random.default_rng(M + C)
     xn = rng.standard_normal((M, C)).astype(np.float16)
     w1 = (rng.standard_normal((4 * C, C)) / np.sqrt(C)).astype(np.float32)
@@ -192,7 +193,7 @@ def test_mlp_fused_against_float64(M, C, with_rs, with_ln):
     got = x.copy()
     xo = np.zeros((M, C), dtype=np.float16)
     st = f(xn.ctypes.data, w1.ctypes.data, w2.ctypes.data, got.ctypes.data, rs.ctypes.data if with_rs else None, g.ctypes.data if with_ln else None,
-           xo.ctypes.data, M, C, s, b, eps, 0, None)
+           xo.ctypes.data, M, C, s, b, eps, 0, None, waves)
     assert st == 0, _lib.last_error()
     # a hidden value that lands on a rounding boundary of half may round the other way under another summation order: 2^-11 relative on one
     # of 4C terms -- far below the bound

@@ -8,7 +8,7 @@ import numpy as np
 from hiptagsearch import _lib
 lib = _lib.load()
 f = lib.hiptsdbg_mlp_fused
-f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
 rng = np.random.default_rng(0)
 for M, C in ((32 * 96 * 96, 128), (32 * 48 * 48, 256)):
     xn = rng.standard_normal((M, C)).astype(np.float16)
@@ -18,7 +18,7 @@ for M, C in ((32 * 96 * 96, 128), (32 * 48 * 48, 256)):
     rs = np.ones(C, dtype=np.float32); g = np.ones(C, dtype=np.float32)
     xo = np.zeros((M, C), dtype=np.float16)
     ms = ctypes.c_float(0)
-    assert f(xn.ctypes.data, w1.ctypes.data, w2.ctypes.data, x.ctypes.data, rs.ctypes.data, g.ctypes.data, xo.ctypes.data, M, C, 0.8944, -0.4472, 1e-6, 4, ctypes.byref(ms)) == 0, _lib.last_error()
+    assert f(xn.ctypes.data, w1.ctypes.data, w2.ctypes.data, x.ctypes.data, rs.ctypes.data, g.ctypes.data, xo.ctypes.data, M, C, 0.8944, -0.4472, 1e-6, 4, ctypes.byref(ms), 8) == 0, _lib.last_error()
     st = (ctypes.c_ulonglong * 16)()
     assert lib.hiptsdbg_mlp_stamps(st, 16) == 0
     t = np.array(list(st), dtype=np.float64) / 100.0
