@@ -292,28 +292,28 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
     // eight waves (256 rows) per workgroup share a chunk's weights; a launch that would leave CUs without a workgroup, or whose last round
     // is nearly empty, takes four-wave workgroups (128 rows: twice the weight traffic, half the lifetime).  HIPTS_MLP_WAVES=4 / 8 forces.
     static const int waves_env = getenv("HIPTS_MLP_WAVES") ? atoi(getenv("HIPTS_MLP_WAVES")) : 0;
-    static int cus_of[64] = {};          // CUs per device, asked once
+    static int cus_of[64] = {};          // CUs per device, asked once -- together with the kernels' LDS attribute, which is per device
     int dev = 0;
     HIPTS_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && cus_of[dev] == 0) {
+    HIPTS_REQUIRE(dev >= 0 && dev < 64, "fused MLP: device %d", dev);
+    if (cus_of[dev] == 0) {
         int n = 0;
         HIPTS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        cus_of[dev] = n > 0 ? n : 256;
-    }
-    const int cus = (dev >= 0 && dev < 64) ? cus_of[dev] : 256;
-    const int g8 = (M + 255) / 256, g4 = (M + 127) / 128;
-    const double t8 = (double)((g8 + cus - 1) / cus), t4 = 0.6 * (double)((g4 + cus - 1) / cus);      // rounds x relative lifetime (measured: 85 / 50 us at C = 256)
-    const int want = waves ? waves : waves_env;
-    const bool four = want == 4 || (want != 8 && t4 < t8);
-    const int grid = four ? g4 : g8;
-    static bool once = false;
-    if (!once) {
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
-        once = true;
+        cus_of[dev] = n > 0 ? n : 256;
     }
+    const int cus = cus_of[dev];
+    const int g8 = (M + 255) / 256, g4 = (M + 127) / 128;
+    // rounds x relative lifetime.  C = 256: one workgroup per CU either way, a four-wave one lives 50 us against 85; C = 128: two four-wave
+    // workgroups per CU (LDS 76 KB, 150 registers), each about as long as the eight-wave one, out of step with each other (152 against 175 us)
+    const int slots4 = C == 128 ? 2 * cus : cus;
+    const double t8 = (double)((g8 + cus - 1) / cus), t4 = (C == 128 ? 0.9 : 0.6) * (double)((g4 + slots4 - 1) / slots4);
+    const int want = waves ? waves : waves_env;
+    const bool four = want == 4 || (want != 8 && t4 < t8);
+    const int grid = four ? g4 : g8;
 #define HIPTS_MLP_LAUNCH(CC, WW) mlp_fused_kernel<CC, WW><<<grid, WW * 64, 4 * MlpImg<CC>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps)
     if (C == 128) { if (four) HIPTS_MLP_LAUNCH(128, 4); else HIPTS_MLP_LAUNCH(128, 8); }
     else { if (four) HIPTS_MLP_LAUNCH(256, 4); else HIPTS_MLP_LAUNCH(256, 8); }
