@@ -27,7 +27,6 @@
 namespace hipts {
 namespace {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef HIPTS_MLP_RING
 #define HIPTS_MLP_RING 4
