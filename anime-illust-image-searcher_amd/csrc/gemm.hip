@@ -46,6 +46,9 @@ constexpr int BM = 256, BN = 256, BK = 64;
 #ifndef HIPTS_STAGE_ORDER_OLD
 #define HIPTS_STAGE_ORDER_OLD 0       // 1: the previous staging order of the ping-pong loop (A/B builds)
 #endif
+#ifndef HIPTS_STAGED_INTERIOR
+#define HIPTS_STAGED_INTERIOR 1         // 0: the staged 16-bit epilogues store under per-lane predicates everywhere (A/B builds)
+#endif
 constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 128 KiB
@@ -240,13 +243,28 @@ __device__ __forceinline__ void staged_store_rows(char* region, int lane, int mr
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (HIPTS_STAGED_INTERIOR && mrow0 + pass * 64 + 64 <= M && pass * 64 + 64 <= MR * 16 && ncol0 + 64 <= N) {
+            // all 64 rows x 64 columns of this pass exist (wave-uniform: every tile but the last row / column of tiles): eight LDS reads,
+            // then eight stores from one base address -- with the per-lane test each store is an exec-masked block with its own LDS read,
+            // lgkmcnt(0) and 64-bit address arithmetic
+            bf16_t* base = out + (size_t)(mrow0 + pass * 64 + lrow) * ld + ncol0 + lc * 8;
+            uint4 v[8];
 #pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-            const int row = r8 * 8 + lrow;
-            const int m = mrow0 + pass * 64 + row;
-            const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
-            if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
-            *reinterpret_cast<uint4*>(out + (size_t)m * ld + ncol0 + lc * 8) = v;
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int row = r8 * 8 + lrow;
+                v[r8] = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+            }
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) *reinterpret_cast<uint4*>(base + (size_t)r8 * 8 * ld) = v[r8];
+        } else {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int row = r8 * 8 + lrow;
+                const int m = mrow0 + pass * 64 + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+                if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
+                *reinterpret_cast<uint4*>(out + (size_t)m * ld + ncol0 + lc * 8) = v;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
@@ -1013,6 +1031,23 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (EPI == EPI_GELU || EPI == EPI_STAR) {
+                // all 64 rows x 64 columns of this pass exist (wave-uniform: every tile but the last row / column of tiles): eight LDS reads,
+                // then eight stores from one base address (see staged_store_rows)
+                if (HIPTS_STAGED_INTERIOR && mrow0 + pass * 64 + 64 <= a.M && pass * 64 + 64 <= MR * 16 && ncol0 + 64 <= a.N) {
+                    bf16_t* base = a.out_bf16 + (size_t)(mrow0 + pass * 64 + lrow) * ld + ncol0 + lc * 8;
+                    uint4 v[8];
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int row = r8 * 8 + lrow;
+                        v[r8] = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) *reinterpret_cast<uint4*>(base + (size_t)r8 * 8 * ld) = v[r8];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    continue;
+                }
+            }
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8) {
                 const int row = r8 * 8 + lrow;
