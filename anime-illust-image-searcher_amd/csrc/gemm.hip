@@ -388,13 +388,26 @@ __device__ __forceinline__ void staged_store_half_rows(char* region, int lane, i
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (HIPTS_STAGED_INTERIOR && mrow0 + pass * 64 + 64 <= M && pass * 64 + 64 <= MR * 16 && ocol0 + 32 <= Nout) {
+            // the pass lies inside the matrix (wave-uniform): reads, then stores from one base address (see staged_store_rows)
+            bf16_t* base = out + (size_t)(mrow0 + pass * 64 + lrow) * ld + ocol0 + lc * 8;
+            uint4 v[4];
 #pragma unroll
-        for (int r16 = 0; r16 < 4; ++r16) {
-            const int row = r16 * 16 + lrow;
-            const int m = mrow0 + pass * 64 + row;
-            const uint4 v = *reinterpret_cast<const uint4*>(region + row * 64 + ((lc ^ ((row >> 2) & 3)) * 16));
-            if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
-            *reinterpret_cast<uint4*>(out + (size_t)m * ld + ocol0 + lc * 8) = v;
+            for (int r16 = 0; r16 < 4; ++r16) {
+                const int row = r16 * 16 + lrow;
+                v[r16] = *reinterpret_cast<const uint4*>(region + row * 64 + ((lc ^ ((row >> 2) & 3)) * 16));
+            }
+#pragma unroll
+            for (int r16 = 0; r16 < 4; ++r16) *reinterpret_cast<uint4*>(base + (size_t)r16 * 16 * ld) = v[r16];
+        } else {
+#pragma unroll
+            for (int r16 = 0; r16 < 4; ++r16) {
+                const int row = r16 * 16 + lrow;
+                const int m = mrow0 + pass * 64 + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(region + row * 64 + ((lc ^ ((row >> 2) & 3)) * 16));
+                if (pass * 64 + row >= MR * 16 || m >= M || !nvl) continue;
+                *reinterpret_cast<uint4*>(out + (size_t)m * ld + ocol0 + lc * 8) = v;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
@@ -1044,6 +1057,28 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& a, f32x4 (&
                     }
 #pragma unroll
                     for (int r8 = 0; r8 < 8; ++r8) *reinterpret_cast<uint4*>(base + (size_t)r8 * 8 * ld) = v[r8];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    continue;
+                }
+            }
+            if constexpr (IS_QK) {
+                // the same for the q | k | v layouts: the eight (image, token) addresses first, then reads, then stores
+                if (HIPTS_STAGED_INTERIOR && mrow0 + pass * 64 + 64 <= a.M && pass * 64 + 64 <= MR * 16 && ncol0 + 64 <= a.N) {
+                    uint4 v[8];
+                    size_t off[8];
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int row = r8 * 8 + lrow;
+                        v[r8] = *reinterpret_cast<const uint4*>(region + row * 128 + ((lc ^ ((row >> 1) & 7)) * 16));
+                        off[r8] = ((((size_t)(qb * a.heads + head) * a.tokens_pad + qt)) << a.hd_log2) + hd_off;
+                        qt += 8;
+                        while (qt >= a.tokens) {
+                            qt -= a.tokens;
+                            ++qb;
+                        }
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) *reinterpret_cast<uint4*>(qk_base + off[r8]) = v[r8];
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     continue;
                 }

@@ -3,6 +3,7 @@
 # with -DHIPTS_STAGED_INTERIOR=0, benched, then the default object again, benched, then once more each (A B A B); the default object stays
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -30 gpurun_out/build.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_vit.py tests/test_gpu_eva.py tests/test_gpu_ccip.py -m gpu -q -x 2>&1 | tail -2 || exit 1
 cd anime-illust-image-searcher_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function"
 cp gemm.o /tmp/gemm_default.o
