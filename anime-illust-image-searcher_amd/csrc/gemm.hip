@@ -2158,8 +2158,12 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
         // 2 x the slots (measured, CCIP B36 @384 batch 20: 9.3 -> 8.8 ms; no difference at batch 64).
         const int cus0 = cus_dev;
         static const bool auto_dw = !(getenv("HIPTS_GEMM_AUTO_DW") && atoi(getenv("HIPTS_GEMM_AUTO_DW")) == 0);      // A/B
-        // (round 3: only below 3/4 of the CUs -- EVA02-L's q|k|v at batch 10 is 252 tiles on 256 CUs and runs 1 % faster on the persistent kernel)
-        if (auto_dw && (long)tiles_m * ((a.N + BN - 1) / BN) * 4 < (long)cus0 * 3 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_SWIGLU) && a.stat_part)) variant = 4;
+        // (round 3: only below 3/4 of the CUs -- EVA02-L's q|k|v at batch 10 is 252 tiles on 256 CUs and runs 1 % faster on the persistent kernel.
+        // Late round 4: only up to HALF the CUs, where every 256 x 128 tile gets a CU of its own; between a half and the whole chip the
+        // persistent kernel with 192-row tiles -- one round of 3/4 the length -- is faster: CCIP batch 64, whose stage-2 launches are 144
+        // tiles, 3244 -> 3412 images/s, batch 20 (90 tiles) stays on this kernel: 2586 against 2553.  HIPTS_GEMM_DW_LIMIT = n/4 of the CUs.)
+        static const int dw_limit4 = getenv("HIPTS_GEMM_DW_LIMIT") ? atoi(getenv("HIPTS_GEMM_DW_LIMIT")) : 2;
+        if (auto_dw && (long)tiles_m * ((a.N + BN - 1) / BN) * 4 <= (long)cus0 * dw_limit4 && a.M > BM && !((EPI == EPI_RESID_XG || EPI == EPI_RESID_XGI || EPI == EPI_SWIGLU) && a.stat_part)) variant = 4;
     }
     {   // A/B: HIPTS_GEMM_DW_MASK = bit mask over epilogue numbers whose launches take the two-workgroups-per-CU 256 x 128 kernel (its
         // residents run out of phase, so one's epilogue overlaps the other's main loop; it pays only where the epilogue is long and K short)
@@ -2204,7 +2208,10 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             // 192 rows (round 3, half operands only): EVA02-L at the reference's batch of 10 -- 10 250 rows x 1024 columns are 164
             // tiles of 256 rows on 256 CUs (one round, 64 % of the chip) but 216 tiles of 192 rows (one round of 3/4 the length).
             int mr = 8;
-            if (!a.shared_chip) {
+            // ... unless the whole launch is smaller than the chip (late round 4): then there is no last round for the other stream to fill,
+            // and shorter tiles end the launch sooner (HIPTS_GEMM_MR_SHARED=0: as before, 1: by cost for every shared launch)
+            static const int mr_shared = getenv("HIPTS_GEMM_MR_SHARED") ? atoi(getenv("HIPTS_GEMM_MR_SHARED")) : -1;
+            if (!a.shared_chip || mr_shared == 1 || (mr_shared != 0 && (long)tiles_of(8) * tiles_n < cus)) {
                 long best = cost_of(8) * 93;
                 for (int c = 7; c >= (a.f16 ? min_mr : (min_mr > 7 ? min_mr : 7)); --c)
                     if (cost_of(c) * 100 < best) {
