@@ -851,7 +851,8 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
     static const int want_streams = getenv("HIPTS_CCIP_STREAMS") ? atoi(getenv("HIPTS_CCIP_STREAMS")) : 2;
     // (measured, B36 @384: batch 64 2567 -> 2809 images/s; at the reference's batch of 20 the halves are too small
     // to gain and the doubled launch count costs, so small batches stay on the caller's stream)
-    const int ns = std::min({want_streams, 2, batch / 16});
+    static const int min_sub = getenv("HIPTS_CCIP_MINSUB") && atoi(getenv("HIPTS_CCIP_MINSUB")) > 0 ? atoi(getenv("HIPTS_CCIP_MINSUB")) : 16;      // images per sub-batch needed to split
+    const int ns = std::min({want_streams, 2, batch / min_sub});
     if (ns >= 2) {
         if (!h->ev_fork) {
             HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
