@@ -1161,6 +1161,15 @@ int hiptsdbg_dwconv7(const uint16_t* in_f16, const float* w, uint16_t* out_f16, 
     return HIPTS_OK;
 }
 
+// Host only (no GPU call): the lane images dw_toeplitz_lanes builds from weights [channels][49], u32 [channels][7][64]
+// (tests/test_host_layouts.py, runs without a GPU).
+int hiptsdbg_dw_toeplitz(const float* w, int channels, uint32_t* out) {
+    HIPTS_REQUIRE(w && out && channels >= 1, "hiptsdbg_dw_toeplitz: bad argument");
+    const std::vector<uint32_t> t = dw_toeplitz_lanes(w, channels);
+    memcpy(out, t.data(), t.size() * 4);
+    return HIPTS_OK;
+}
+
 // the stamps of a -DHIPTS_DW_STAMPS build (zeros otherwise): [0] start, [1] operands built, then per tile 8 stamps from [2]: start, loads
 // requested, planes written, barrier, products done, barrier, results in LDS + barrier, stores issued; [31] end
 int hiptsdbg_dwconv7_stamps(unsigned long long* host, int n) {

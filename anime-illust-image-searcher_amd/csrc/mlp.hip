@@ -325,6 +325,16 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
 
 // Debug / test entry (include/hip_tagsearch_debug.h): the fused MLP on its own.  Host arrays: xn IEEE-half bits [M][C], w1 [4C][C], w2 [C][4C],
 // x [M][C] (in / out), res_scale [C] or null, gamma [C] or null (then xn_out is not written).
+// Host only (no GPU call): the chunk images mlp_weight_image builds, for the layout test that runs without a GPU (tests/test_host_layouts.py).
+extern "C" int hiptsdbg_mlp_weight_image(const float* w1, const float* w2, int C, uint16_t* out, long long out_halves) {
+    using namespace hipts;
+    HIPTS_REQUIRE(w1 && w2 && out && mlp_fused_supports(C), "hiptsdbg_mlp_weight_image: bad argument");
+    const std::vector<uint16_t> img = mlp_weight_image(w1, w2, C);
+    HIPTS_REQUIRE((long long)img.size() == out_halves, "hiptsdbg_mlp_weight_image: the image has %lld halves, the buffer %lld", (long long)img.size(), out_halves);
+    memcpy(out, img.data(), img.size() * 2);
+    return HIPTS_OK;
+}
+
 // the stamps of a -DHIPTS_MLP_STAMPS build (zeros otherwise): [0..6] chunk 8 of wave 0: start, copy of chunk 10 requested, first product done,
 // StarReLU done, second product done, own copies landed, barrier passed; [8] kernel start, [9] last chunk done, [10] epilogue done
 extern "C" int hiptsdbg_mlp_stamps(unsigned long long* host, int n) {

@@ -39,6 +39,13 @@ int hiptsdbg_mlp_fused(const uint16_t* xn, const float* w1, const float* w2, flo
 /* Phase time stamps (100 MHz) of one wave of the fused MLP kernel's last launch; zeros unless csrc/mlp.hip was built with
  * -DHIPTS_MLP_STAMPS=<workgroup> (tools/mlp_stamps.py). */
 int hiptsdbg_mlp_stamps(unsigned long long* host, int n);
+/* Host only, no GPU call: the weight layouts the two round-4 CCIP kernels read (tests/test_host_layouts.py builds them again in numpy).
+ * hiptsdbg_mlp_weight_image: per 32 hidden units one block of IEEE-half bits [32 rows of w1, pitch C + 16 halves][C rows of w2, pitch 40 halves,
+ * position 8 q + e of a row = hidden unit 16 (e >> 2) + 4 q + (e & 3) of the chunk]; out_halves = (4C / 32) * (32 * (C + 16) + C * 40).
+ * hiptsdbg_dw_toeplitz: out u32 [channels][7][64] -- per (channel, kernel row) the 7 weights as halves Z[16 + kx] inside 48 zero halves;
+ * lane L < 24 holds (Z[2L], Z[2L+1]), lane 32 + L holds (Z[2L+1], Z[2L+2]), the other lanes zero. */
+int hiptsdbg_mlp_weight_image(const float* w1, const float* w2, int C, uint16_t* out, long long out_halves);
+int hiptsdbg_dw_toeplitz(const float* w, int channels, uint32_t* out);
 /* out_host float32 [M][N] = A W^T for bf16 bit patterns a_bf16 [M][K], w_bf16 [N][K] (plain epilogue). */
 int hiptsdbg_gemm_run(int M, int N, int K, const uint16_t* a_bf16, const uint16_t* w_bf16, float* out_host);
 /* The e4m3 operand path: a_f32 / w_f32 are quantised by the library (per-tensor power-of-two weight scale returned in
