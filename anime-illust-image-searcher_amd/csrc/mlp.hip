@@ -72,8 +72,8 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int C, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void mlp_fused_kernel(const bf16_t* xn, const char* __restrict__ wimg, float* __restrict__ x,
+template <int C, int WAVES, int NBUF = 4>
+__global__ __launch_bounds__(WAVES * 64, NBUF == 2 ? 2 : 1) void mlp_fused_kernel(const bf16_t* xn, const char* __restrict__ wimg, float* __restrict__ x,
                                                         const float* __restrict__ res_scale, const float* __restrict__ gamma,
                                                         bf16_t* xn_out, int M, int chunks, float star_s, float star_b, float eps) {
     using I = MlpImg<C>;
@@ -87,14 +87,18 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fused_kernel(const bf16_t* xn,
 
     MLP_STAMP_AT(8);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);          // in a scalar register: no divergent control flow around the copies
-    constexpr int NBUF = 4, NP = I::BYTES / 1024, PER = (NP + WAVES - 1) / WAVES;
+    // NBUF = 4: the scheme described above.  NBUF = 2 (four-wave workgroups at C = 256: 74 KB of LDS, TWO workgroups per CU, each other's
+    // waits filled): chunk j + 1 is copied during chunk j, published by the barrier that ends chunk j, and the read ring is refilled behind it.
+    static_assert(NBUF == 2 || NBUF == 4, "chunk buffers");
+    constexpr bool CROSS = NBUF == 4;
+    constexpr int NP = I::BYTES / 1024, PER = (NP + WAVES - 1) / WAVES;
     // piece i of this wave for chunk j: the 1 KiB pieces w, w + WAVES, ...; every wave issues PER of them (the last ones twice: the same bytes),
     // so that "PER copies outstanding" means the same in every wave
     auto copy_piece = [&](int j, int slot, int i) {
         const int p = min(wave_u + WAVES * i, NP - 1);
         glds16(wimg + (size_t)j * I::BYTES + p * 1024 + lane * 16, smem + slot * I::BYTES + p * 1024);
     };
-    for (int j = 0; j < 3 && j < chunks; ++j)
+    for (int j = 0; j < (CROSS ? 3 : 1) && j < chunks; ++j)
 #pragma unroll
         for (int i = 0; i < PER; ++i) copy_piece(j, j, i);
 
@@ -133,18 +137,19 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fused_kernel(const bf16_t* xn,
     });
     auto chunk = [&](auto first_tag, auto last_tag, int j, int slot) {
         constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
-        const int slot1 = (slot + 1) & (NBUF - 1), slot3 = (slot + 3) & (NBUF - 1);
-        const bool copying = !LAST && j + 3 < chunks;          // chunk j + 3 into the buffer that held chunk j - 1 (every wave is past the barrier that ended it)
+        const int slot1 = (slot + 1) & (NBUF - 1), slot3 = (slot + 3) & (NBUF - 1);          // NBUF = 2: both are the other buffer
+        constexpr int AHEAD = CROSS ? 3 : 1;
+        const bool copying = !LAST && j + AHEAD < chunks;          // chunk j + AHEAD into the buffer that held chunk j - 1 (every wave is past the barrier that ended it)
         MLP_STAMP(0);
         const uint32_t a1 = lds_base + slot * I::BYTES + lane_w1, a2 = lds_base + slot * I::BYTES + lane_w2, n1 = lds_base + slot1 * I::BYTES + lane_w1;
         auto read = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if constexpr (t < 2 * KS) lds_read16<(t & 1) * 16 * I::P1 + (t >> 1) * 64>(w[t % RING], a1);
             else if constexpr (t < T) lds_read16<(t - 2 * KS) * 16 * I::P2>(w[t % RING], a2);
-            else if constexpr (!LAST) lds_read16<((t - T) & 1) * 16 * I::P1 + ((t - T) >> 1) * 64>(w[t % RING], n1);
+            else if constexpr (!LAST && CROSS) lds_read16<((t - T) & 1) * 16 * I::P1 + ((t - T) >> 1) * 64>(w[t % RING], n1);
         };
         auto wait = [&](auto tc) {          // until the read of step t has landed
-            constexpr int t = decltype(tc)::value, n = (LAST && (T - 1 - t) < (RING - 1)) ? (T - 1 - t) : (RING - 1);
+            constexpr int t = decltype(tc)::value, n = ((LAST || !CROSS) && (T - 1 - t) < (RING - 1)) ? (T - 1 - t) : (RING - 1);
             lds_wait<n>(w[t % RING]);
         };
         MLP_STAMP(1);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fused_kernel(const bf16_t* xn,
             issue_fence(S[hf][0], S[hf][1]);
             read(std::integral_constant<int, t + RING>{});
             if constexpr (!LAST && t < PER) {          // one piece of the copy behind a pair of MFMAs
-                if (copying) copy_piece(j + 3, slot3, t);
+                if (copying) copy_piece(j + AHEAD, slot3, t);
             }
         });
         MLP_STAMP(2);
@@ -199,11 +204,17 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_fused_kernel(const bf16_t* xn,
         MLP_STAMP(4);
         if constexpr (!LAST) {
             // this wave's pieces of chunk j + 2 (requested a chunk ago); those of chunk j + 3 stay in flight
-            if (copying) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            if (CROSS && copying) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             MLP_STAMP(5);
             __builtin_amdgcn_s_barrier();                              // everybody's; and everybody is done with chunk j's buffer
             MLP_STAMP(6);
+            if constexpr (!CROSS) {          // the ring starts again on the chunk just published
+                static_for<0, RING>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    lds_read16<(t & 1) * 16 * I::P1 + (t >> 1) * 64>(w[t], n1);
+                });
+            }
         }
     };
     chunk(std::true_type{}, std::false_type{}, 0, 0);          // chunks >= 16
@@ -302,19 +313,24 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<256>::BYTES));
         cus_of[dev] = n > 0 ? n : 256;
     }
     const int cus = cus_of[dev];
     const int g8 = (M + 255) / 256, g4 = (M + 127) / 128;
+    static const bool two_buffers = !(getenv("HIPTS_MLP_NBUF") && atoi(getenv("HIPTS_MLP_NBUF")) == 4);      // C = 256, four waves: two chunk buffers = two workgroups per CU (A/B: HIPTS_MLP_NBUF=4, one per CU)
     // rounds x relative lifetime.  C = 256: one workgroup per CU either way, a four-wave one lives 50 us against 85; C = 128: two four-wave
     // workgroups per CU (LDS 76 KB, 150 registers), each about as long as the eight-wave one, out of step with each other (152 against 175 us)
+    // C = 256 with two chunk buffers (late round 4): two four-wave workgroups per CU as well (M = 73728: 160 -> 127 us, M = 23040: 77 -> 49 us);
+    // only a launch that fills more than half the chip with ONE round of eight-wave workgroups stays with those (M = 46080: 82 against 84 us)
     const int slots4 = C == 128 ? 2 * cus : cus;
     const double t8 = (double)((g8 + cus - 1) / cus), t4 = (C == 128 ? 0.9 : 0.6) * (double)((g4 + slots4 - 1) / slots4);
     const int want = waves ? waves : waves_env;
-    const bool four = want == 4 || (want != 8 && t4 < t8);
+    const bool four = want == 4 || (want != 8 && ((C == 256 && two_buffers) ? !(g8 <= cus && g8 * 2 > cus) : t4 < t8));
     const int grid = four ? g4 : g8;
 #define HIPTS_MLP_LAUNCH(CC, WW) mlp_fused_kernel<CC, WW><<<grid, WW * 64, 4 * MlpImg<CC>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps)
     if (C == 128) { if (four) HIPTS_MLP_LAUNCH(128, 4); else HIPTS_MLP_LAUNCH(128, 8); }
+    else if (four && two_buffers) mlp_fused_kernel<256, 4, 2><<<grid, 256, 2 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
     else { if (four) HIPTS_MLP_LAUNCH(256, 4); else HIPTS_MLP_LAUNCH(256, 8); }
 #undef HIPTS_MLP_LAUNCH
     HIPTS_LAUNCH_CHECK();

@@ -10,7 +10,7 @@ lib = _lib.load()
 f = lib.hiptsdbg_mlp_fused
 f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
 rng = np.random.default_rng(0)
-for M, C in ((32 * 96 * 96, 128), (32 * 48 * 48, 256), (10 * 96 * 96, 128), (10 * 48 * 48, 256)):
+for M, C in ((32 * 96 * 96, 128), (32 * 48 * 48, 256), (10 * 96 * 96, 128), (10 * 48 * 48, 256), (20 * 48 * 48, 256)):
     xn = rng.standard_normal((M, C)).astype(np.float16)
     w1 = (rng.standard_normal((4 * C, C)) / np.sqrt(C)).astype(np.float32)
     w2 = (rng.standard_normal((C, 4 * C)) / np.sqrt(4 * C)).astype(np.float32)
