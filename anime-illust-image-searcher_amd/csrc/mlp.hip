@@ -314,6 +314,7 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
         HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<256>::BYTES));
+        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<128>::BYTES));
         cus_of[dev] = n > 0 ? n : 256;
     }
     const int cus = cus_of[dev];
@@ -329,7 +330,9 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
     const bool four = want == 4 || (want != 8 && ((C == 256 && two_buffers) ? !(g8 <= cus && g8 * 2 > cus) : t4 < t8));
     const int grid = four ? g4 : g8;
 #define HIPTS_MLP_LAUNCH(CC, WW) mlp_fused_kernel<CC, WW><<<grid, WW * 64, 4 * MlpImg<CC>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps)
-    if (C == 128) { if (four) HIPTS_MLP_LAUNCH(128, 4); else HIPTS_MLP_LAUNCH(128, 8); }
+    static const bool two_buffers128 = !(getenv("HIPTS_MLP_NBUF128") && atoi(getenv("HIPTS_MLP_NBUF128")) == 4);      // C = 128 four waves with two chunk buffers: three workgroups per CU (148 -> 134 us alone, the encoder the same; A/B: HIPTS_MLP_NBUF128=4)
+    if (C == 128 && four && two_buffers128) mlp_fused_kernel<128, 4, 2><<<grid, 256, 2 * MlpImg<128>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
+    else if (C == 128) { if (four) HIPTS_MLP_LAUNCH(128, 4); else HIPTS_MLP_LAUNCH(128, 8); }
     else if (four && two_buffers) mlp_fused_kernel<256, 4, 2><<<grid, 256, 2 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
     else { if (four) HIPTS_MLP_LAUNCH(256, 4); else HIPTS_MLP_LAUNCH(256, 8); }
 #undef HIPTS_MLP_LAUNCH
