@@ -521,13 +521,16 @@ __global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const bf16_t* __re
 template <int XT, int CS>
 int launch_dwconv7_mfma_as(const bf16_t* in, const uint32_t* tz, bf16_t* out, int batch, int H, int C, hipStream_t s) {
     using L = DwMfma<XT, CS>;
-    static bool done[64] = {};          // the attribute is per device
+    static PerDevice once;              // the attribute is per device
     int dev = 0;
     HIPTS_HIP(hipGetDevice(&dev));
     HIPTS_REQUIRE(dev >= 0 && dev < 64, "depthwise 7x7: device %d", dev);
-    if (!done[dev]) {
-        HIPTS_HIP(hipFuncSetAttribute((const void*)dwconv7_mfma_kernel<XT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS));
-        done[dev] = true;
+    {
+        std::lock_guard<std::mutex> lk(once.mu);
+        if (!once.done(dev)) {
+            HIPTS_HIP(hipFuncSetAttribute((const void*)dwconv7_mfma_kernel<XT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS));
+            once.mark(dev);
+        }
     }
     const int tiles_x = (H + 16 * XT - 1) / (16 * XT), tiles_y = (H + 15) / 16;
     const int ntiles = batch * tiles_y * tiles_x, slabs = C / CS;

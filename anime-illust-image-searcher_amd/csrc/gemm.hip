@@ -2279,11 +2279,14 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
                 // (Not instantiated for RESID_XGI: its only user, EVA02, has 1025 tokens per image -- no launch of whole tiles -- and with the
                 // input fold's extra column vector the interior form compiled to 60 spilled registers.)
                 if (mr == 8 && a.M % 256 == 0 && a.N % 256 == 0 && a.N <= 1024 && !a.pos && a.out_bf16 && a.stat_part && !resid_general) {
-                    static bool attr_int = false;
-                    if (!attr_int) {
-                        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-                        HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-                        attr_int = true;
+                    static PerDevice attr_int;
+                    {
+                        std::lock_guard<std::mutex> lk(attr_int.mu);
+                        if (!attr_int.done(dev)) {
+                            HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                            HIPTS_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 8, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                            attr_int.mark(dev);
+                        }
                     }
                     if (a.f16) gemm_pp_kernel<EPI, 8, true, false, false, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);
                     else gemm_pp_kernel<EPI, 8, false, false, false, true><<<grid, 512, LDS_BYTES, s>>>(ar, tiles_m, tiles_n);

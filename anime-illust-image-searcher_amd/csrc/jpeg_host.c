@@ -369,6 +369,7 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
     if (!data || !slot || n < 4 || slot_bytes < HIPTS_JPEG_HEADER_BYTES) return JH_TOO_SMALL;
     if (data[0] != 0xFF || data[1] != 0xD8) return JH_UNSUPPORTED;
     uint16_t qt[4][64];
+    memset(qt, 0, sizeof(qt));
     int qt_present[4] = {0, 0, 0, 0};
     static _Thread_local Huff dc[4], ac[4];
     for (int i = 0; i < 4; ++i) dc[i].present = ac[i].present = 0;
@@ -399,10 +400,19 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
         const uint8_t* seg = data + pos + 2;
         int sl = len - 2;
         if (m == 0xDB) {
+            /* libjpeg latches a component's table at the first scan that contains it (jdinput.c latch_quant_tables); the slot header takes
+             * every component's table at the FIRST scan, so a table (re)defined between the scans of a progressive file is Pillow's business */
+            if (prog_started) return JH_UNSUPPORTED;
             while (sl > 0) {
                 const int pq = seg[0] >> 4, tq = seg[0] & 15;
                 if (tq > 3 || pq > 1 || sl < 1 + 64 * (pq + 1)) return JH_CORRUPT;
-                for (int i = 0; i < 64; ++i) qt[tq][ZIGZAG[i]] = pq ? (uint16_t)be16(seg + 1 + 2 * i) : seg[1 + i];
+                for (int i = 0; i < 64; ++i) {
+                    const unsigned q = pq ? be16(seg + 1 + 2 * i) : seg[1 + i];
+                    /* 8-bit frames only (SOF below): an entry above 255 is legal with pq = 1 but beyond any real 8-bit file, and it would take
+                     * the |coefficient x quantiser| column sums out of int (COLSUM_LIMIT guard) */
+                    if (q > 255) return JH_UNSUPPORTED;
+                    qt[tq][ZIGZAG[i]] = (uint16_t)q;
+                }
                 qt_present[tq] = 1;
                 seg += 1 + 64 * (pq + 1);
                 sl -= 1 + 64 * (pq + 1);
@@ -486,6 +496,10 @@ int hipts_jpeg_entropy_decode(const uint8_t* data, int64_t n, void* slot, int64_
                 pos = pbr.p - data;
                 continue;
             }
+            /* the header below copies EVERY frame component's table now: all of them must have arrived (a first scan with Y only and the
+             * chroma DQT after it is legal T.81 -- and decoded by libjpeg, i.e. Pillow) */
+            for (int c = 0; c < ncomp; ++c)
+                if (!qt_present[ctq[c]]) return JH_UNSUPPORTED;
             /* ---- colour model and sampling, by libjpeg's rules (jdapimin.c default_decompress_parms) */
             if (width < 16 || height < 16) return JH_UNSUPPORTED; /* (jdsample.c leaves the fancy upsampling below 3 chroma columns) */
             if (ncomp == 3) {

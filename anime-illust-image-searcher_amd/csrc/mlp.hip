@@ -303,19 +303,24 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
     // is nearly empty, takes four-wave workgroups (128 rows: twice the weight traffic, half the lifetime).  HIPTS_MLP_WAVES=4 / 8 forces.
     static const int waves_env = getenv("HIPTS_MLP_WAVES") ? atoi(getenv("HIPTS_MLP_WAVES")) : 0;
     static int cus_of[64] = {};          // CUs per device, asked once -- together with the kernels' LDS attribute, which is per device
+    static PerDevice once;
     int dev = 0;
     HIPTS_HIP(hipGetDevice(&dev));
     HIPTS_REQUIRE(dev >= 0 && dev < 64, "fused MLP: device %d", dev);
-    if (cus_of[dev] == 0) {
-        int n = 0;
-        HIPTS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<256>::BYTES));
-        HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<128>::BYTES));
-        cus_of[dev] = n > 0 ? n : 256;
+    {
+        std::lock_guard<std::mutex> lk(once.mu);
+        if (!once.done(dev)) {
+            int n = 0;
+            HIPTS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<128>::BYTES));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MlpImg<256>::BYTES));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<256, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<256>::BYTES));
+            HIPTS_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MlpImg<128>::BYTES));
+            cus_of[dev] = n > 0 ? n : 256;
+            once.mark(dev);
+        }
     }
     const int cus = cus_of[dev];
     const int g8 = (M + 255) / 256, g4 = (M + 127) / 128;

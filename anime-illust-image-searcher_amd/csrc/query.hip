@@ -49,6 +49,7 @@ struct hipts_bm25 {
         PinBuf pin_in, pin_out;
         hipEvent_t done = nullptr;
         int nq = 0, k = 0, kk = 0;
+        hipStream_t stream = nullptr;                   // the stream of the pending batch (both slots share the device workspaces: one stream)
         bool pending = false, host_result = false;      // host_result: the one-query path ran synchronously, its results wait in ids1 / vals1
         std::vector<int32_t> ids1;
         std::vector<double> vals1;
@@ -2743,6 +2744,10 @@ static int search_submit_impl(hipts_bm25_t* bm25, hipts_index_t* index, const in
     HIPTS_TRY(use_device(bm25->device));
     hipts_bm25::SearchSlot& S = bm25->slot[sl];
     HIPTS_REQUIRE(!S.pending, "hipts_search_submit: slot %d still holds an uncollected batch", sl);
+    // ws_q / ws_scores / ws_sims / ws_out are shared by the two slots: stream order is what keeps batch i + 1 off batch i's rows
+    HIPTS_REQUIRE(!bm25->slot[sl ^ 1].pending || bm25->slot[sl ^ 1].stream == s,
+                  "hipts_search_submit: slot %d holds a batch submitted on another stream (all batches of a handle use ONE stream)", sl ^ 1);
+    S.stream = s;
     const int64_t D = bm25->D;
     HIPTS_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "hipts_search: k must be in [1, %d]", TOPK_MAX_K);
     const int nt = q_ptr[nq];

@@ -226,8 +226,13 @@ class Predictor:
     the reference downloads from the HF hub (tagging.py:146-151); offline it takes local files or the
     seeded synthetic stand-ins."""
 
-    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False, gpu_resize: bool = False, gpu_jpeg: bool = False) -> None:
+    def __init__(self, device: int = 0, max_batch: int = 64, compat: bool = False, gpu_resize: bool = False, gpu_jpeg: bool = False,
+                 precise: bool = False) -> None:
         self.device = device
+        # precise: operand_f16 |= 16 (HIPTS_OPERAND_SPLIT_ATT, include/hip_tagsearch.h) for ViT and EVA02 -- the attention output reaches the
+        # output projection as a hi | lo pair of halves.  Flat pictures' logit error 1.7e-3 -> 2.1e-4 for about 5 % of the throughput
+        # (profiles/r04_precision_vit.json; the bench line's `precise` block carries both)
+        self.precise = precise
         self.max_batch = max_batch
         self.compat = compat            # reproduce the reference's dropped tail batch (SURVEY.md section 0.4)
         self.gpu_resize = gpu_resize    # the decode threads only decode and pad; Resize(bicubic) runs on the device (hipts_resize_u8)
@@ -278,6 +283,8 @@ class Predictor:
         if self.tagger_model is not None:
             return
         self.cfg = dict(cfg or synth.VIT_B16_448)
+        if self.precise:
+            self.cfg["operand_f16"] = int(self.cfg.get("operand_f16", 1)) | 16
         # an EVA02 configuration (the reference's MODEL_REPO, tagging.py:45) is recognised by its SwiGLU width
         eva = "mlp_hidden" in self.cfg
         cls_ = EvaTagger if eva else ViTTagger

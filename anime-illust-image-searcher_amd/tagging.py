@@ -3,7 +3,8 @@
 
 Extra switches: --model vit-b16|eva02-l14, --checkpoint model.safetensors (timm key layout) and --labels
 selected_tags.csv for a real wd tagger; without them the seeded synthetic stand-ins are used (no network here).
---compat reproduces the reference's dropped tail batch; --batch sets the device batch size.
+--compat reproduces the reference's dropped tail batch; --batch sets the device batch size; --precise trades about 5 % of the
+throughput for the 1e-3 logit tolerance on flat / padded pictures (operand_f16 bit 4).
 Input pipeline (hiptagsearch/pipeline.py): --workers N decodes in N processes through shared memory; --write-shards DIR
 decodes the corpus once into packed uint8 shards and --shards DIR tags from them (utility/make_tensor_files.py's idea).
 
@@ -40,13 +41,17 @@ def main(arg_str: list) -> None:
                              'upsampling and colour conversion (libjpeg-turbo\'s arithmetic, byte for byte) run on the device; other files as before')
     parser.add_argument('--synthetic', type=int, default=0, metavar='N',
                         help='tag N images of the synthetic benchmark corpus generated on the device (BASELINE.json configs[3]; --dir is ignored)')
+    parser.add_argument('--precise', action='store_true',
+                        help='attention output handed to the output projection as a hi | lo pair of 16-bit halves (operand_f16 |= 16): logits of '
+                             'flat / padded pictures within 1e-3 of the fp32 reference at a trained checkpoint\'s scale, about 5 %% fewer images/s')
     parser.add_argument('--device', type=int, default=0)
     args = parser.parse_args(arg_str)
     # under torch.distributed.run (WORLD_SIZE > 1): one process per GPU, the process group comes up before any GPU call
     from hiptagsearch import dist as hdist
     dist, rank, world, device = hdist.init_from_env(args.device)
     from hiptagsearch.tagger import Predictor
-    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat, gpu_resize=args.gpu_resize or args.gpu_jpeg, gpu_jpeg=args.gpu_jpeg)
+    predictor = Predictor(device=device, max_batch=args.batch, compat=args.compat, gpu_resize=args.gpu_resize or args.gpu_jpeg, gpu_jpeg=args.gpu_jpeg,
+                          precise=args.precise)
     from hiptagsearch import synth
     model_cfg = {'vit-b16': synth.VIT_B16_448, 'eva02-l14': synth.EVA02_L14_448, 'vit-tiny': synth.VIT_TINY}[args.model]   # vit-tiny: test geometry
     after_date = None

@@ -252,3 +252,16 @@ def test_config0_tagging_cli_on_32_synthetic_448_images(tmp_path):
     r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--compat"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read().splitlines()) == 30
+    # --precise (operand_f16 |= 16: the attention output as a hi | lo pair): the lines are the oracle's selection from THAT mode's probabilities
+    os.remove(tmp_path / "tags-wd-tagger.txt")
+    r = subprocess.run([sys.executable, cli, "--dir", "imgs", "--precise"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(tmp_path / "tags-wd-tagger.txt", encoding="utf-8").read().splitlines()
+    model_p = ViTTagger(dict(cfg, operand_f16=1 | 16), synth.vit_weights(cfg, seed=0, trained_like=True), max_batch=32)
+    _, probs_p = model_p.forward_u8(imgs)
+    assert not np.array_equal(probs_p, probs)                           # the switch reached the device
+    want_p = otags.predict_lines(probs_p, names, cat)
+    by_path = {l.split(",")[0]: l for l in lines}
+    for i in range(32):
+        p = os.path.join("imgs", "%02d.png" % i)
+        assert by_path[p] == p + "," + want_p[i], "image %d (--precise)" % i

@@ -202,3 +202,84 @@ def test_every_accepted_mutated_stream_still_equals_pillow():
             want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
         assert np.array_equal(oj.decode_slot(slot), want), it
     assert accepted > 200 and refused > 200, (accepted, refused)
+
+
+def _segments(data):
+    """(marker, start, end) of the marker segments up to and including the first SOS header (entropy data excluded)"""
+    out, pos = [], 2
+    while True:
+        assert data[pos] == 0xFF
+        m = data[pos + 1]
+        ln = (data[pos + 2] << 8) | data[pos + 3]
+        out.append((m, pos, pos + 2 + ln))
+        pos += 2 + ln
+        if m == 0xDA:
+            return out
+
+
+def test_quantisation_tables_between_progressive_scans_are_refused():
+    """libjpeg latches a component's quantisation table at the first scan that contains the component; the slot header takes all of them
+    at the first scan.  A table that arrives (or is redefined) after the first SOS therefore never reaches the header: such files --
+    legal T.81 -- must go to Pillow (status 1), never be decoded with a missing table (advisor finding, round 4)."""
+    from oracle import jpeg as oj
+    lib = host_lib()
+    rng = np.random.default_rng(5)
+    im = synth_image(rng, 120, 160)
+    prog = jpeg_bytes(im, quality=80, subsampling=2, progressive=True)
+    nb = lib.hipts_jpeg_slot_bytes(160, 120)
+    st, slot = entropy_decode(lib, prog)
+    assert st == 0 and np.array_equal(oj.decode_slot(slot), np.asarray(Image.open(io.BytesIO(prog)).convert("RGB")))
+    segs = _segments(prog)
+    dqts = [(a, b) for (m, a, b) in segs if m == 0xDB]
+    assert dqts
+    second_sos = prog.index(b"\xff\xda", segs[-1][2])
+    # (a) the same tables repeated between the first and the second scan: Pillow decodes the same picture, the fast path steps aside
+    dup = b"".join(prog[a:b] for a, b in dqts)
+    redefined = prog[:second_sos] + dup + prog[second_sos:]
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(redefined)).convert("RGB")), np.asarray(Image.open(io.BytesIO(prog)).convert("RGB")))
+    assert entropy_decode(lib, redefined, slot_bytes=nb)[0] == 1
+    # (b) every table moved behind the first scan: the first SOS names components whose tables have not arrived (corrupt: 3), and with
+    # only the chroma table moved the frame is incomplete at the first scan (refused: 1 or 3, never 0)
+    a0, b0 = dqts[0][0], dqts[-1][1]
+    moved = prog[:a0] + prog[b0:second_sos] + prog[a0:b0] + prog[second_sos:]
+    assert entropy_decode(lib, moved, slot_bytes=nb)[0] in (1, 3)
+    # split a two-table DQT segment (Pillow writes one segment per table or one for both) and move the last table only
+    tables = []
+    for a, b in dqts:
+        p = a + 4
+        while p < b:
+            n = 65 + 64 * (prog[p] >> 4)
+            tables.append(prog[p:p + n])
+            p += n
+    assert len(tables) == 2
+    seg = lambda t: b"\xff\xdb" + (len(t) + 2).to_bytes(2, "big") + t
+    chroma_late = prog[:a0] + seg(tables[0]) + prog[b0:second_sos] + seg(tables[1]) + prog[second_sos:]
+    assert entropy_decode(lib, chroma_late, slot_bytes=nb)[0] in (1, 3)
+
+
+def test_sixteen_bit_quantisation_entries_are_refused():
+    """A DQT with 16-bit entries (Pq = 1) above 255 is beyond any 8-bit file and would overflow the per-column |coefficient x quantiser|
+    guard: refused (status 1).  The same table written with Pq = 1 and entries <= 255 decodes like its 8-bit form."""
+    from oracle import jpeg as oj
+    lib = host_lib()
+    rng = np.random.default_rng(6)
+    prog = jpeg_bytes(synth_image(rng, 64, 80), quality=85, subsampling=0, progressive=True)
+    nb = lib.hipts_jpeg_slot_bytes(80, 64)
+    segs = _segments(prog)
+    dqts = [(a, b) for (m, a, b) in segs if m == 0xDB]
+    wide, huge = b"", b""
+    for a, b in dqts:
+        p = a + 4
+        while p < b:
+            assert prog[p] >> 4 == 0
+            vals = prog[p + 1:p + 65]
+            body = bytes([0x10 | (prog[p] & 15)]) + b"".join(bytes([0, v]) for v in vals)
+            wide += b"\xff\xdb" + (len(body) + 2).to_bytes(2, "big") + body
+            body = bytes([0x10 | (prog[p] & 15)]) + b"".join(bytes([0x7f, v]) for v in vals)
+            huge += b"\xff\xdb" + (len(body) + 2).to_bytes(2, "big") + body
+            p += 65
+    a0, b0 = dqts[0][0], dqts[-1][1]
+    st, slot = entropy_decode(lib, prog[:a0] + wide + prog[b0:], slot_bytes=nb)
+    st0, slot0 = entropy_decode(lib, prog, slot_bytes=nb)
+    assert st == 0 and st0 == 0 and np.array_equal(oj.decode_slot(slot), oj.decode_slot(slot0))
+    assert entropy_decode(lib, prog[:a0] + huge + prog[b0:], slot_bytes=nb)[0] == 1
