@@ -1112,8 +1112,9 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     std::vector<uint16_t> ha((size_t)M * K), hw((size_t)Np * K);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f * 2.0f - 1.0f; };
-    for (auto& v : ha) v = f32_to_bf16_rne(rnd());
-    for (auto& v : hw) v = f32_to_bf16_rne(rnd() * 0.05f);
+    const bool dbg_f16 = getenv("HIPTS_DBG_GEMM_F16") != nullptr;      // IEEE-half operands (the product's default)
+    for (auto& v : ha) v = dbg_f16 ? f32_to_f16_rne(rnd()) : f32_to_bf16_rne(rnd());
+    for (auto& v : hw) v = dbg_f16 ? f32_to_f16_rne(rnd() * 0.05f) : f32_to_bf16_rne(rnd() * 0.05f);
     const bool op8 = getenv("HIPTS_GEMM_OP8") != nullptr;      // e4m3 operands: the same bytes, two finite codes per element
     if (op8) {
         for (auto& v : ha) v &= 0xbfbf;
@@ -1135,6 +1136,9 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
         g.pos = nullptr; g.ln_gamma = bias.as<float>(); g.stat_part = statp.as<float>(); g.stat_stride = M;
     }
     if (op8) { g.op8 = 1; g.f16 = 1; g.w_exp = 3; g.out8 = (epi == EPI_STAR && getenv("HIPTS_GEMM_OUT8")) ? 1 : 0; }
+    if (dbg_f16) g.f16 = 1;
+    if (getenv("HIPTS_DBG_GEMM_SHARED")) g.shared_chip = 1;      // as under sub-batch streams: 256-row tiles whatever the round count
+    if (epi == EPI_QK && N % 3 == 0) { g.dim = N / 3; g.heads = g.dim / 64; g.out3_bf16 = obf2.as<bf16_t>(); }      // fused q | k | v (timing only: v shares k's buffer)
     DevBuf stamps;
     if (getenv("HIPTS_GEMM_STAMPS")) {
         HIPTS_TRY(stamps.alloc(4096 * 8 * 8));
@@ -1165,6 +1169,19 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
         HIPTS_HIP(hipMemcpy(h, g.stamps, sizeof(h), hipMemcpyDeviceToHost));
         unsigned long long base = ~0ull;
         for (int w = 0; w < 8; ++w) if (h[w * 64] && h[w * 64] < base) base = h[w * 64];
+        if (gemm_q4_launch_count() > 0 && getenv("HIPTS_GEMM_Q4")) {
+            // gemm4.hip's records of workgroup 8: per wave and tile [top, loop start, loop end, epilogue end, sum phase 0, sum wait + barrier,
+            // sum phase 1, loop wall ticks of 10 ns]
+            fprintf(stderr, "4-wave loop, workgroup 8: per tile start -> loop | loop (phase 0 | wait + barrier | phase 1) | epilogue, cycles\n");
+            for (int w = 0; w < 4; ++w)
+                for (int t = 0; t < 8; ++t) {
+                    const unsigned long long* o = h + w * 64 + t * 8;
+                    if (!o[0]) continue;
+                    fprintf(stderr, "wave %d tile %d: top +%6lld  start %5lld  loop %7lld (p0 %7lld | wait %6lld | p1 %7lld)  epilogue %6lld  clock %.2f GHz\n", w, t,
+                            (long long)(o[0] - base), (long long)(o[1] - o[0]), (long long)(o[2] - o[1]), (long long)o[4], (long long)o[5], (long long)o[6],
+                            (long long)(o[3] - o[2]), o[7] ? (o[2] - o[1]) / (o[7] * 10.0) : 0.0);
+                }
+        } else
         if (getenv("HIPTS_GEMM_TRACE")) {
             std::vector<unsigned long long> tr(4096 * 8);
             HIPTS_HIP(hipMemcpy(tr.data(), g.stamps, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -1197,6 +1214,90 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return HIPTS_OK;
+}
+
+// Development/test aid: the same GEMM launch through gemm_pp_kernel (8 waves) and through gemm4.hip's 4-wave loop on identical random
+// operands; every output buffer of the two must agree byte for byte (the MFMA chain of an element runs over K in the same order).
+// epi: EPI_GELU (4), EPI_QK (1; N % 3 == 0: the fused q | k | v launch), EPI_RESID_XG (13).  *mismatch_out = number of differing bytes;
+// HIPTS_ERR_INVALID when the launch is not one gemm4.hip is built for.  ms_out[0 / 1]: average device time of `iters` launches each way.
+extern "C" int hiptsdbg_gemm_q4_compare(int M, int N, int K, int epi, int f16, int iters, long long* mismatch_out, float* ms_out) {
+    HIPTS_TRY(use_device(0));
+    HIPTS_REQUIRE(mismatch_out && ms_out && (epi == EPI_GELU || epi == EPI_QK || epi == EPI_RESID_XG), "hiptsdbg_gemm_q4_compare: epilogue %d", epi);
+    HIPTS_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && M % 784 == 0, "hiptsdbg_gemm_q4_compare: whole tiles, even K-tile count, whole images");
+    DevBuf A, W, bias, gamma, x0, of32, obf[3], statp;
+    HIPTS_TRY(A.alloc((size_t)M * K * 2));
+    HIPTS_TRY(W.alloc((size_t)N * K * 2));
+    HIPTS_TRY(bias.alloc((size_t)N * 4));
+    HIPTS_TRY(gamma.alloc((size_t)N * 4));
+    HIPTS_TRY(x0.alloc((size_t)M * N * 4));
+    HIPTS_TRY(of32.alloc((size_t)M * N * 4));
+    const size_t obytes = ((size_t)M / 784) * 832 * N * 2 + (1 << 20);
+    for (auto& b : obf) HIPTS_TRY(b.alloc(obytes));
+    HIPTS_TRY(statp.alloc((size_t)(N / 256) * M * 8));
+    {
+        std::vector<uint16_t> ha((size_t)M * K), hw((size_t)N * K);
+        std::vector<float> hb((size_t)N), hg((size_t)N), hx((size_t)M * N);
+        uint32_t st = 2468u + (uint32_t)(M + 3 * N + 7 * K);
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f * 2.0f - 1.0f; };
+        for (auto& v : ha) v = f16 ? f32_to_f16_rne(rnd()) : f32_to_bf16_rne(rnd());
+        for (auto& v : hw) v = f16 ? f32_to_f16_rne(rnd() * 0.05f) : f32_to_bf16_rne(rnd() * 0.05f);
+        for (auto& v : hb) v = rnd() * 0.3f;
+        for (auto& v : hg) v = 1.0f + rnd() * 0.2f;
+        for (auto& v : hx) v = rnd() * 3.0f;
+        HIPTS_TRY(upload(A.p, ha.data(), ha.size() * 2));
+        HIPTS_TRY(upload(W.p, hw.data(), hw.size() * 2));
+        HIPTS_TRY(upload(bias.p, hb.data(), hb.size() * 4));
+        HIPTS_TRY(upload(gamma.p, hg.data(), hg.size() * 4));
+        HIPTS_TRY(upload(x0.p, hx.data(), hx.size() * 4));
+    }
+    GemmArgs g{};
+    g.A = A.as<bf16_t>(); g.W = W.as<bf16_t>(); g.M = M; g.N = N; g.K = K; g.bias = bias.as<float>(); g.f16 = f16 ? 1 : 0;
+    g.out_f32 = of32.as<float>(); g.out_bf16 = obf[0].as<bf16_t>(); g.out2_bf16 = obf[1].as<bf16_t>();
+    g.tokens = 784; g.tokens_pad = 832; g.qscale = 0.125f;
+    if (epi == EPI_QK) {
+        if (N % 3 == 0) { g.dim = N / 3; g.out3_bf16 = obf[2].as<bf16_t>(); } else g.dim = N / 2;
+        g.heads = g.dim / 64;
+        HIPTS_REQUIRE(g.dim % 64 == 0, "hiptsdbg_gemm_q4_compare: q | k | v widths must be multiples of 64");
+    }
+    if (epi == EPI_RESID_XG) { g.ln_gamma = gamma.as<float>(); g.stat_part = statp.as<float>(); g.stat_stride = M; }
+    g.shared_chip = 1;      // as the forwards launch it (sub-batch streams): 256-row tiles whatever the round count
+    const long long q4_before = gemm_q4_launch_count();
+    std::vector<std::vector<char>> keep[2];
+    hipEvent_t e0, e1;
+    HIPTS_HIP(hipEventCreate(&e0));
+    HIPTS_HIP(hipEventCreate(&e1));
+    const unsigned mask_before = 0;
+    (void)mask_before;
+    for (int pass = 0; pass < 2; ++pass) {
+        set_gemm_q4_mask(pass ? (1u << epi) : 0u);
+        HIPTS_HIP(hipMemcpy(of32.p, x0.p, of32.bytes, hipMemcpyDeviceToDevice));
+        for (auto& b : obf) HIPTS_HIP(hipMemset(b.p, 0, b.bytes));
+        HIPTS_HIP(hipMemset(statp.p, 0, statp.bytes));
+        HIPTS_TRY(launch_gemm((GemmEpilogue)epi, g, nullptr));
+        HIPTS_HIP(hipDeviceSynchronize());
+        DevBuf* outs[5] = {&of32, &obf[0], &obf[1], &obf[2], &statp};
+        for (DevBuf* b : outs) {
+            keep[pass].emplace_back(b->bytes);
+            HIPTS_HIP(hipMemcpy(keep[pass].back().data(), b->p, b->bytes, hipMemcpyDeviceToHost));
+        }
+        // timing (the residual stream keeps accumulating: values do not matter here)
+        HIPTS_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) HIPTS_TRY(launch_gemm((GemmEpilogue)epi, g, nullptr));
+        HIPTS_HIP(hipEventRecord(e1, nullptr));
+        HIPTS_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms_out[pass] = iters > 0 ? ms / iters : 0.f;
+    }
+    set_gemm_q4_mask(getenv("HIPTS_GEMM_Q4") ? (unsigned)strtoul(getenv("HIPTS_GEMM_Q4"), nullptr, 0) : GEMM_Q4_DEFAULT_MASK);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPTS_REQUIRE(gemm_q4_launch_count() == q4_before + 1 + iters, "hiptsdbg_gemm_q4_compare: the launcher did not take the 4-wave loop for this shape");
+    long long bad = 0;
+    for (size_t b = 0; b < keep[0].size(); ++b)
+        for (size_t i = 0; i < keep[0][b].size(); ++i) bad += keep[0][b][i] != keep[1][b][i];
+    *mismatch_out = bad;
     return HIPTS_OK;
 }
 

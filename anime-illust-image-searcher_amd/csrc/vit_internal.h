@@ -267,12 +267,19 @@ struct GemmArgs {
     int sk_first = 0, sk_slices = 1;        // set by the launcher: tiles [sk_first, tiles) are split sk_slices ways
     int raster_gn = 0;                      // > 0: column groups of this many column tiles outermost, row-major inside (set by the launcher)
     int raster_gm = 0;                      // > 0: tile order in groups of this many row panels, column-major inside (set by the launcher)
+    int epi_prio = 0;                       // the two waves of a SIMD alternate s_setprio through the epilogue's steps (set by the launcher from HIPTS_EPI_PRIO)
     int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
     int trace = 0;                          // diagnostic: per-workgroup timeline records instead of stamps (dw loop)
     unsigned long long* stamps = nullptr;   // diagnostic build only (tools/gemm_bench.py): s_memtime stamps of block 0
 };
 
 int launch_gemm(GemmEpilogue epi, const GemmArgs& a, hipStream_t s);
+// gemm4.hip: the 4-wave (one wave per SIMD) main loop for launches of whole 256 x 256 tiles with an even number of K-tiles and the
+// GELU / QK / RESID_XG epilogues; *handled = false: not built for this launch, the caller goes on to gemm_pp_kernel
+int launch_gemm_q4(GemmEpilogue epi, const GemmArgs& a, hipStream_t s, bool* handled);
+constexpr unsigned GEMM_Q4_DEFAULT_MASK = 0u;      // epilogues whose eligible launches take gemm4.hip by default (HIPTS_GEMM_Q4 overrides)
+void set_gemm_q4_mask(unsigned mask);
+long long gemm_q4_launch_count();              // launches gemm4.hip has taken so far (tests: the comparison really compared)
 constexpr size_t GEMM_SK_WS_BYTES = 4096 + 256 * (size_t)(256 * 256 * 4);      // tickets + one 256 x 256 fp32 slab per work item of a full round
 
 // softmax(Q K^T) V for every (image, head): q,k [B*H][tokens_pad][64] bf16 (q pre-scaled by

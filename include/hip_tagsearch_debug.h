@@ -22,6 +22,10 @@ int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float* ms_out);
 /* The same, and the shader clock (GHz) held inside the main loop of the stamped workgroup (s_memtime against the
  * 100 MHz s_memrealtime); 0 when the library was built without HIPTS_GEMM_STAMPS support for that epilogue. */
 int hiptsdbg_gemm_clock(int M, int N, int K, int epi, int iters, float* ms_out, float* loop_ghz);
+/* One GEMM launch through the 8-wave loop (csrc/gemm.hip) and through the 4-wave loop (csrc/gemm4.hip) on the same random operands: number
+ * of output bytes that differ (must be 0) and the average launch time each way (ms_out[0]: 8-wave, ms_out[1]: 4-wave).  epi: 4 (GELU),
+ * 1 (QK; N % 3 == 0: fused q | k | v), 13 (RESID_XG); M % 256 == 0, M % 784 == 0, N % 256 == 0, K % 128 == 0. */
+int hiptsdbg_gemm_q4_compare(int M, int N, int K, int epi, int f16, int iters, long long* mismatch_out, float* ms_out);
 /* y_host[i] = the GELU of the fc1 epilogue (csrc/gemm.hip gelu_f4) of x_host[i]; n % 4 == 0; tanh_form as hipts_vit_config::gelu_tanh. */
 int hiptsdbg_gelu(const float* x_host, int n, int tanh_form, float* y_host);
 /* The depthwise 7 x 7 (padding 3) of the CCIP encoder's SepConv blocks on its own: in / out IEEE-half bit patterns [batch][H][H][C] (host),

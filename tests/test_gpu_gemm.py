@@ -181,3 +181,25 @@ def test_fc1_epilogue_gelu_against_float64(form):
     assert np.isfinite(y).all()
     assert err.max() <= 3e-7, (err.max(), x[err.argmax()])
     assert (y[x >= 0] >= 0).all() and (np.abs(y[x > 6] / x[x > 6] - 1) <= 1.2e-7).all()
+
+
+def test_four_wave_loop_equals_eight_wave_loop_bit_for_bit():
+    """csrc/gemm4.hip (4 waves, one per SIMD, 128 x 128 per wave, accumulators in AGPRs, inline-asm MFMA / LDS / LDS-DMA stream; round 5, off by
+    default: HIPTS_GEMM_Q4) hands its accumulators to the same epilogues as gemm_pp_kernel and runs an element's MFMA chain over K in the
+    same order: every output buffer (16-bit GELU / q | k | v tensors, the fp32 residual stream, its 16-bit gamma * x copy, the row sums) must
+    agree byte for byte with the 8-wave loop on the same operands -- persistent grids (several tiles per workgroup: the K-tile stream runs
+    across tiles), 2 .. 48 K-tiles, both operand types."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "anime-illust-image-searcher_amd"))
+    from hiptagsearch import _lib
+    lib = _lib.load()
+    f = lib.hiptsdbg_gemm_q4_compare
+    f.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_float)]
+    cases = [(4, 25088, 3072, 128), (4, 25088, 1024, 768), (1, 25088, 2304, 256), (1, 25088, 1536, 128), (13, 25088, 768, 768), (13, 25088, 768, 3072)]
+    for f16 in (1, 0):
+        for epi, M, N, K in cases:
+            bad = ctypes.c_longlong(-1)
+            ms = (ctypes.c_float * 2)()
+            st = f(M, N, K, epi, f16, 1, ctypes.byref(bad), ms)
+            assert st == 0, (epi, M, N, K, f16, _lib.last_error())
+            assert bad.value == 0, (epi, M, N, K, f16, bad.value)
