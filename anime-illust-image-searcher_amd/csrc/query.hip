@@ -1485,6 +1485,12 @@ __device__ void search1_state_debug(Search1State* st, uint32_t cnt, uint32_t fas
     }
 }
 
+// PIPE (round 5, the default; HIPTS_S1_PIPE=0 runs the sequential form): the BM25 part is a chain of dependent round trips -- the span's
+// bounds, its term ids (up to 12 passes of four loads -> LDS, each a round trip of its own), the matches' tf, the idf values -- about 12 of
+// the kernel's 32 us during which only ONE round of the index stream was in flight.  Here the rounds of the stream are dealt between the
+// chain's steps (two rounds in flight throughout, every consume waits only for loads older than the chain's), the term ids are requested 16
+// per lane at once, and the idf values go through LDS, requested with the first round.  Same operations per document in the same order.
+template <bool PIPE>
 __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1Query Q, const float4* __restrict__ tiled, int64_t D,
                                                                    const int64_t* __restrict__ ptr, const int32_t* __restrict__ term,
                                                                    const int32_t* __restrict__ tf, const int32_t* __restrict__ dl,
@@ -1507,7 +1513,7 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
     const float4* __restrict__ p = tiled + ((dd >> 5) * KQ) * 32 + (dd & 31);
     constexpr int U = 8;
     static_assert(S1_MAX_DIM % (4 * U) == 0, "Q.q must cover whole rounds");
-    float4 va[U], vb[U];
+    float4 va[U], vb[U], vc[U];      // (vc: the PIPE form keeps THREE rounds in flight -- the chain's LDS phases are longer than a round)
     auto request = [&](float4(&v)[U], int kq0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1526,6 +1532,27 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
             acc = fmaf(v[u].w, qq[3], acc);
         }
     };
+    const int rounds = (KQ + U - 1) / U;
+    // one step of the stream: round r is consumed, round r + 2 requested into its buffer (past the end: a clamped re-read nobody consumes)
+    constexpr int AHEAD = PIPE ? 3 : 2;
+    auto step_a = [&](int r) {
+        if (r < rounds) {
+            consume(va, r * U);
+            request(va, (r + AHEAD) * U);
+        }
+    };
+    auto step_b = [&](int r) {
+        if (r < rounds) {
+            consume(vb, r * U);
+            request(vb, (r + AHEAD) * U);
+        }
+    };
+    auto step_c = [&](int r) {
+        if (r < rounds) {
+            consume(vc, r * U);
+            request(vc, (r + AHEAD) * U);
+        }
+    };
     request(va, 0);
     // ---- BM25 (webui.py:139-170), the arithmetic of bm25_score_kernel.  The (term, tf) lists of a workgroup's documents are one
     // contiguous span of the document-major CSR: its term ids are staged in LDS with coalesced loads, then walked ONCE, coalesced:
@@ -1541,6 +1568,104 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
     const int64_t b0 = ptr[d_first], e0 = ptr[d_last];
     const bool staged = e0 - b0 <= S1_LDS_TERMS;
     const int nspan = staged ? (int)(e0 - b0) : 0;
+    __shared__ double sidf[S1_MAX_TERMS];
+    const int64_t b = ptr[dd], e = ptr[dd + 1];
+    const double dlv = (double)dl[dd];
+    double s = 0.0;
+    bool masked = false;
+    if constexpr (PIPE) {
+        double idf_mine = 0.0;
+        if (tid < Q.nt) {
+            const int32_t t = Q.terms[tid];
+            idf_mine = (t >= 0 && t < V) ? idf[t] : 0.0;
+        }
+        request(vb, U);
+        request(vc, 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        step_a(0);
+        // the span's term ids, 16 per lane in flight (2048 ids per pass: most spans in one)
+        constexpr int TU = 16;
+        int32_t t16[TU];
+        auto req_terms = [&](int i0) {
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int i = i0 + u * S1_THREADS + tid;
+                t16[u] = i < nspan ? term[b0 + i] : 0;
+            }
+        };
+        auto put_terms = [&](int i0) {
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int i = i0 + u * S1_THREADS + tid;
+                if (i < nspan) sterm[i] = t16[u];
+            }
+        };
+        if (nspan > 0) req_terms(0);
+        __builtin_amdgcn_sched_barrier(0);
+        step_b(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nspan > 0) put_terms(0);
+        for (int i0 = TU * S1_THREADS; i0 < nspan; i0 += TU * S1_THREADS) {
+            req_terms(i0);
+            put_terms(i0);
+        }
+        for (int j = 0; j < Q.nt; ++j) stf[j][tid] = 0;
+        sptr[tid] = valid ? (int)(b - b0) : (int)(e0 - b0);
+        if (tid == 0) sptr[S1_THREADS] = (int)(e0 - b0);
+        if (tid < Q.nt) sidf[tid] = idf_mine;
+        __syncthreads();
+        step_c(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (staged) {
+            for (int i = tid; i < nspan; i += S1_THREADS) {
+                const int32_t ti = sterm[i];
+                for (int j = 0; j < Q.nt; ++j)
+                    if (ti == Q.terms[j]) {
+                        int lo = 0, hi = S1_THREADS;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (sptr[mid] <= i) lo = mid;
+                            else hi = mid;
+                        }
+                        stf[j][lo] = tf[b0 + i];
+                    }
+            }
+            __syncthreads();
+        } else {
+            for (int64_t i = b; i < e; ++i) {
+                const int32_t ti = term[i];
+                for (int j = 0; j < Q.nt; ++j)
+                    if (ti == Q.terms[j]) stf[j][tid] = tf[i];
+            }
+        }
+        step_a(3);
+        __builtin_amdgcn_sched_barrier(0);
+        const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv / avgdl));
+        for (int j = 0; j < Q.nt; ++j) {
+            const double w = Q.weights[j];
+            const int32_t tfv = stf[j][tid];
+            const double idf_t = sidf[j];
+            const double tfd = (double)tfv;
+            const double sc = idf_t * ((tfd * (BM25_K1 + 1.0)) / (tfd + nrm));
+            if (w < 0.0) {
+                if (tfv > 0) masked = true;
+            } else if (w > REQUIRE_MAGIC) {
+                s += (w - REQUIRE_MAGIC) * sc;
+                if (tfv == 0) masked = true;
+            } else {
+                s += w * sc;
+            }
+        }
+        if (masked) s = -INFINITY;
+        // ---- the rest of the index stream
+        step_b(4);
+        step_c(5);
+        for (int r = 6; r < rounds; r += 3) {
+            step_a(r);
+            step_b(r + 1);
+            step_c(r + 2);
+        }
+    } else {
     for (int i0 = 0; i0 < nspan; i0 += 4 * S1_THREADS) {
         int32_t t4[4];
 #pragma unroll
@@ -1555,10 +1680,8 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
         }
     }
     for (int j = 0; j < Q.nt; ++j) stf[j][tid] = 0;
-    const int64_t b = ptr[dd], e = ptr[dd + 1];
     sptr[tid] = valid ? (int)(b - b0) : (int)(e0 - b0);         // where this thread's document starts inside the staged span (threads past D: nowhere)
     if (tid == 0) sptr[S1_THREADS] = (int)(e0 - b0);
-    const double dlv = (double)dl[dd];
     __syncthreads();
     if (staged) {
         for (int i = tid; i < nspan; i += S1_THREADS) {
@@ -1583,8 +1706,6 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
         }
     }
     const double nrm = BM25_K1 * ((1.0 - BM25_B) + BM25_B * (dlv / avgdl));
-    double s = 0.0;
-    bool masked = false;
     for (int j = 0; j < Q.nt; ++j) {
         const int32_t t = Q.terms[j];
         const double w = Q.weights[j];
@@ -1603,7 +1724,6 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
     }
     if (masked) s = -INFINITY;
     // ---- the index stream
-    const int rounds = (KQ + U - 1) / U;
     int r = 0;
     for (; r + 2 <= rounds; r += 2) {
         request(vb, (r + 1) * U);
@@ -1612,6 +1732,7 @@ __global__ __launch_bounds__(S1_THREADS) void search1_score_kernel(const Search1
         consume(vb, (r + 1) * U);
     }
     if (r < rounds) consume(va, r * U);
+    }
     if (valid) {
         bm_out[d] = s;
         sim_out[d] = acc;
@@ -2222,10 +2343,17 @@ int search_one(hipts_bm25* bm25, hipts_index* index, const int32_t* q_terms, con
     }
     {
         QueryProfScope ps(bm25, s, QP_S1_SCORE, (double)D * index->dim * 4.0 + (double)bm25->nnz * 8.0 + (double)D * (8 + 4 + 8 + 4));
-        search1_score_kernel<<<ceil_div(D, S1_THREADS), S1_THREADS, 0, s>>>(Q, index->tiled.as<float4>(), D, bm25->d_ptr.as<int64_t>(),
-                                                                            bm25->d_term.as<int32_t>(), bm25->d_tf.as<int32_t>(),
-                                                                            bm25->d_dl.as<int32_t>(), bm25->d_idf.as<double>(), bm25->V, bm25->avgdl,
-                                                                            bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), st, wit);
+        static const bool pipe = !(getenv("HIPTS_S1_PIPE") && atoi(getenv("HIPTS_S1_PIPE")) == 0);      // A/B: the sequential form
+        if (pipe)
+            search1_score_kernel<true><<<ceil_div(D, S1_THREADS), S1_THREADS, 0, s>>>(Q, index->tiled.as<float4>(), D, bm25->d_ptr.as<int64_t>(),
+                                                                                  bm25->d_term.as<int32_t>(), bm25->d_tf.as<int32_t>(),
+                                                                                  bm25->d_dl.as<int32_t>(), bm25->d_idf.as<double>(), bm25->V, bm25->avgdl,
+                                                                                  bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), st, wit);
+        else
+            search1_score_kernel<false><<<ceil_div(D, S1_THREADS), S1_THREADS, 0, s>>>(Q, index->tiled.as<float4>(), D, bm25->d_ptr.as<int64_t>(),
+                                                                                   bm25->d_term.as<int32_t>(), bm25->d_tf.as<int32_t>(),
+                                                                                   bm25->d_dl.as<int32_t>(), bm25->d_idf.as<double>(), bm25->V, bm25->avgdl,
+                                                                                   bm25->ws_scores.as<double>(), bm25->ws_sims.as<float>(), st, wit);
         HIPTS_LAUNCH_CHECK();
     }
     if (finish) {

@@ -90,7 +90,11 @@ def test_eva02_large_trained_like_checkpoint():
     mx, rel = np.abs(d).max(axis=1), np.sqrt((d ** 2).mean(axis=1)) / rms_l
     for name, a, r in zip(("noise", "flat", "blocks"), mx, rel):
         print("EVA02-L trained-like, %-6s max |dlogit| %.3e  rms-relative %.3e  (logit rms %.2f)" % (name, a, r, rms_l.mean()))
-    assert rel.max() <= 2e-3 and mx.max() <= 1e-1, (mx, rel)
+    # Bounds = what is measured (noise 2.6e-2 / rms-relative 6.1e-4, flat 2.5e-3, blocks 9e-3; bench.py's eva02_large.oracle_check carries the
+    # same numbers) + 25 %.  Attribution (tools/logit_attribution.py --model eva, profiles/r05_eva_attribution.txt): every 16-bit operand carries
+    # about 1e-2 of it on the noise image (xn1 1.3e-2, q|k|v 1.5e-2, xn2 1.1e-2, hmid 6.6e-3, att 4.5e-3, P 1.9e-3) -- amplification through
+    # 24 blocks of peaked attention, not one operand: the cheapest single hi | lo split (q, k, v) would buy 19 %.
+    assert rel.max() <= 8e-4 and mx.max() <= 3.3e-2, (mx, rel)
     names, cat = synth.label_table(cfg["num_classes"])
     counts, ids, _ = TagSelector(cat, max_batch=4).run(probs, 0.3, True, 0.3, True)
     gi, ci = list(np.where(cat == 0)[0]), list(np.where(cat == 4)[0])

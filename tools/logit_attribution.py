@@ -89,8 +89,55 @@ def forward(w, x, rd, heads=12, eps=1e-6, folded=True):
     return F.linear(f, w["head.weight"], w["head.bias"])
 
 
+@torch.no_grad()
+def forward_eva(w, x, rd, heads=16, eps=1e-6, ref_grid=16, patch=14):
+    """oracle/eva.py::eva_forward with the HIP path's operand roundings (csrc/eva.hip): xn1 = 16bit(gamma1 * x) into q | k | v; q, k (after
+    the rotary embedding, q pre-scaled) and v; P; the attention output into proj; xn2 = 16bit(gamma2 * x) into the SwiGLU GEMM; hmid =
+    16bit(gamma_mlp * silu(g) * u) into fc2 (the inner LayerNorm folded like the outer ones)."""
+    from oracle import eva as oeva
+    B = x.shape[0]
+    t = F.conv2d(x, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+    grid = int(round(t.shape[1] ** 0.5))
+    t = torch.cat([w["cls_token"].expand(B, -1, -1), t], dim=1) + w["pos_embed"]
+    N, D = t.shape[1], t.shape[2]
+    hd = D // heads
+    sin, cos = oeva.rope_tables(grid, hd, ref_grid)
+    depth = 1 + max(int(k.split(".")[1]) for k in w if k.startswith("blocks."))
+
+    def ln(t, g, b, name, i):
+        mu = t.mean(-1, keepdim=True)
+        rstd = torch.rsqrt(t.var(-1, unbiased=False, keepdim=True) + eps)
+        return (rd(name, t * g, i) - mu * g) * rstd + b
+
+    for i in range(depth):
+        p = "blocks.%d." % i
+        h = ln(t, w[p + "norm1.weight"], w[p + "norm1.bias"], "xn1", i)
+        q = F.linear(h, w[p + "attn.q_proj.weight"], w[p + "attn.q_proj.bias"]).reshape(B, N, heads, hd).transpose(1, 2)
+        k = F.linear(h, w[p + "attn.k_proj.weight"]).reshape(B, N, heads, hd).transpose(1, 2)
+        v = F.linear(h, w[p + "attn.v_proj.weight"], w[p + "attn.v_proj.bias"]).reshape(B, N, heads, hd).transpose(1, 2)
+        q = torch.cat([q[:, :, :1], q[:, :, 1:] * cos + oeva._rot(q[:, :, 1:]) * sin], dim=2)
+        k = torch.cat([k[:, :, :1], k[:, :, 1:] * cos + oeva._rot(k[:, :, 1:]) * sin], dim=2)
+        q = rd("qkv", q * (hd ** -0.5 * 1.4426950408889634), i)
+        k = rd("qkv", k, i)
+        v = rd("qkv", v, i)
+        s = q @ k.transpose(-2, -1)
+        pw = torch.exp2(s - s.max(-1, keepdim=True).values)
+        l = pw.sum(-1, keepdim=True)
+        o = ((rd("P", pw, i) @ v) / l).transpose(1, 2).reshape(B, N, D)
+        t = t + F.linear(rd("att", o, i), w[p + "attn.proj.weight"], w[p + "attn.proj.bias"])
+        h = ln(t, w[p + "norm2.weight"], w[p + "norm2.bias"], "xn2", i)
+        g = F.linear(h, w[p + "mlp.fc1_g.weight"], w[p + "mlp.fc1_g.bias"])
+        u = F.linear(h, w[p + "mlp.fc1_x.weight"], w[p + "mlp.fc1_x.bias"])
+        m = ln(F.silu(g) * u, w[p + "mlp.norm.weight"], w[p + "mlp.norm.bias"], "hmid", i)
+        t = t + F.linear(m, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+    f = t[:, 1:].mean(dim=1)
+    f = F.layer_norm(f, (D,), w["fc_norm.weight"], w["fc_norm.bias"], eps)
+    return F.linear(f, w["head.weight"], w["head.bias"])
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", choices=["vit", "eva"], default="vit", help="eva: EVA02-L/14, the model the reference loads (tagging.py:45); 3 images")
     ap.add_argument("--random-init", action="store_true", help="the random-init checkpoint instead of the trained-like one")
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--dither", action="store_true")
@@ -103,16 +150,25 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
-    cfg = dict(synth.VIT_B16_448)
-    w = ovit.to_torch(synth.vit_weights(cfg, seed=0, trained_like=not a.random_init))
-    imgs = np.concatenate([synth.images_u8(2, 448, seed=5), synth.structured_images_u8(448, seed=a.seed)])
-    kinds = ["noise", "noise"] + list(synth.STRUCTURED_KINDS)
+    if a.model == "eva":        # the images of tests/test_gpu_eva.py::test_eva02_large_trained_like_checkpoint
+        cfg = dict(synth.EVA02_L14_448)
+        w = ovit.to_torch(synth.eva_weights(cfg, seed=0, trained_like=not a.random_init))
+        imgs = np.concatenate([synth.images_u8(1, 448, seed=5), synth.structured_images_u8(448, seed=a.seed, kinds=("flat", "blocks"))])
+        kinds = ["noise", "flat", "blocks"]
+    else:
+        cfg = dict(synth.VIT_B16_448)
+        w = ovit.to_torch(synth.vit_weights(cfg, seed=0, trained_like=not a.random_init))
+        imgs = np.concatenate([synth.images_u8(2, 448, seed=5), synth.structured_images_u8(448, seed=a.seed)])
+        kinds = ["noise", "noise"] + list(synth.STRUCTURED_KINDS)
     x = ovit.preprocess_u8_nhwc(imgs)
     blocks = tuple(int(v) for v in a.blocks.split("-"))
     split = [s for s in a.split.split(",") if s]
 
     def run(on):
-        return forward(w, x, Rounder(on, split, a.bf16, blocks, a.dither), folded=not a.unfolded).numpy().astype(np.float64)
+        rd = Rounder(on, split, a.bf16, blocks, a.dither)
+        if a.model == "eva":
+            return forward_eva(w, x, rd).numpy().astype(np.float64)
+        return forward(w, x, rd, folded=not a.unfolded).numpy().astype(np.float64)
 
     t0 = time.time()
     base = run(())
