@@ -312,6 +312,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
 
         bf16x8 wf[2][4];
         i32x8 wf8[4], af8[4];
+        unsigned xpf = 0;       // destination of the epilogue prefetch: stays allocated until the epilogue's own loads have been waited for
         for (int t = 0; t < nt; ++t) {
             const char* cur = smem + ((par + t) & 1) * STAGE_BYTES;
             char* nxt = smem + ((par + t + 1) & 1) * STAGE_BYTES;
@@ -399,6 +400,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
                     }
                 } else if (p == 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if constexpr (INT) {
+                    // HIPTS_EPI_PREFETCH (A/B): behind the loop's last counted wait, one dword of each of the 256 lines of this wave's part of
+                    // the fp32 stream is requested into a register nobody reads -- the epilogue's four load steps then find the tile in L2
+                    // instead of paying the trip beyond it four times in sequence.  (Earlier in the loop it cannot go: vmcnt retires in order,
+                    // every later wait for a K-tile would wait for these loads too.)
+                    if (!more && p == 2 && a.epi_prefetch) {
+                        const int ldx = a.ld_out ? a.ld_out : a.N;
+                        const char* xb = reinterpret_cast<const char*>(a.out_f32 + (size_t)(m0 + wave_m * 128) * ldx + n0 + wave_n * 64);
+                        const unsigned o0 = (unsigned)(((lane >> 1) * ldx + (lane & 1) * 32) * 4), ost = (unsigned)(32 * ldx * 4);
+                        asm volatile("global_load_dword %0, %1, %5\n\tglobal_load_dword %0, %2, %5\n\tglobal_load_dword %0, %3, %5\n\tglobal_load_dword %0, %4, %5"
+                                     : "=&v"(xpf)
+                                     : "v"(o0), "v"(o0 + ost), "v"(o0 + 2 * ost), "v"(o0 + 3 * ost), "s"(xb)
+                                     : "memory");
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -563,6 +579,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gem
                                              fold_st ? st_table : nullptr, INT ? colvec : nullptr);
         }       // run_epilogue
         if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
+        if constexpr (INT) asm volatile("" ::"v"(xpf));
         PPSTAMP(5);
         ++stamp_tile;
         if (!has_next) break;
@@ -1172,6 +1189,8 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
             GemmArgs ar = a;
             static const int epi_prio = getenv("HIPTS_EPI_PRIO") ? atoi(getenv("HIPTS_EPI_PRIO")) : 0;
             ar.epi_prio = epi_prio;
+            static const int epi_prefetch = getenv("HIPTS_EPI_PREFETCH") ? atoi(getenv("HIPTS_EPI_PREFETCH")) : 0;
+            ar.epi_prefetch = epi_prefetch;
             ar.raster_gm = (raster > 0 && tiles_n >= 8) ? raster : 0;
             ar.raster_gn = (raster_gn > 0 && tiles_n >= 8 && tiles_n > raster_gn) ? raster_gn : 0;
             {   // the 4-wave, one-wave-per-SIMD loop (gemm4.hip) where it is built: HIPTS_GEMM_Q4 = bit mask over epilogue numbers (A/B)

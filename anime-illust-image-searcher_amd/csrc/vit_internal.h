@@ -267,6 +267,7 @@ struct GemmArgs {
     int sk_first = 0, sk_slices = 1;        // set by the launcher: tiles [sk_first, tiles) are split sk_slices ways
     int raster_gn = 0;                      // > 0: column groups of this many column tiles outermost, row-major inside (set by the launcher)
     int raster_gm = 0;                      // > 0: tile order in groups of this many row panels, column-major inside (set by the launcher)
+    int epi_prefetch = 0;                   // interior residual epilogue: its fp32 tile is requested into L2 during the last K-tile (HIPTS_EPI_PREFETCH)
     int epi_prio = 0;                       // the two waves of a SIMD alternate s_setprio through the epilogue's steps (set by the launcher from HIPTS_EPI_PRIO)
     int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
     int trace = 0;                          // diagnostic: per-workgroup timeline records instead of stamps (dw loop)
