@@ -38,6 +38,8 @@ struct Block {
     DevBuf fc1, fc2;               // [4C,C], [C,4C]
     DevBuf mlp_img;                // the two as the chunk images of the fused MLP kernel (mlp.hip; widths 128 / 256, half operands)
     std::vector<float> fc1_host, fc2_host;      // host copies (stages 0-1: 15 MB in all): the image is rebuilt whenever either tensor is set again
+    DevBuf u_qk, u_v, u_fc1;       // attention blocks of the wide stages: W gamma per output column of q | k, v (norm1) and fc1 (norm2) -- the
+                                   // LayerNorm folded into the consumer GEMM (round 5; EPI_RESID_XG prepares gamma * x and the row sums)
     DevBuf rs1, rs2;               // optional res_scale vectors
     bool has_rs1 = false, has_rs2 = false;
     float s1 = 1.f, b1 = 0.f;      // token-mixer StarReLU
@@ -63,6 +65,9 @@ struct hipts_ccip {
     std::vector<std::string> missing;
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, h1, h2, m1, col, q, k, vT, feat;
+    DevBuf stat_part, fold_c;      // folded LayerNorms of the wide stages: per (256-column tile, row) partial (sum, sum of squares); scratch for W beta (unused: no beta)
+    size_t pstat = 0;              // float2 per image of stat_part (largest wide stage)
+    bool fold_dirty = true;        // a norm / qkv / fc1 tensor changed since the fold vectors were computed
     size_t px = 0, p2c = 0, p4c = 0, pcol = 0, pqk = 0;   // per-image element strides of the workspace buffers (largest stage)
     hipStream_t sub[2] = {};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {};
@@ -748,10 +753,34 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         // that produces the row (EPI_RESID_LN): the separate pass over the fp32 stream is the largest HBM
         // consumer of the wide early stages.
         const bool fuse_ln = C <= 256 && !getenv("HIPTS_CCIP_NO_LN_FUSION");
+        // Wide stages (rows of more than one 256-column tile: C = 512, 768; round 5): the LayerNorms are folded as in the ViT -- the residual
+        // GEMM that finishes a row (EPI_RESID_XG, here with the CAFormer's res_scale) also writes gamma * x as the consumer's 16-bit operand
+        // and the row's partial sums; q | k, v and fc1 apply rstd / mean in their epilogues (col_u = W gamma; the CAFormer's norms have no
+        // beta).  40 of a forward's 45 layernorm_kernel launches (5.2 % of its kernel time, each a pass over the fp32 stream) go; a stage's
+        // first norm1 (its rows come from the downsample GEMM) and the downsample norms (their consumer is the im2col) stay.  Only when the
+        // stage's residual launches are not the two-workgroups-per-CU kernel's anyway (that loop has no statistics epilogue): more tiles
+        // than half the CUs.  HIPTS_CCIP_LN_FOLD=0: off (A/B).
+        static const bool fold_env = !(getenv("HIPTS_CCIP_LN_FOLD") && atoi(getenv("HIPTS_CCIP_LN_FOLD")) == 0);
+        const int cus_dev = current_device_cus(nullptr);
+        const int sblocks = (C + 255) / 256;
+        const bool fold23 = fold_env && !fuse_ln && si >= c.attn_from_stage && C % 256 == 0 && M % 256 == 0 && h->stat_part.p &&
+                            (long)((M + 255) / 256) * sblocks * 4 > (long)cus_dev * 2;
+        float* stat_p = fold23 ? h->stat_part.as<float>() + 2 * (size_t)i0 * h->pstat : nullptr;
+        bool xn_folded = false;         // xn holds gamma * x + stat_p the row sums (not the LayerNorm itself)
+        auto folded = [&](GemmArgs& ga, const float* u) {
+            ga.stat_in = stat_p; ga.stat_in_blocks = sblocks; ga.stat_in_stride = M; ga.ln_dim = C; ga.ln_eps = c.ln_eps;
+            ga.col_u = u; ga.bias = zeros;
+        };
+        auto residual_xg = [&](GemmArgs& ga, const float* rs, const float* gamma) -> int {
+            ga.res_scale = rs; ga.ln_gamma = gamma; ga.ln_eps = c.ln_eps; ga.out_bf16 = xn; ga.stat_part = stat_p; ga.stat_stride = M;
+            return launch_gemm(EPI_RESID_XG, ga, s);
+        };
         for (size_t bi = 0; bi < St.blocks.size(); ++bi) {
             Block& B = St.blocks[bi];
+            const bool in_folded = xn_ready && xn_folded;
             if (!xn_ready) HIPTS_TRY(layernorm_xn(B.n1.as<float>(), M, C));
             xn_ready = false;
+            xn_folded = false;
             // LayerNorm that follows this block's MLP: the next block's norm1, or the next stage's downsample norm
             const float* next_gamma = bi + 1 < St.blocks.size() ? St.blocks[bi + 1].n1.as<float>()
                                       : (si < 3 ? h->st[si + 1].ds_norm.as<float>() : nullptr);
@@ -783,6 +812,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g.out_bf16 = qb; g.out2_bf16 = kb;
                 g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
                 g.qscale = 0.17677669529663687f * 1.4426950408889634f;      // 32^-0.5 * log2(e): attention works in base 2
+                if (in_folded) folded(g, B.u_qk.as<float>());
                 HIPTS_TRY(gemm(EPI_QK, g, s));
                 g = GemmArgs{};
                 g.f16 = f16;
@@ -790,6 +820,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g.A = xn; g.W = B.w_in.as<bf16_t>() + (size_t)2 * C * C; g.M = M; g.N = C; g.K = C; g.bias = zeros;
                 g.out_bf16 = vb;
                 g.tokens = T; g.tokens_pad = Tp; g.heads = heads; g.dim = C; g.hd_log2 = 5;
+                if (in_folded) folded(g, B.u_v.as<float>());
                 HIPTS_TRY(gemm(EPI_VT, g, s));
                 HIPTS_TRY(launch_attention(qb, kb, vb, h1, batch, heads, T, Tp,
                                            f16, s, 32));
@@ -797,10 +828,12 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
                 g.f16 = f16;
                 g.shared_chip = shared_chip;
                 g.A = h1; g.W = B.w_out.as<bf16_t>(); g.M = M; g.N = C; g.K = C; g.bias = zeros; g.out_f32 = x;
-                HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr));
+                if (fold23) HIPTS_TRY(residual_xg(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, B.n2.as<float>()));
+                else HIPTS_TRY(residual(g, B.has_rs1 ? B.rs1.as<float>() : nullptr, fuse_ln ? B.n2.as<float>() : nullptr));
             }
             // MLP: fc1 + StarReLU, fc2 + residual
-            if (!fuse_ln) HIPTS_TRY(layernorm_xn(B.n2.as<float>(), M, C));
+            const bool mlp_folded = fold23 && B.attn;
+            if (!fuse_ln && !mlp_folded) HIPTS_TRY(layernorm_xn(B.n2.as<float>(), M, C));
             if (fused_mlp && fuse_ln && f16 && B.mlp_img.p) {
                 // stages 0-1 (rows of <= 256 columns): one kernel, the hidden tensor stays in registers (mlp.hip)
                 const bool fuse_next = next_gamma != nullptr;
@@ -813,14 +846,19 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
             g.shared_chip = shared_chip;
             g.A = xn; g.W = B.fc1.as<bf16_t>(); g.M = M; g.N = 4 * C; g.K = C; g.bias = zeros;
             g.out_bf16 = m1; g.star_scale = B.s2; g.star_bias = B.b2;
+            if (mlp_folded) folded(g, B.u_fc1.as<float>());
             HIPTS_TRY(gemm(EPI_STAR, g, s));
             g = GemmArgs{};
             g.f16 = f16;
             g.shared_chip = shared_chip;
             g.A = m1; g.W = B.fc2.as<bf16_t>(); g.M = M; g.N = C; g.K = 4 * C; g.bias = zeros; g.out_f32 = x;
             const bool fuse_next = fuse_ln && next_gamma != nullptr;
-            HIPTS_TRY(residual(g, B.has_rs2 ? B.rs2.as<float>() : nullptr, fuse_next ? next_gamma : nullptr));
-            xn_ready = fuse_next;
+            // folded: the next block's norm1 (same stage: an attention block too) is prepared here
+            const bool xg_next = fold23 && bi + 1 < St.blocks.size() && St.blocks[bi + 1].attn;
+            if (xg_next) HIPTS_TRY(residual_xg(g, B.has_rs2 ? B.rs2.as<float>() : nullptr, St.blocks[bi + 1].n1.as<float>()));
+            else HIPTS_TRY(residual(g, B.has_rs2 ? B.rs2.as<float>() : nullptr, fuse_next ? next_gamma : nullptr));
+            xn_ready = fuse_next || xg_next;
+            xn_folded = xg_next;
         }
     }
     // ---- head: global average pool -> LayerNorm
@@ -849,6 +887,26 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
     }
     const bool dev_out = out_memspace == HIPTS_DEVICE;
     float* f_dev = dev_out ? out : h->feat.as<float>();
+    if (h->fold_dirty) {        // W gamma of the wide stages' q | k, v and fc1 (folded LayerNorms): once per checkpoint
+        const bool f16w = c.operand_f16 != 0;
+        for (int si = c.attn_from_stage; si < 4; ++si) {
+            Stage& St = h->st[si];
+            const int C = St.C;
+            if (C <= 256 || C % 256) continue;
+            HIPTS_TRY(h->fold_c.reserve((size_t)4 * C * 4));
+            for (Block& B : St.blocks) {
+                if (!B.attn) continue;
+                HIPTS_TRY(B.u_qk.reserve((size_t)2 * C * 4));
+                HIPTS_TRY(B.u_v.reserve((size_t)C * 4));
+                HIPTS_TRY(B.u_fc1.reserve((size_t)4 * C * 4));
+                HIPTS_TRY(launch_fold_ln(B.w_in.as<bf16_t>(), f16w, B.n1.as<float>(), nullptr, nullptr, B.u_qk.as<float>(), h->fold_c.as<float>(), 2 * C, C, s));
+                HIPTS_TRY(launch_fold_ln(B.w_in.as<bf16_t>() + (size_t)2 * C * C, f16w, B.n1.as<float>(), nullptr, nullptr, B.u_v.as<float>(),
+                                         h->fold_c.as<float>(), C, C, s));
+                HIPTS_TRY(launch_fold_ln(B.fc1.as<bf16_t>(), f16w, B.n2.as<float>(), nullptr, nullptr, B.u_fc1.as<float>(), h->fold_c.as<float>(), 4 * C, C, s));
+            }
+        }
+        h->fold_dirty = false;
+    }
     // Two sub-batches on two internal streams (as in the ViT forward): the late stages have fewer output
     // tiles than the chip has CUs, and a kernel of one half fills the CUs the other half leaves idle.
     static const int want_streams = getenv("HIPTS_CCIP_STREAMS") ? atoi(getenv("HIPTS_CCIP_STREAMS")) : 2;
@@ -927,6 +985,7 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
             flops += 2.0 * T * 4 * C * C * 2;
         }
         h->px = std::max(h->px, (size_t)St.T * St.C);
+        if (St.C > 256 && St.C % 256 == 0) h->pstat = std::max(h->pstat, (size_t)(St.C / 256) * St.T);
         h->p2c = std::max(h->p2c, (size_t)St.T * 2 * St.C);
         h->p4c = std::max(h->p4c, (size_t)St.T * 4 * St.C);
         if (s > 0) h->pcol = std::max(h->pcol, (size_t)St.T * 9 * cfg->dims[s - 1]);
@@ -949,7 +1008,8 @@ int hipts_ccip_create(const hipts_ccip_config_t* cfg, int device, hipts_ccip_t**
     if ((st = upload_f32(h->zeros, z.data(), z.size())) || (st = upload_f32(h->lut, lut.data(), lut.size())) || (st = h->a0.alloc((size_t)B * h->st[0].T * STEM_K * 2)) ||
         (st = h->x.alloc(max_x * 4)) || (st = h->xn.alloc(max_x * 2)) || (st = h->h1.alloc(max_2c * 2)) || (st = h->h2.alloc(max_2c * 2)) ||
         (st = h->m1.alloc(max_4c * 2)) || (st = h->col.alloc(max_col * 2)) || (st = h->q.alloc(max_qk * 2)) || (st = h->k.alloc(max_qk * 2)) ||
-        (st = h->vT.alloc(max_qk * 2)) || (st = h->feat.alloc((size_t)B * cfg->dims[3] * 4))) {
+        (st = h->vT.alloc(max_qk * 2)) || (st = h->feat.alloc((size_t)B * cfg->dims[3] * 4)) ||
+        (h->pstat && (st = h->stat_part.alloc((size_t)B * h->pstat * 8)))) {
         delete h;
         return st;
     }
@@ -1104,6 +1164,7 @@ int hipts_ccip_set_tensor(hipts_ccip_t* h, const char* key_c, const float* data,
     } else return set_error(HIPTS_ERR_INVALID, "unknown tensor key %s", key_c);
 #undef EXPECT
     if (st) return st;
+    h->fold_dirty = true;
     auto it = std::find(h->missing.begin(), h->missing.end(), key);
     if (it != h->missing.end()) h->missing.erase(it);
     return HIPTS_OK;

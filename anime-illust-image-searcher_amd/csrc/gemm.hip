@@ -1248,7 +1248,7 @@ int launch_t(const GemmArgs& a, hipStream_t s) {
                 // every tile inside the matrix: the instantiation without per-lane predication (HIPTS_RESID_GENERAL=1: the general one, A/B).
                 // (Not instantiated for RESID_XGI: its only user, EVA02, has 1025 tokens per image -- no launch of whole tiles -- and with the
                 // input fold's extra column vector the interior form compiled to 60 spilled registers.)
-                if (mr == 8 && a.M % 256 == 0 && a.N % 256 == 0 && a.N <= 1024 && !a.pos && a.out_bf16 && a.stat_part && !resid_general) {
+                if (mr == 8 && a.M % 256 == 0 && a.N % 256 == 0 && a.N <= 1024 && !a.pos && !a.res_scale && a.out_bf16 && a.stat_part && !resid_general) {
                     static PerDevice attr_int;
                     {
                         std::lock_guard<std::mutex> lk(attr_int.mu);

@@ -417,7 +417,7 @@ int launch_gemm_q4(GemmEpilogue epi, const GemmArgs& a, hipStream_t s, bool* han
         case EPI_QK:
             return f16 ? launch_q4_t<EPI_QK, true, false>(a, s, tiles_m, tiles_n, cus, dev) : launch_q4_t<EPI_QK, false, false>(a, s, tiles_m, tiles_n, cus, dev);
         case EPI_RESID_XG: {
-            const bool interior = a.N <= 1024 && !a.pos && a.out_bf16 && a.stat_part && !a.rowstat && !a.stat_in;
+            const bool interior = a.N <= 1024 && !a.pos && !a.res_scale && a.out_bf16 && a.stat_part && !a.rowstat && !a.stat_in;
             if (interior)
                 return f16 ? launch_q4_t<EPI_RESID_XG, true, true>(a, s, tiles_m, tiles_n, cus, dev) : launch_q4_t<EPI_RESID_XG, false, true>(a, s, tiles_m, tiles_n, cus, dev);
             return f16 ? launch_q4_t<EPI_RESID_XG, true, false>(a, s, tiles_m, tiles_n, cus, dev) : launch_q4_t<EPI_RESID_XG, false, false>(a, s, tiles_m, tiles_n, cus, dev);

@@ -662,6 +662,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     for (int j = 0; j < 4; ++j) {
                         if constexpr (fold)
                             acc[i2 + u][j] = nv[j] ? xv[u][j] + (acc[i2 + u][j] * st[u].x + (bv[j] - uv[j] * st[u].y)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        else if (a.res_scale)      // (round 5) the CAFormer's scaled residual, EPI_RESCALE's expression: x = x * rs + (acc + bias)
+                            acc[i2 + u][j] = nv[j] ? xv[u][j] * *reinterpret_cast<const f32x4*>(a.res_scale + nc[j]) + (acc[i2 + u][j] + bv[j])
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
                         else
                             acc[i2 + u][j] = nv[j] ? (a.pos ? acc[i2 + u][j] * a.qscale + bv[j] + xv[u][j] : xv[u][j] + (acc[i2 + u][j] + bv[j]))
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};

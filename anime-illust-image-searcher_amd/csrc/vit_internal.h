@@ -206,7 +206,8 @@ enum GemmEpilogue {
                             // the LayerNorm folded in -- A holds gamma * p (raw rows times the LayerNorm weight, written by the producer),
                             // col_u[n] = sum_k W[n][k] gamma[k], bias[n] = W beta + b, rowstat[m] = (rstd, rstd * mean) of the raw row m
                             // (from the stat_part partials of EPI_SWIGLU).  W itself is unchanged: folding gamma into W would round W again.
-    EPI_RESID_XG = 13, // the residual GEMM with the NEXT LayerNorm prepared in its epilogue (and optionally the fold of EPI_RESID_ROWSTAT on its
+    EPI_RESID_XG = 13, // (with res_scale set: x[m][n] = x[m][n] * res_scale[n] + acc + bias[n], the CAFormer's scaled residual; general form only)
+                       // the residual GEMM with the NEXT LayerNorm prepared in its epilogue (and optionally the fold of EPI_RESID_ROWSTAT on its
                        // input): x[m][n] += rowstat[m].x * acc - rowstat[m].y * col_u[n] + bias[n] (rowstat null: += acc + bias), then
                        // out_bf16[m][n] = 16bit(x[m][n] * ln_gamma[n]) and per (256-column tile, row) partial (sum x, sum x^2) into stat_part
                        // (the four waves of a row reduce through LDS; persistent loop only).

@@ -89,6 +89,30 @@ def test_ccip_b36_384_matches_oracle(f16):
     print("CCIP B36@384: %.2f GFLOP / image" % (enc.flops_per_image() / 1e9))
 
 
+def test_ccip_b36_384_batch_64_folded_layernorms():
+    """Batch 64 (two sub-batch streams of 32 images): stage 2's residual launches have more tiles than half the CUs, so its LayerNorms are
+    FOLDED (round 5: EPI_RESID_XG with res_scale writes gamma * x and the row sums, q | k, v and fc1 apply rstd / mean in their epilogues;
+    csrc/ccip.hip) -- a path the 2-image test never takes.  Rows 0, 31, 32 and 63 against the float32 oracle of those images (the oracle
+    does not depend on the batch), every row finite, and run to run identical."""
+    from hiptagsearch import synth
+    from hiptagsearch.cfeatures import CCIPEncoder
+    cfg = dict(synth.CCIP_B36_384, operand_f16=1)
+    w = synth.ccip_weights(cfg, seed=46)
+    imgs = synth.images_u8(64, 384, seed=48)
+    enc = CCIPEncoder(cfg, w, max_batch=64)
+    got = enc.forward_u8(imgs)
+    assert got.shape == (64, 768) and np.isfinite(got).all()
+    pick = [0, 31, 32, 63]
+    want, _ = _oracle(cfg, w, imgs[pick])
+    _check(got[pick], want, 1)
+    np.testing.assert_array_equal(enc.forward_u8(imgs), got)
+    # a sub-batch of the same images without the fold (batch 8: stage 2 is 36 tiles, the two-workgroups-per-CU kernels): the two forms of
+    # the LayerNorm round differently (gamma * x before the statistics are applied), nothing more
+    small = CCIPEncoder(cfg, w, max_batch=8).forward_u8(imgs[:8])
+    cos = (small * got[:8]).sum(1) / (np.linalg.norm(small, axis=1) * np.linalg.norm(got[:8], axis=1))
+    assert np.abs(small - got[:8]).max() <= 2e-2 and cos.min() >= 0.99999, (np.abs(small - got[:8]).max(), cos.min())
+
+
 def test_ccip_e4m3_mode_is_withdrawn():
     """operand_f16 = 2 (e4m3 operands for pwconv2 / fc1 / fc2, BASELINE.json configs[4]'s fp8 leg) was built in round 1 and withdrawn in
     round 4: cosine 0.968 against the float32 oracle on B36 @384, 1 % slower than half operands, and a CPU emulation of every scaling
