@@ -26,12 +26,20 @@ for k, c in agg.items():
     busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     if gui <= 0:
         continue
-    res[k] = {"launches": n[k], "mfma_busy_frac": busy / (gui * SIMDS), "elapsed_cycles_per_launch": gui / max(n[k], 1),
-              "effective_clock_ghz": (gui / dur[k]) if dur[k] > 0 else None}
+    avg_ms = dur[k] / max(n[k], 1) / 1e6
+    # GRBM_GUI_ACTIVE / 8 / wall time reads HIGH on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back): the quotient is
+    # not a clock there (round-4 files showed 2.2-3.7 GHz on a 2.4 GHz part), and mfma_busy_frac, which divides by the same cycle count,
+    # is then a LOWER bound.  The trustworthy clock of a GEMM loop is the in-kernel one (bench.py: roofline.clock.main_loop_ghz).
+    short = avg_ms < 0.3
+    res[k] = {"launches": n[k], "mfma_busy_frac": busy / (gui * SIMDS), "mfma_busy_frac_is_lower_bound": short,
+              "elapsed_cycles_per_launch": gui / max(n[k], 1), "avg_dispatch_ms": avg_ms,
+              "effective_clock_ghz": None if short or dur[k] <= 0 else gui / dur[k]}
 json.dump({"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
                      "--no-query --no-exclusive`; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): the share of "
                      "SIMD-cycles AT THE CLOCK THE KERNEL RAN AT in which the matrix pipe was busy (two-stream forward: a launch shares the chip)",
+           "note": "effective_clock_ghz is null, and mfma_busy_frac a lower bound (mfma_busy_frac_is_lower_bound), for kernels whose average "
+                   "dispatch is shorter than 0.3 ms: GRBM_GUI_ACTIVE / 8 over-counts elapsed cycles there",
            "kernels": res}, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["mfma_busy_frac"])[:12]:
-    print("%-44s n=%4d  MFMA busy %5.1f %%  clock %s GHz" % (k[:44], v["launches"], 100 * v["mfma_busy_frac"],
-                                                           ("%.2f" % v["effective_clock_ghz"]) if v["effective_clock_ghz"] else "-"))
+    print("%-44s n=%4d  MFMA busy %s%5.1f %%  clock %s GHz" % (k[:44], v["launches"], ">= " if v["mfma_busy_frac_is_lower_bound"] else "", 100 * v["mfma_busy_frac"],
+                                                             ("%.2f" % v["effective_clock_ghz"]) if v["effective_clock_ghz"] else "-"))
