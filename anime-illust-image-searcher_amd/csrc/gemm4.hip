@@ -41,6 +41,9 @@ __device__ __forceinline__ void q4_mfma0(f32x4& acc, const bf16x8& w, const bf16
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(x));
 }
 
+#ifndef HIPTS_Q4_EXECMASK
+#define HIPTS_Q4_EXECMASK 0       // 1: bit-equal (MFMAs do ignore EXEC) and 1.4-1.7 x SLOWER: phase 1 goes from 1700 to 3760 cycles per K-tile -- an EXEC write, the dropped request and the restore cost ~59 cycles per gap in all four waves
+#endif
 #ifndef HIPTS_Q4_STAGGER
 #define HIPTS_Q4_STAGGER 0         // 1: measured 1.7 x SLOWER and wrong -- the wave-uniform branches make hipcc copy the asm-owned accumulators at every merge (2452 v_accvgpr moves in the loop, read before the MFMAs have written them)
 #endif
@@ -55,6 +58,13 @@ __device__ __forceinline__ void q4_mfma0(f32x4& acc, const bf16x8& w, const bf16
 // scalar base pointer
 #define Q4_GLDS(SB, IMM, VOFF, SPTR)                                                                                                             \
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" ::"s"(SB), "i"(IMM), "v"(VOFF), "s"(SPTR) : "memory", "scc")
+// The same under an EXEC mask that is all ones for ONE of the four waves and zero for the others (HIPTS_Q4_EXECMASK): every wave runs the
+// same instruction stream -- no branch, so hipcc keeps the asm-owned accumulators where they are -- but a request with EXEC = 0 never
+// reaches the address path.  MFMAs ignore EXEC; nothing else sits between the two s_mov.
+#define Q4_GLDS_X(WAVE, G, SB, IMM, VOFF, SPTR)                                                                                                  \
+    asm volatile("s_cmp_eq_u32 %4, %5\n\ts_cselect_b64 exec, -1, 0\n\ts_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1" ::"s"(SB), \
+                 "i"(IMM), "v"(VOFF), "s"(SPTR), "s"(WAVE), "i"(G)                                                                               \
+                 : "memory", "scc")
 
 // Measurement builds only (STAMP instantiations, tools/gemm_bench.py with HIPTS_GEMM_STAMPS=1 HIPTS_GEMM_Q4=...): the shader clock, with the
 // wait inside the statement (s_memtime returns through the scalar cache's counter)
@@ -117,7 +127,23 @@ __device__ __forceinline__ void q4_ktile(f32x4 (&acc)[8][8], bf16x8 (&fa0)[8], b
     // The four waves run in step, and four LDS-DMA requests at once queue on the CU's one address path (measured: 44 cycles of a wave's
     // issue per request when all four ask in the same gap, phase 1 at 1700 cycles for 1024 of MFMAs).  HIPTS_Q4_STAGGER: wave w asks in
     // gaps 16 w .. 16 w + 15 -- one request in flight per gap over the whole phase; the price is a wave-uniform branch per 16 gaps.
-#if HIPTS_Q4_STAGGER
+#if HIPTS_Q4_EXECMASK
+    // wave w's 16 requests ride in gaps 16 w .. 16 w + 15; the other three waves execute the same statements with EXEC = 0
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const int i = s >> 3, j = s & 7;
+        q4_mfma<F16>(acc[i][j], fw1[j], fa1[i]);
+        if constexpr (RD) {
+            if (s < 8) Q4_DSREAD(fa0[s], bA[S ^ 1][0], s * 2048);
+            else if (s < 16) Q4_DSREAD(fw0[s - 8], bW[S ^ 1][0], (s - 8) * 2048);
+        }
+        if constexpr (IS) {
+            const int u = s & 15;
+            if (u < 8) Q4_GLDS_X(wave, s >> 4, sb, S * STAGE_BYTES + u * 4096, voff[u], asrc);
+            else Q4_GLDS_X(wave, s >> 4, sb, S * STAGE_BYTES + TILE_BYTES + (u - 8) * 4096, voff[u], wsrc);
+        }
+    }
+#elif HIPTS_Q4_STAGGER
     if (IS && wave == 0) q4_p1_seg<F16, S, RD, true, 0>(acc, fa0, fw0, fa1, fw1, bA, bW, sb, voff, asrc, wsrc);
     else q4_p1_seg<F16, S, RD, false, 0>(acc, fa0, fw0, fa1, fw1, bA, bW, sb, voff, asrc, wsrc);
     if (IS && wave == 1) q4_p1_seg<F16, S, RD, true, 1>(acc, fa0, fw0, fa1, fw1, bA, bW, sb, voff, asrc, wsrc);
