@@ -160,6 +160,16 @@ __device__ __forceinline__ void epi_turn(const GemmArgs& a, int wave_m, int step
     }
 }
 
+// Element offset of x[m][nc .. nc + 3] in the fp32 residual stream (round 5).  Row-major, or -- GemmArgs::x_blocked -- 16 x 16 blocks of
+// 1 KB: [m / 16][nc / 16][m % 16][nc % 16].  An epilogue load / store instruction of the accumulator layout (lane = row lr, four lanes x 16 B
+// per row of a 16-column block) touches 16 rows x 64 B of a row-major stream -- sixteen half lines, twice the address work per byte of
+// whole lines, on the launch's 512 such instructions per tile and CU -- and ONE contiguous kilobyte (eight whole lines) of the blocked one.
+// The stream is a workspace nobody else reads: only residual epilogues touch it (ld % 16 == 0, rows allocated up to a multiple of 16).
+__device__ __forceinline__ size_t x_off(const GemmArgs& a, int m, int nc, int ld) {
+    if (a.x_blocked) return (((size_t)(m >> 4) * (size_t)(ld >> 4) + (size_t)(nc >> 4)) << 8) + (size_t)((m & 15) * 16 + (nc & 15));
+    return (size_t)m * ld + nc;
+}
+
 // The bias values an epilogue needs, in its accumulator layout (V^T: one column per lane and 16-column
 // block, in [j][0]; otherwise four consecutive columns).  The persistent loop issues these loads before
 // the next tile's prologue so that their latency is not the first thing the epilogue waits for.
@@ -587,15 +597,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 // with them, 128 accumulators and two sets of 32 load registers the allocator spilled addresses, and a scratch reload is
                 // a VMEM operation -- s_waitcnt vmcnt(0), i.e. a drain of every store in flight, in front of each use
                 const f32x4* cvec = colvec + (ncol0 >> 2);
-                const int lane_off = lr * ld + 4 * lq;
-                float* base = a.out_f32 + (size_t)(m0 + wave_m * 128) * ld + ncol0;            // uniform: row block i adds 16 i ld
+                // row-major: row block i adds 16 i ld, column block j 16 floats; blocked: block (i, j) is 256 floats, a row block ld / 16 blocks
+                const int lane_off = a.x_blocked ? lr * 16 + 4 * lq : lr * ld + 4 * lq;
+                const size_t rb_step = a.x_blocked ? (size_t)(ld >> 4) * 256 : (size_t)16 * ld;
+                const int cb_step = a.x_blocked ? 256 : 16;
+                float* base = a.out_f32 + x_off(a, m0 + wave_m * 128, ncol0, ld);            // uniform
                 f32x4 xv[2][RB][4];
                 auto request = [&](int buf, int i2) {
 #pragma unroll
                     for (int u = 0; u < RB; ++u)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            xv[buf][u][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(i2 + u) * 16 * ld + lane_off + j * 16);
+                            xv[buf][u][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(i2 + u) * rb_step + lane_off + j * cb_step);
                 };
                 request(0, 0);
 #pragma unroll
@@ -615,7 +628,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                             else acc[i2 + u][j] = xv[cur][u][j] + (acc[i2 + u][j] + bj);
                             // (non-temporal loads / loads and stores of this stream, __builtin_nontemporal_*: 5277 / 5256-5294 images/s against
                             // 5294-5324 with the default policy on one box -- no gain, not kept)
-                            *reinterpret_cast<f32x4*>(base + (size_t)(i2 + u) * 16 * ld + lane_off + j * 16) = acc[i2 + u][j];
+                            *reinterpret_cast<f32x4*>(base + (size_t)(i2 + u) * rb_step + lane_off + j * cb_step) = acc[i2 + u][j];
                         }
                     }
 #pragma unroll
@@ -648,16 +661,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                     const int mc = m < a.M ? m : a.M - 1;
                     // a.pos: the patch embedding as the first "residual" GEMM -- x = acc * qscale + bias + pos[token] instead of x += ...
-                    const float* row = a.pos ? a.pos + (size_t)(mc % a.tokens) * a.N : a.out_f32 + (size_t)mc * ld;
                     st[u] = fold ? (st_lds ? st_lds[mc - m0] : row_stat(a, mc)) : make_float2(1.f, 0.f);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 4; ++j)
+                        xv[u][j] = !nv[j] ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                          : *reinterpret_cast<const f32x4*>(a.pos ? a.pos + (size_t)(mc % a.tokens) * a.N + nc[j] : a.out_f32 + x_off(a, mc, nc[j], ld));
                 }
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     if (i2 + u >= MR) continue;
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
-                    float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+                    const int mcs = m < a.M ? m : a.M - 1;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if constexpr (fold)
@@ -668,7 +682,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                         else
                             acc[i2 + u][j] = nv[j] ? (a.pos ? acc[i2 + u][j] * a.qscale + bv[j] + xv[u][j] : xv[u][j] + (acc[i2 + u][j] + bv[j]))
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(row + nc[j]) = acc[i2 + u][j];
+                        if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(a.out_f32 + x_off(a, mcs, nc[j], ld)) = acc[i2 + u][j];
                     }
                 }
                 if (!copy) continue;
@@ -738,17 +752,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                     for (int u = 0; u < RB; ++u) {
                         if (i2 + u >= MR) continue;
                         const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
-                        const float* row = a.out_f32 + (size_t)((INTERIOR || m < a.M) ? m : a.M - 1) * ld;
+                        const int mr = (INTERIOR || m < a.M) ? m : a.M - 1;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            xv[u][j] = (INTERIOR || nv[j]) ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            xv[u][j] = (INTERIOR || nv[j]) ? *reinterpret_cast<const f32x4*>(a.out_f32 + x_off(a, mr, nc[j], ld)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
                         if (i2 + u >= MR) continue;
                         const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
                         const int mc = (INTERIOR || m < a.M) ? m : a.M - 1;
-                        float* row = a.out_f32 + (size_t)mc * ld;
+                        // x_blocked with resid_rowmajor_out set (the last residual launch of a forward): the new rows leave row-major for
+                        // the kernels behind the stream (final norm + pool)
+                        float* row = (a.x_blocked && a.resid_rowmajor_out) ? a.resid_rowmajor_out + (size_t)mc * ld : nullptr;
                         float2 st = make_float2(1.f, 0.f);
                         if constexpr (EPI == EPI_RESID_ROWSTAT) st = st_lds ? st_lds[mc - m0] : row_stat(a, mc);
 #pragma unroll
@@ -760,7 +776,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                                 v = xv[u][j] + ((acc[i2 + u][j] * st.x - rs[j] * st.y) + bv[j]);
                             else
                                 v = xv[u][j] + (acc[i2 + u][j] + bv[j]);
-                            if (INTERIOR || (nv[j] && m < a.M)) *reinterpret_cast<f32x4*>(row + nc[j]) = v;
+                            if (INTERIOR || (nv[j] && m < a.M)) *reinterpret_cast<f32x4*>(row ? row + nc[j] : a.out_f32 + x_off(a, mc, nc[j], ld)) = v;
                         }
                     }
                 }

@@ -63,6 +63,7 @@ struct hipts_vit {
     std::vector<std::string> missing;   // tensors not yet set
     // workspace (sized for cfg.max_batch)
     DevBuf img_in, a0, x, xn, q, k, v, att, hmid, pool_part, pooled2, logits, probs, stat_part;
+    DevBuf x_rm;                   // the last residual launch's rows, row-major, when the stream itself is blocked (GemmArgs::x_blocked)
     DevBuf sk_ws;                                 // split-K workspaces of the residual GEMMs (GemmArgs::sk_ws), one per sub-batch stream, zeroed once
     bool fold_ln = false;                         // LayerNorms folded into the GEMM epilogues (default; HIPTS_LN_FOLD=0 turns it off)
     bool fold_dirty = true;                       // a tensor changed: the folded vectors are rebuilt at the next forward
@@ -418,7 +419,7 @@ int hipts_vit_create(const hipts_vit_config_t* cfg, int device, hipts_vit_t** ou
     h->pool_splits = h->tokens >= 64 ? std::min(32, std::max(8, h->tokens / 28)) : 1;      // 784 tokens: 28 splits of 28 tokens, 7 per wave
     if (getenv("HIPTS_POOL_SPLITS") && h->tokens >= 64) h->pool_splits = std::max(1, std::min(32, atoi(getenv("HIPTS_POOL_SPLITS"))));      // A/B
     int st = HIPTS_OK;
-    if ((st = h->a0.alloc(M * h->patch_k * 2 * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
+    if ((st = h->a0.alloc(M * h->patch_k * 2 * 2)) || (st = h->x.alloc(M * D * 4)) || (st = h->x_rm.alloc(M * D * 4)) || (st = h->xn.alloc(M * D * 2)) ||
         (st = h->q.alloc(qkv_elems * 2)) || (st = h->k.alloc(qkv_elems * 2)) || (st = h->v.alloc(qkv_elems * 2)) ||
         (st = h->att.alloc(M * D * 2 * (h->split_att ? 2 : 1))) || (st = h->hmid.alloc(M * (size_t)cfg->mlp_dim * 2)) ||
         (st = h->pool_part.alloc(B * h->pool_splits * D * 4)) || (st = h->pooled2.alloc(B * 2 * D * 2)) ||
@@ -671,6 +672,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     const int a0_ld = is_u8 ? h->patch_k : 2 * h->patch_k;
     bf16_t* a0 = h->a0.as<bf16_t>() + r0 * a0_ld;
     float* x = h->x.as<float>() + r0 * D;
+    float* x_rm = h->x_rm.as<float>() + r0 * D;
     bf16_t* xn = h->xn.as<bf16_t>() + r0 * D;
     const int att_k = h->split_att ? 2 * D : D;                          // row width of the attention output: [hi | lo] when split
     bf16_t* att = h->att.as<bf16_t>() + r0 * att_k;
@@ -715,12 +717,19 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         g.W = h->patch_w2.as<bf16_t>(); g.K = 2 * h->patch_k; g.bias = h->patch_b.as<float>(); g.qscale = 1.0f;
     }
     const bool fold = h->fold_ln;
+    // The fp32 residual stream as 16 x 16 blocks (round 5, gemm_epi.h::x_off): every epilogue load / store instruction then moves one
+    // contiguous kilobyte instead of sixteen half lines.  Only the residual epilogues touch the stream (folded LayerNorms); the last
+    // launch writes its rows row-major for the pool.  A sub-batch starts at a multiple of 16 rows when tokens % 16 == 0.
+    // HIPTS_X_BLOCKED=0: row-major (A/B).
+    static const bool xb_env = !(getenv("HIPTS_X_BLOCKED") && atoi(getenv("HIPTS_X_BLOCKED")) == 0);
+    const bool xb = xb_env && fold && D % 16 == 0 && T % 16 == 0 && c.depth >= 1;
     const int sblocks = (D + 255) / 256;                 // partial (sum, sum of squares) pairs per row: one per 256-column tile
     float* stat_p = fold ? h->stat_part.as<float>() + 2 * (size_t)sblocks * r0 : nullptr;
     {
         ProfScope ps(h, s, PC_GEMM_PATCH, 2.0 * dM * dD * h->patch_k, dM * h->patch_k * 2 + dM * dD * 4 + (fold ? dM * dD * 2 : 0.0));
         if (fold) {      // the first norm1 is prepared by this epilogue as well (EPI_RESID_XG with `pos`: x = acc * qscale + bias + pos)
             g.out_bf16 = xn; g.ln_gamma = h->layers[0].ln1_g.as<float>(); g.stat_part = stat_p; g.stat_stride = M;
+            g.x_blocked = xb ? 1 : 0;
             HIPTS_TRY(launch_gemm(EPI_RESID_XG, g, s));
         } else {
             HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
@@ -749,8 +758,11 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
         r.shared_chip = shared_chip;
         r.A = A; r.W = W; r.M = M; r.N = D; r.K = K; r.bias = bias; r.out_f32 = x;
         r.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; r.sk_ws_bytes = GEMM_SK_WS_BYTES;      // this stream's split-K workspace
+        r.x_blocked = xb ? 1 : 0;
         if (next_gamma) {
             r.out_bf16 = xn; r.ln_gamma = next_gamma; r.stat_part = stat_p; r.stat_stride = M;
+        } else if (xb) {
+            r.resid_rowmajor_out = x_rm;        // the forward's last residual launch: rows for the final norm + pool
         }
         {
             ProfScope ps(h, s, PC_GEMM_RESID, flops, bytes + (next_gamma ? dM * dD * 2 : 0.0));
@@ -813,7 +825,7 @@ int vit_run_images(hipts_vit* h, const void* in_dev, bool is_u8, int i0, int nb,
     // final norm + mean pool (+ hi/lo split)
     {
         ProfScope ps(h, s, PC_POOL, 0.0, dM * dD * 4);
-        pool_partial_kernel<<<dim3(h->pool_splits, nb), 256, 0, s>>>(x, pool_part, T, D, c.ln_eps, c.pool_then_norm ? 0 : 1, h->pool_splits);
+        pool_partial_kernel<<<dim3(h->pool_splits, nb), 256, 0, s>>>(xb ? x_rm : x, pool_part, T, D, c.ln_eps, c.pool_then_norm ? 0 : 1, h->pool_splits);
         HIPTS_LAUNCH_CHECK();
         if (f16)
             pool_finalize_kernel<true><<<nb, 256, 0, s>>>(pool_part, h->norm_g.as<float>(), h->norm_b.as<float>(), pooled2, T, D, c.ln_eps,
@@ -1137,6 +1149,7 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     }
     if (op8) { g.op8 = 1; g.f16 = 1; g.w_exp = 3; g.out8 = (epi == EPI_STAR && getenv("HIPTS_GEMM_OUT8")) ? 1 : 0; }
     if (dbg_f16) g.f16 = 1;
+    if (getenv("HIPTS_DBG_X_BLOCKED")) g.x_blocked = 1;         // the fp32 stream as 16 x 16 blocks (timing only: the buffer is scratch here)
     if (getenv("HIPTS_DBG_GEMM_SHARED")) g.shared_chip = 1;      // as under sub-batch streams: 256-row tiles whatever the round count
     if (epi == EPI_QK && N % 3 == 0) { g.dim = N / 3; g.heads = g.dim / 64; g.out3_bf16 = obf2.as<bf16_t>(); }      // fused q | k | v (timing only: v shares k's buffer)
     DevBuf stamps;

@@ -268,6 +268,9 @@ struct GemmArgs {
     int sk_first = 0, sk_slices = 1;        // set by the launcher: tiles [sk_first, tiles) are split sk_slices ways
     int raster_gn = 0;                      // > 0: column groups of this many column tiles outermost, row-major inside (set by the launcher)
     int raster_gm = 0;                      // > 0: tile order in groups of this many row panels, column-major inside (set by the launcher)
+    int x_blocked = 0;                      // out_f32 of the residual epilogues (RESID, RESCALE, RESID_ROWSTAT, RESID_XG / XGI) is stored as 16 x 16 blocks of
+                                            // 1 KB, [m / 16][n / 16][m % 16][n % 16] (gemm_epi.h::x_off); ld % 16 == 0, rows allocated up to a multiple of 16
+    float* resid_rowmajor_out = nullptr;    // x_blocked, EPI_RESID: the new rows are written here, row-major, instead of back into the blocked stream
     int epi_prefetch = 0;                   // interior residual epilogue: its fp32 tile is requested into L2 during the last K-tile (HIPTS_EPI_PREFETCH)
     int epi_prio = 0;                       // the two waves of a SIMD alternate s_setprio through the epilogue's steps (set by the launcher from HIPTS_EPI_PRIO)
     int shared_chip = 0;                    // another stream's kernels run concurrently (sub-batch streams)
