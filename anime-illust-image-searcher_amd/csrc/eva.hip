@@ -48,6 +48,7 @@ struct hipts_eva {
     DevBuf patch_w, patch_b, cls, pos, fcn_g, fcn_b, head_w, head_b, rope;
     std::vector<std::string> missing;
     DevBuf img_in, a0, tmp, x, xn, q, k, v, att, g1, stat_part, rowstat, xstat, pool_part, pooled2, logits, probs;
+    DevBuf x0, x_rm;               // blocked residual stream (GemmArgs::x_blocked): the assembled rows row-major for layer 0's LayerNorm, the last layer's rows row-major for the pool
     bool fold_ln = false, fold_dirty = true;      // as in the ViT forward (vit.hip)
     bool split_att = false;                       // cfg.operand_f16 bit 4 (HIPTS_OPERAND_SPLIT_ATT), as in the ViT forward
     DevBuf sk_ws;                                 // split-K workspaces of proj / fc2 (GemmArgs::sk_ws), one per sub-batch stream, zeroed once
@@ -98,9 +99,10 @@ __global__ __launch_bounds__(256) void eva_patchify_kernel(const void* __restric
 
 // x[b*TS + 0] = cls + pos[0]; x[b*TS + 1 + t] = tmp[b*np + t] (conv + bias + pos[1 + t], from the GEMM epilogue);
 // x[b*TS + T .. TS) = 0.   One thread per float4.
+// xblk (optional): the same rows a second time in the residual stream's blocked layout, [m / 16][n / 16][m % 16][n % 16] (gemm_epi.h::x_off)
 __global__ __launch_bounds__(256) void eva_assemble_kernel(const float* __restrict__ tmp, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, float* __restrict__ x, int batch, int np, int TS,
-                                                           int D) {
+                                                           int D, float* __restrict__ xblk) {
     const int dq = D >> 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)batch * TS * dq;
@@ -116,6 +118,10 @@ __global__ __launch_bounds__(256) void eva_assemble_kernel(const float* __restri
         v = reinterpret_cast<const float4*>(tmp)[(b * np + (r - 1)) * dq + c4];
     }
     reinterpret_cast<float4*>(x)[idx] = v;
+    if (xblk) {
+        const int64_t m = idx / dq;
+        *reinterpret_cast<float4*>(xblk + ((((m >> 4) * (int64_t)(D >> 4) + (c4 >> 2)) << 8) + (m & 15) * 16 + (c4 & 3) * 4)) = v;
+    }
 }
 
 // part[b][split][:] = sum of the patch-token rows of split `split` of image b (grid (POOL_SPLITS, batch)): the whole chip
@@ -224,7 +230,13 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     const size_t r0 = (size_t)i0 * TS, qo = (size_t)i0 * H * Tp * 64;
     bf16_t* a0_p = h->a0.as<bf16_t>() + (size_t)i0 * np * 2 * h->PK;
     float* tmp_p = h->tmp.as<float>() + (size_t)i0 * np * D;
-    float* x = h->x.as<float>() + r0 * D;
+    // the fp32 residual stream as 16 x 16 blocks (round 5; csrc/gemm_epi.h::x_off, the ViT forward has the measurements): a sub-batch's
+    // region starts at a multiple of 16 rows of its own (1032 rows per image: odd image offsets are not)
+    static const bool xb_env = !(getenv("HIPTS_X_BLOCKED") && atoi(getenv("HIPTS_X_BLOCKED")) == 0);
+    const bool xb = xb_env && h->fold_ln && D % 16 == 0;
+    float* x = h->x.as<float>() + (xb ? ((r0 + 15) / 16 * 16 + (size_t)16 * sub) : r0) * D;
+    float* x0 = xb ? h->x0.as<float>() + r0 * D : x;                // what eva_assemble_kernel writes row-major (layer 0's LayerNorm reads it)
+    float* x_rm = h->x_rm.as<float>() + r0 * D;                     // the last layer's rows for the column sums
     bf16_t* xn = h->xn.as<bf16_t>() + r0 * D;
     bf16_t* q_p = h->q.as<bf16_t>() + qo;
     bf16_t* k_p = h->k.as<bf16_t>() + qo;
@@ -257,7 +269,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.bias = h->patch_b.as<float>(); g.out_f32 = tmp_p; g.pos = h->pos.as<float>() + D; g.tokens = np; g.qscale = 1.0f;
         HIPTS_TRY(launch_gemm(EPI_PATCH, g, s));
         const int64_t tot4 = (int64_t)batch * TS * (D / 4);
-        eva_assemble_kernel<<<ceil_div(tot4, 256), 256, 0, s>>>(tmp_p, h->cls.as<float>(), h->pos.as<float>(), x, batch, np, TS, D);
+        eva_assemble_kernel<<<ceil_div(tot4, 256), 256, 0, s>>>(tmp_p, h->cls.as<float>(), h->pos.as<float>(), x0, batch, np, TS, D, xb ? x : nullptr);
         HIPTS_LAUNCH_CHECK();
     }
     // pre-LayerNorms folded into the neighbouring GEMM epilogues, as in the ViT forward: the residual GEMM writes gamma * x (16-bit)
@@ -272,7 +284,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
     for (int li = 0; li < c.depth; ++li) {
         EvaLayer& L = h->layers[li];
         const bool ln1_folded = fold && li > 0;
-        if (!ln1_folded) HIPTS_TRY(launch_layernorm(x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
+        if (!ln1_folded) HIPTS_TRY(launch_layernorm(li == 0 ? x0 : x, L.ln1_g.as<float>(), L.ln1_b.as<float>(), xn, M, D, c.ln_eps, f16, s));
         g = GemmArgs{};
         g.f16 = f16;
         g.shared_chip = shared_chip;
@@ -288,6 +300,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.f16 = f16;
         g.shared_chip = shared_chip;
         g.A = att_p; g.W = L.proj_w.as<bf16_t>(); g.M = M; g.N = D; g.K = att_k; g.bias = L.proj_b.as<float>(); g.out_f32 = x;
+        g.x_blocked = xb ? 1 : 0;
         g.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; g.sk_ws_bytes = GEMM_SK_WS_BYTES;      // split-K when the launch under-fills the chip
         if (fold) {
             g.out_bf16 = xn; g.ln_gamma = L.ln2_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
@@ -312,6 +325,7 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
         g.f16 = f16;
         g.shared_chip = shared_chip;
         g.A = g1_p; g.W = L.fc2_w.as<bf16_t>(); g.M = M; g.N = D; g.K = h->HK; g.bias = L.fc2_c.as<float>(); g.out_f32 = x;
+        g.x_blocked = xb ? 1 : 0;
         g.sk_ws = h->sk_ws.as<char>() + (size_t)sub * GEMM_SK_WS_BYTES; g.sk_ws_bytes = GEMM_SK_WS_BYTES;
         static const bool rowstat_kernel = getenv("HIPTS_EVA_ROWSTAT_KERNEL") && atoi(getenv("HIPTS_EVA_ROWSTAT_KERNEL"));      // A/B: finish the pairs in a kernel of its own
         if (rowstat_kernel) {
@@ -325,11 +339,12 @@ int eva_run_images(hipts_eva* h, const void* in_dev, bool is_u8, int i0, int bat
             g.out_bf16 = xn; g.ln_gamma = h->layers[li + 1].ln1_g.as<float>(); g.stat_part = xstat_p; g.stat_stride = M;
             HIPTS_TRY(launch_gemm(EPI_RESID_XGI, g, s));
         } else {
+            if (xb) g.resid_rowmajor_out = x_rm;        // the forward's last residual launch (fold: the last layer): rows for the column sums
             HIPTS_TRY(launch_gemm(EPI_RESID_ROWSTAT, g, s));
         }
     }
     float* part_p = h->pool_part.as<float>() + (size_t)i0 * POOL_SPLITS * D;
-    eva_colsum_kernel<<<dim3(POOL_SPLITS, batch), 256, 0, s>>>(x, part_p, np, TS, D);
+    eva_colsum_kernel<<<dim3(POOL_SPLITS, batch), 256, 0, s>>>(xb ? x_rm : x, part_p, np, TS, D);
     if (f16) eva_pool_kernel<true><<<batch, 1024, 0, s>>>(part_p, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, POOL_SPLITS, POOL_SPLITS, D, c.ln_eps, np);
     else eva_pool_kernel<false><<<batch, 1024, 0, s>>>(part_p, h->fcn_g.as<float>(), h->fcn_b.as<float>(), pooled2_p, POOL_SPLITS, POOL_SPLITS, D, c.ln_eps, np);
     HIPTS_LAUNCH_CHECK();
@@ -434,7 +449,7 @@ int hipts_eva_create(const hipts_eva_config_t* cfg, int device, hipts_eva_t** ou
     const size_t M = (size_t)B * h->TS;
     const size_t qk = (size_t)B * cfg->heads * h->Tp * 64 * 2;
     int st = 0;
-    if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, M * D * 4)) ||
+    if ((st = alloc_zero(h->a0, (size_t)B * h->np * 2 * h->PK * 2)) || (st = h->tmp.alloc((size_t)B * h->np * D * 4)) || (st = alloc_zero(h->x, (M + 16 * 9) * D * 4)) || (st = h->x0.alloc(M * D * 4)) || (st = h->x_rm.alloc(M * D * 4)) ||
         (st = alloc_zero(h->xn, M * D * 2)) || (st = alloc_zero(h->q, qk)) || (st = alloc_zero(h->k, qk)) || (st = alloc_zero(h->v, qk)) ||
         (st = alloc_zero(h->att, M * D * 2 * (h->split_att ? 2 : 1))) || (st = alloc_zero(h->g1, M * h->HK * 2)) ||
         (st = h->stat_part.alloc((size_t)((2 * h->HK + 255) / 256) * M * 8)) || (st = h->xstat.alloc((size_t)((D + 255) / 256) * M * 8)) || (st = h->rowstat.alloc(M * 8)) || (st = h->pooled2.alloc((size_t)B * 2 * D * 2)) || (st = h->pool_part.alloc((size_t)B * 16 * D * 4)) ||
