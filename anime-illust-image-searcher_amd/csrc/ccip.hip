@@ -188,19 +188,24 @@ __global__ __launch_bounds__(256) void stem_im2col_u8_kernel(const uint8_t* __re
 }
 
 // Bias-free LayerNorm of float32 rows, in place (the stem's norm: its output IS the residual stream).
+// float4 c of row `row` of the fp32 residual stream: row-major, or (blk) in 16 x 16 blocks of 1 KB (csrc/gemm_epi.h::x_off)
+__device__ __forceinline__ float4* x_vec(float* x, int64_t row, int c, int D, int blk) {
+    if (blk) return reinterpret_cast<float4*>(x + ((((row >> 4) * (int64_t)(D >> 4)) + (c >> 2)) << 8) + (row & 15) * 16 + (c & 3) * 4);
+    return reinterpret_cast<float4*>(x + row * D) + c;
+}
+
 __global__ __launch_bounds__(256) void ln_inplace_kernel(float* __restrict__ x, const float* __restrict__ g, int64_t rows, int D,
-                                                         float eps) {
+                                                         float eps, int blk) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = D >> 2;
-    float4* xr = reinterpret_cast<float4*>(x + row * D);
     float4 v[4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
-        v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = c < nvec ? *x_vec(x, row, c, D, blk) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum_f(s) / (float)D;
@@ -218,8 +223,48 @@ __global__ __launch_bounds__(256) void ln_inplace_kernel(float* __restrict__ x, 
         const int c = lane + 64 * i;
         if (c < nvec) {
             const float4 gg = gr[c];
-            xr[c] = make_float4((v[i].x - mean) * rstd * gg.x, (v[i].y - mean) * rstd * gg.y, (v[i].z - mean) * rstd * gg.z,
+            *x_vec(x, row, c, D, blk) = make_float4((v[i].x - mean) * rstd * gg.x, (v[i].y - mean) * rstd * gg.y, (v[i].z - mean) * rstd * gg.z,
                                 (v[i].w - mean) * rstd * gg.w);
+        }
+    }
+}
+
+// vit.hip's layernorm_kernel (bias-free, 16-bit output, same operations in the same order) reading the BLOCKED residual stream: the
+// downsample norms of the stages whose stream is stored in 16 x 16 blocks (two launches per forward)
+template <bool F16>
+__global__ __launch_bounds__(256) void layernorm_blk_kernel(float* __restrict__ x, const float* __restrict__ g, bf16_t* __restrict__ out,
+                                                            int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = D >> 2;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nvec ? *x_vec(x, row, c, D, 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum_f(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i < nvec) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            ss += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_f(ss) / (float)D + eps);
+    const float4* gr = reinterpret_cast<const float4*>(g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            const float4 gg = gr[c];
+            *reinterpret_cast<bf16x4*>(out + row * D + 4 * c) =
+                pack4<F16>((v[i].x - mean) * rstd * gg.x + 0.f, (v[i].y - mean) * rstd * gg.y + 0.f, (v[i].z - mean) * rstd * gg.z + 0.f,
+                           (v[i].w - mean) * rstd * gg.w + 0.f);
         }
     }
 }
@@ -597,7 +642,7 @@ __global__ __launch_bounds__(256) void ds_im2col_kernel(const bf16_t* __restrict
 // four row groups x 256 channel threads sum a quarter of the tokens each (the loop is load-latency bound,
 // so more rows in flight is what matters), partial sums meet in LDS, the first 256 threads normalise.
 __global__ __launch_bounds__(1024) void pool_ln_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                       const float* __restrict__ bta, float* __restrict__ out, int T, int C, float eps) {
+                                                       const float* __restrict__ bta, float* __restrict__ out, int T, int C, float eps, int blk) {
     __shared__ float part[4][1024];
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x & 255, rg = threadIdx.x >> 8;
@@ -608,7 +653,7 @@ __global__ __launch_bounds__(1024) void pool_ln_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = tid + 256 * u;
-            if (c < C) m[u] += xb[(int64_t)r * C + c];
+            if (c < C) m[u] += blk ? xb[((((int64_t)(r >> 4) * (C >> 4)) + (c >> 4)) << 8) + (r & 15) * 16 + (c & 15)] : xb[(int64_t)r * C + c];
         }
 #pragma unroll
     for (int u = 0; u < 4; ++u) part[rg][tid + 256 * u] = m[u];
@@ -683,11 +728,30 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     // depthwise 7x7: 0 = the VALU kernel, 1 = matrix cores with the tile shape chosen by the spatial side, 2 / 3 = 32- / 48-column tiles forced
     static const int dw_mfma = getenv("HIPTS_CCIP_DW_MFMA") ? atoi(getenv("HIPTS_CCIP_DW_MFMA")) : 1;
     static const bool fused_mlp = !(getenv("HIPTS_CCIP_FUSED_MLP") && atoi(getenv("HIPTS_CCIP_FUSED_MLP")) == 0);      // A/B: 0 = fc1 and fc2 as two GEMM launches
+    // The fp32 residual stream of the narrow stages (C <= 256: SepConv blocks, fused MLP) in 16 x 16 blocks of 1 KB (round 5,
+    // csrc/gemm_epi.h::x_off; the ViT forward has the measurements): the loads / stores of the residual epilogues and of the fused MLP
+    // are lane = (row, 4 columns of a 16-column block) -- one contiguous kilobyte per instruction instead of sixteen half lines.  Every
+    // stage's stream is produced afresh by its stem / downsample GEMM, so the layout is a per-stage choice: blocked where the readers are
+    // the epilogues and the fused MLP (stages 0-1; their three elementwise readers -- stem norm, two downsample norms -- read blocks),
+    // row-major for the wide stages (LayerNorm kernels, pool).  HIPTS_CCIP_X_BLOCKED=0: row-major everywhere (A/B).
+    static const bool xblk_env = !(getenv("HIPTS_CCIP_X_BLOCKED") && atoi(getenv("HIPTS_CCIP_X_BLOCKED")) == 0);
+    auto stage_blocked = [&](int si) {
+        const Stage& Sg = h->st[si];
+        return xblk_env && Sg.C <= 256 && Sg.C % 16 == 0 && Sg.T % 16 == 0;
+    };
+    bool xblk = false;          // layout of x right now (the stage being processed)
     auto layernorm_xn = [&](const float* gamma, int64_t rows, int D) -> int {
+        if (xblk) {
+            if (f16) layernorm_blk_kernel<true><<<ceil_div(rows, 4), 256, 0, s>>>(x, gamma, xn, rows, D, c.ln_eps);
+            else layernorm_blk_kernel<false><<<ceil_div(rows, 4), 256, 0, s>>>(x, gamma, xn, rows, D, c.ln_eps);
+            HIPTS_LAUNCH_CHECK();
+            return HIPTS_OK;
+        }
         return launch_layernorm(x, gamma, nullptr, xn, rows, D, c.ln_eps, f16, s);
     };
     auto residual = [&](GemmArgs& ga, const float* rs, const float* gamma) -> int {
         ga.res_scale = rs;
+        ga.x_blocked = xblk ? 1 : 0;
         if (gamma) {
             ga.ln_gamma = gamma;
             ga.ln_eps = c.ln_eps;
@@ -717,8 +781,10 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         g.shared_chip = shared_chip;
         g.A = a0; g.W = h->stem_w.as<bf16_t>(); g.M = (int)M; g.N = S0.C; g.K = STEM_K;
         g.bias = h->stem_b.as<float>(); g.out_f32 = x;
+        xblk = stage_blocked(0);
+        g.x_blocked = xblk ? 1 : 0;
         HIPTS_TRY(gemm(EPI_BIAS, g, s));
-        ln_inplace_kernel<<<ceil_div(M, 4), 256, 0, s>>>(x, h->stem_norm.as<float>(), M, S0.C, c.ln_eps);
+        ln_inplace_kernel<<<ceil_div(M, 4), 256, 0, s>>>(x, h->stem_norm.as<float>(), M, S0.C, c.ln_eps, xblk ? 1 : 0);
         HIPTS_LAUNCH_CHECK();
     }
 
@@ -739,6 +805,8 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
             g.shared_chip = shared_chip;
             g.A = col; g.W = St.ds_w.as<bf16_t>(); g.M = M; g.N = C; g.K = 9 * Pv.C;
             g.bias = St.ds_b.as<float>(); g.out_f32 = x;
+            xblk = stage_blocked(si);           // (the norm above read the previous stage's layout)
+            g.x_blocked = xblk ? 1 : 0;
             HIPTS_TRY(gemm(EPI_BIAS, g, s));
         }
         if (si >= c.attn_from_stage && Tp != T) {
@@ -773,6 +841,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
         };
         auto residual_xg = [&](GemmArgs& ga, const float* rs, const float* gamma) -> int {
             ga.res_scale = rs; ga.ln_gamma = gamma; ga.ln_eps = c.ln_eps; ga.out_bf16 = xn; ga.stat_part = stat_p; ga.stat_stride = M;
+            ga.x_blocked = xblk ? 1 : 0;
             return launch_gemm(EPI_RESID_XG, ga, s);
         };
         for (size_t bi = 0; bi < St.blocks.size(); ++bi) {
@@ -837,7 +906,8 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
             if (fused_mlp && fuse_ln && f16 && B.mlp_img.p) {
                 // stages 0-1 (rows of <= 256 columns): one kernel, the hidden tensor stays in registers (mlp.hip)
                 const bool fuse_next = next_gamma != nullptr;
-                HIPTS_TRY(launch_mlp_fused(xn, B.mlp_img.p, x, B.has_rs2 ? B.rs2.as<float>() : nullptr, next_gamma, xn, M, C, B.s2, B.b2, c.ln_eps, s));
+                HIPTS_TRY(launch_mlp_fused(xn, B.mlp_img.p, x, B.has_rs2 ? B.rs2.as<float>() : nullptr, next_gamma, xn, M, C, B.s2, B.b2, c.ln_eps, s, 0,
+                                           xblk ? 1 : 0));
                 xn_ready = fuse_next;
                 continue;
             }
@@ -863,7 +933,7 @@ int ccip_run_images(hipts_ccip* h, const void* in_dev, bool is_u8, int i0, int b
     }
     // ---- head: global average pool -> LayerNorm
     const Stage& L = h->st[3];
-    pool_ln_kernel<<<batch, 1024, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev + (size_t)i0 * L.C, L.T, L.C, c.ln_eps);
+    pool_ln_kernel<<<batch, 1024, 0, s>>>(x, h->head_g.as<float>(), h->head_b.as<float>(), f_dev + (size_t)i0 * L.C, L.T, L.C, c.ln_eps, xblk ? 1 : 0);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }

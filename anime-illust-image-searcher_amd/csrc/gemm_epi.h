@@ -494,19 +494,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 for (int u = 0; u < RB; ++u) {
                     if (i2 + u >= MR) continue;
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
-                    const float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+                    const int mr = m < a.M ? m : a.M - 1;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(row + nc[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 4; ++j) xv[u][j] = nv[j] ? *reinterpret_cast<const f32x4*>(a.out_f32 + x_off(a, mr, nc[j], ld)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     if (i2 + u >= MR) continue;
                     const int m = m0 + wave_m * (MR * 16) + (i2 + u) * 16 + lr;
-                    float* row = a.out_f32 + (size_t)(m < a.M ? m : a.M - 1) * ld;
+                    const int mr = m < a.M ? m : a.M - 1;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         acc[i2 + u][j] = nv[j] ? xv[u][j] * rs[j] + (acc[i2 + u][j] + bv[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(row + nc[j]) = acc[i2 + u][j];
+                        if (nv[j] && m < a.M) *reinterpret_cast<f32x4*>(a.out_f32 + x_off(a, mr, nc[j], ld)) = acc[i2 + u][j];
                     }
                 }
             }
@@ -800,7 +800,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if constexpr (EPI == EPI_PATCH) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] * a.qscale + bv[j] + pv[j];
-                        else *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] + bv[j];
+                        else *reinterpret_cast<f32x4*>(a.out_f32 + x_off(a, m, nc[j], ld)) = acc[i][j] + bv[j];
                     }
                 }
                 return;
@@ -822,7 +822,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
             } else if constexpr (EPI == EPI_BIAS) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (nv[j]) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * ld + nc[j]) = acc[i][j] + bv[j];
+                    if (nv[j]) *reinterpret_cast<f32x4*>(a.out_f32 + x_off(a, m, nc[j], ld)) = acc[i][j] + bv[j];
             } else if constexpr (EPI == EPI_STAR) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
 template <int C, int WAVES, int NBUF = 4>
 __global__ __launch_bounds__(WAVES * 64, NBUF == 2 ? 2 : 1) void mlp_fused_kernel(const bf16_t* xn, const char* __restrict__ wimg, float* __restrict__ x,
                                                         const float* __restrict__ res_scale, const float* __restrict__ gamma,
-                                                        bf16_t* xn_out, int M, int chunks, float star_s, float star_b, float eps) {
+                                                        bf16_t* xn_out, int M, int chunks, float star_s, float star_b, float eps, int xblk) {
     using I = MlpImg<C>;
     constexpr int KS = C / 32, CF = C / 16, RF = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,9 +115,12 @@ __global__ __launch_bounds__(WAVES * 64, NBUF == 2 ? 2 : 1) void mlp_fused_kerne
     f32x4 O[CF][RF];
 #pragma unroll
     for (int rf = 0; rf < RF; ++rf) {
-        const float* xr = x + (size_t)min(row0 + rf * 16 + lr, M - 1) * C + 4 * kq;
+        // (xblk: the stream as 16 x 16 blocks of 1 KB, gemm_epi.h::x_off -- a load instruction here is lane (row lr, columns 4 kq ..+3) of a
+        // 16-column block: one contiguous kilobyte of the blocked stream, sixteen half lines of the row-major one)
+        const int rr = min(row0 + rf * 16 + lr, M - 1);
+        const float* xr = xblk ? x + (((size_t)(rr >> 4) * (C >> 4)) << 8) + (rr & 15) * 16 + 4 * kq : x + (size_t)rr * C + 4 * kq;
 #pragma unroll
-        for (int cf = 0; cf < CF; ++cf) O[cf][rf] = *reinterpret_cast<const f32x4*>(xr + cf * 16);
+        for (int cf = 0; cf < CF; ++cf) O[cf][rf] = *reinterpret_cast<const f32x4*>(xr + cf * (xblk ? 256 : 16));
     }
 
     // Operand reads run RING - 1 fragments ahead of the MFMAs that use them, through inline asm with counted waits: written as plain
@@ -234,12 +237,13 @@ __global__ __launch_bounds__(WAVES * 64, NBUF == 2 ? 2 : 1) void mlp_fused_kerne
         for (int rf = 0; rf < RF; ++rf) {
             const int row = row0 + rf * 16 + lr;
             const bool ok = FULL || row < M;
-            float* xr = x + (size_t)(ok ? row : M - 1) * C + 4 * kq;
+            const int rr = ok ? row : M - 1;
+            float* xr = xblk ? x + (((size_t)(rr >> 4) * (C >> 4)) << 8) + (rr & 15) * 16 + 4 * kq : x + (size_t)rr * C + 4 * kq;
             float s1 = 0.f;
 #pragma unroll
             for (int cf = 0; cf < CF; ++cf) {
                 const f32x4 v = O[cf][rf];          // rs * x + the products
-                if (FULL || ok) *reinterpret_cast<f32x4*>(xr + cf * 16) = v;
+                if (FULL || ok) *reinterpret_cast<f32x4*>(xr + cf * (xblk ? 256 : 16)) = v;
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
             }
             if (gamma) {
@@ -295,7 +299,8 @@ std::vector<uint16_t> mlp_weight_image(const float* w1, const float* w2, int C) 
 bool mlp_fused_supports(int C) { return C == 128 || C == 256; }
 
 int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* res_scale, const float* gamma, bf16_t* xn_out, int M, int C,
-                     float star_s, float star_b, float eps, hipStream_t s, int waves) {
+                     float star_s, float star_b, float eps, hipStream_t s, int waves, int xblk) {
+    HIPTS_REQUIRE(!xblk || M % 16 == 0, "fused MLP: the blocked residual stream needs whole 16-row blocks (M = %d)", M);
     HIPTS_REQUIRE(mlp_fused_supports(C), "fused MLP: width %d is not built (128, 256)", C);
     HIPTS_REQUIRE(xn && wimg && x && M >= 1 && (!gamma || xn_out), "fused MLP: bad argument");
     const int chunks = 4 * C / 32;
@@ -334,11 +339,11 @@ int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* 
     const int want = waves ? waves : waves_env;
     const bool four = want == 4 || (want != 8 && ((C == 256 && two_buffers) ? !(g8 <= cus && g8 * 2 > cus) : t4 < t8));
     const int grid = four ? g4 : g8;
-#define HIPTS_MLP_LAUNCH(CC, WW) mlp_fused_kernel<CC, WW><<<grid, WW * 64, 4 * MlpImg<CC>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps)
+#define HIPTS_MLP_LAUNCH(CC, WW) mlp_fused_kernel<CC, WW><<<grid, WW * 64, 4 * MlpImg<CC>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps, xblk)
     static const bool two_buffers128 = !(getenv("HIPTS_MLP_NBUF128") && atoi(getenv("HIPTS_MLP_NBUF128")) == 4);      // C = 128 four waves with two chunk buffers: three workgroups per CU (148 -> 134 us alone, the encoder the same; A/B: HIPTS_MLP_NBUF128=4)
-    if (C == 128 && four && two_buffers128) mlp_fused_kernel<128, 4, 2><<<grid, 256, 2 * MlpImg<128>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
+    if (C == 128 && four && two_buffers128) mlp_fused_kernel<128, 4, 2><<<grid, 256, 2 * MlpImg<128>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps, xblk);
     else if (C == 128) { if (four) HIPTS_MLP_LAUNCH(128, 4); else HIPTS_MLP_LAUNCH(128, 8); }
-    else if (four && two_buffers) mlp_fused_kernel<256, 4, 2><<<grid, 256, 2 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps);
+    else if (four && two_buffers) mlp_fused_kernel<256, 4, 2><<<grid, 256, 2 * MlpImg<256>::BYTES, s>>>(xn, (const char*)wimg, x, res_scale, gamma, xn_out, M, chunks, star_s, star_b, eps, xblk);
     else { if (four) HIPTS_MLP_LAUNCH(256, 4); else HIPTS_MLP_LAUNCH(256, 8); }
 #undef HIPTS_MLP_LAUNCH
     HIPTS_LAUNCH_CHECK();

@@ -324,7 +324,8 @@ int launch_fold_ln(const bf16_t* W, bool f16, const float* gamma, const float* b
 std::vector<uint16_t> mlp_weight_image(const float* w1, const float* w2, int C);
 bool mlp_fused_supports(int C);
 int launch_mlp_fused(const bf16_t* xn, const void* wimg, float* x, const float* res_scale, const float* gamma, bf16_t* xn_out, int M, int C,
-                     float star_s, float star_b, float eps, hipStream_t s, int waves = 0);      // waves per workgroup: 0 = chosen by the launch's size, 4, 8
+                     float star_s, float star_b, float eps, hipStream_t s, int waves = 0,       // waves per workgroup: 0 = chosen by the launch's size, 4, 8
+                     int xblk = 0);                                                             // x is stored as 16 x 16 blocks (gemm_epi.h::x_off)
 // the same with e4m3 output bytes (the A operand of an op8 GEMM)
 int launch_layernorm8(const float* x, const float* g, const float* b, uint8_t* out, int64_t rows, int D, float eps, hipStream_t s);
 
