@@ -141,7 +141,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // SK (round 4): the split-K tail of GemmArgs::sk_* -- work items past sk_first are (tile, K slice) pairs.  A separate instantiation, so
 // the default kernels' code is untouched.
 template <int EPI, int MR = 8, bool F16 = false, bool OP8 = false, bool SK = false, bool INT = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(240))) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(HIPTS_INT_DEPTH == 3 ? 256 : 240))) void gemm_pp_kernel(const GemmArgs a, int tiles_m, int tiles_n) {
     static_assert(!INT || (EPI == EPI_RESID_XG && MR == 8 && !OP8 && !SK), "INT: the residual epilogue's interior form");
     static_assert(!OP8 || (F16 && MR == 8), "e4m3 operands: half 16-bit outputs, full tiles");
     static_assert(!SK || (!OP8 && MR == 8), "split-K: 16-bit operands, full tiles");

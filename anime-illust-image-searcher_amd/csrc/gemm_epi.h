@@ -20,6 +20,9 @@ constexpr int BM = 256, BN = 256, BK = 64;
 #ifndef HIPTS_STAGED_INTERIOR
 #define HIPTS_STAGED_INTERIOR 1         // 0: the staged 16-bit epilogues store under per-lane predicates everywhere (A/B builds)
 #endif
+#ifndef HIPTS_INT_DEPTH
+#define HIPTS_INT_DEPTH 2
+#endif
 constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // 128 KiB
@@ -602,7 +605,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                 const size_t rb_step = a.x_blocked ? (size_t)(ld >> 4) * 256 : (size_t)16 * ld;
                 const int cb_step = a.x_blocked ? 256 : 16;
                 float* base = a.out_f32 + x_off(a, m0 + wave_m * 128, ncol0, ld);            // uniform
-                f32x4 xv[2][RB][4];
+                // HIPTS_INT_DEPTH (2 / 3): register sets of loads in flight.  With the stream in blocks the address path is no longer what a
+                // step waits for, so a third set (two steps ahead, 32 more registers: the instantiation is built for 256) was tried
+                constexpr int DEPTH = HIPTS_INT_DEPTH;
+                f32x4 xv[DEPTH][RB][4];
                 auto request = [&](int buf, int i2) {
 #pragma unroll
                     for (int u = 0; u < RB; ++u)
@@ -611,11 +617,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MR
                             xv[buf][u][j] = *reinterpret_cast<const f32x4*>(base + (size_t)(i2 + u) * rb_step + lane_off + j * cb_step);
                 };
                 request(0, 0);
+                if constexpr (DEPTH == 3) request(1, RB);
 #pragma unroll
                 for (int i2 = 0; i2 < 8; i2 += RB) {
                     epi_turn(a, wave_m, i2 / RB);
-                    const int cur = (i2 / RB) & 1;
-                    if (i2 + RB < 8) request(cur ^ 1, i2 + RB);
+                    const int cur = (i2 / RB) % DEPTH;
+                    if constexpr (DEPTH == 3) {
+                        if (i2 + 2 * RB < 8) request((cur + 2) % 3, i2 + 2 * RB);
+                    } else {
+                        if (i2 + RB < 8) request(cur ^ 1, i2 + RB);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
