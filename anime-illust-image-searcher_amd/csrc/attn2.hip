@@ -21,6 +21,7 @@
 //   K  chunk c of row r at position c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group read 16 different 16 B slots.
 //   V  chunk c of row r at position c ^ (((r >> 1) & 1) << 2): the 4 rows x 64 B a half-wave of ds_read_b64_tr_b16 covers
 //      lie in the four different 64 B quarters of the 64 banks.
+#include <mutex>
 #include <type_traits>
 
 #include "vit_internal.h"
@@ -36,6 +37,9 @@
 namespace hipts {
 namespace {
 
+#ifndef HIPTS_ATTN2_ASM_ADD
+#define HIPTS_ATTN2_ASM_ADD 0
+#endif
 #ifndef HIPTS_ATTN2_SEQ_WAVES
 #define HIPTS_ATTN2_SEQ_WAVES 3          // waves per SIMD the sequential body (MODE 1) is compiled for: 4 -> 128 registers, 3 -> 168
 #endif
@@ -456,7 +460,12 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
             const float p1 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[8 + i] - m_ref : sacc[8 + i]);
 #endif
 #ifndef HIPTS_X_NOSUM
+#if HIPTS_ATTN2_ASM_ADD
+            asm("v_add_f32 %0, %0, %1" : "+v"(ls0) : "v"(p0));      // single adds: hipcc pairs plain ones into v_pk_add_f32, which costs more issue cycles than two v_add_f32
+            asm("v_add_f32 %0, %0, %1" : "+v"(ls1) : "v"(p1));
+#else
             if (i & 1) ls1 += p0 + p1; else ls0 += p0 + p1;
+#endif
 #endif
             w0[i] = to_op<F16>(p0);
             w1[i] = to_op<F16>(p1);
@@ -561,11 +570,12 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 template <bool F16, int QB, int NW>
 __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int bh,
-                                           int blk0, int nblk, int out_stride, int out_ld, int lo_off, float lo_scale) {
+                                           int blk0, int nblk, int out_stride, int out_ld, int lo_off, float lo_scale, int wave_blk0 = -1,
+                                           int wave_nq = 0) {
+    // wave_blk0 >= 0 (attn3_kernel): this wave's blocks are wave_blk0 .. wave_blk0 + wave_nq - 1, one per pass
     constexpr int PCS = 8 / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const bool active = wave < nblk;
     const int b = bh / heads, head = bh - b * heads;
     const int nkv = tokens_pad / KV;
     int ka[4];
@@ -579,7 +589,8 @@ __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf1
         for (int blk = 0; blk < 2; ++blk) va[blk] = (4 * h + qd) * 128 + (2 * dgrp + (p >> 1) + 4 * (blk ^ x)) * 16 + (p & 1) * 8;
     }
     for (int qb = 0; qb < QB; ++qb) {
-        const int q0 = (blk0 + wave) * (32 * QB) + 32 * qb;
+        const int q0 = wave_blk0 >= 0 ? (wave_blk0 + qb) * 32 : (blk0 + wave) * (32 * QB) + 32 * qb;
+        const bool active = wave_blk0 >= 0 ? qb < wave_nq : wave < nblk;
         int qrow = q0 + r;
         qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
         const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
@@ -702,6 +713,56 @@ __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) voi
     if (*redo) attn2_classic<F16, QB, NW>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale);
 }
 
+#include "attn3.h"
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void attn3_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                       bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int chunks, int out_stride,
+                                                       int classic, int out_ld, int lo_off, float lo_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    int* redo = reinterpret_cast<int*>(smem3 + A3_LDS);
+    if (threadIdx.x == 0) *redo = classic;
+    int wid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qd = nwg >> 3, rm = nwg & 7, xcd = wid & 7, loc = wid >> 3;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int bh = wid / chunks, c = wid - bh * chunks;
+    const int nb = (tokens + 31) / 32;
+    const int blk0 = (c * nb) / chunks, nblk = ((c + 1) * nb) / chunks - blk0;       // <= A3_WG_BLOCKS
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wb0 = blk0 + (wave * nblk) / 4, nq = blk0 + ((wave + 1) * nblk) / 4 - wb0;      // 13 -> 3 3 3 4
+    if (!classic) {
+        const unsigned lds0 = (unsigned)(uintptr_t)smem3;
+        bool bad;
+        if (nq == A3_MAXQB) bad = attn3_body<F16, 4, false>(lds0, q, k, v, out, heads, tokens, tokens_pad, bh, wb0, nq, out_stride, out_ld, lo_off, lo_scale);
+        else bad = attn3_body<F16, 3, F16>(lds0, q, k, v, out, heads, tokens, tokens_pad, bh, wb0, nq, out_stride, out_ld, lo_off, lo_scale);
+        if (bad) *redo = 1;
+    }
+    __syncthreads();
+    if (*redo) attn2_classic<F16, A3_MAXQB, 4>(smem3, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale, wb0, nq);
+}
+
+template <bool F16>
+int launch_attn3(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, int ost, int classic,
+                 int out_ld, int lo_off, float lo_scale, hipStream_t s) {
+    static PerDevice attr;
+    int dev = 0;
+    (void)current_device_cus(&dev);
+    {
+        std::lock_guard<std::mutex> lk(attr.mu);
+        if (!attr.done(dev)) {
+            HIPTS_HIP(hipFuncSetAttribute((const void*)attn3_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, A3_LDS + 16));
+            attr.mark(dev);
+        }
+    }
+    const int nb = (tokens + 31) / 32;
+    const int chunks = (nb + A3_WG_BLOCKS - 1) / A3_WG_BLOCKS;
+    attn3_kernel<F16><<<batch * heads * chunks, 256, A3_LDS + 16, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic, out_ld, lo_off, lo_scale);
+    HIPTS_LAUNCH_CHECK();
+    return HIPTS_OK;
+}
+
 template <bool F16, int QB, int NW, int MODE>
 int launch_cfg(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int batch, int heads, int tokens, int tokens_pad, int ost,
                int classic, int out_ld, int lo_off, float lo_scale, hipStream_t s) {
@@ -728,6 +789,10 @@ int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
 #define HIPTS_ATTN2_CASE(QB_, NW_, MODE_)                                                                                        \
     return f16 ? launch_cfg<true, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, lo_scale, s)                      \
                : launch_cfg<false, QB_, NW_, MODE_>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, lo_scale, s)
+    if (variant == 6 && tokens_pad >= 2 * KV)
+        return f16 ? launch_attn3<true>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, lo_scale, s)
+                   : launch_attn3<false>(q, k, v, out, batch, heads, tokens, tokens_pad, ost, classic, out_ld, lo_off, lo_scale, s);
+    if (variant == 6) variant = 5;
     switch (variant) {
         case 1: HIPTS_ATTN2_CASE(2, 4, 0);
         case 2: HIPTS_ATTN2_CASE(1, 8, 0);
@@ -741,6 +806,11 @@ int launch_attention2(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t*
 #ifdef HIPTS_X_STAMPS
 int attention2_read_stamps(unsigned long long* host, int n) {
     HIPTS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn2_stamps), (size_t)n * 8));
+    return HIPTS_OK;
+}
+#elif defined(HIPTS_A3_STAMPS)
+int attention2_read_stamps(unsigned long long* host, int n) {
+    HIPTS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn3_stamps), (size_t)n * 8));
     return HIPTS_OK;
 }
 #else

@@ -105,6 +105,33 @@ def stamps(variant, f16=0, T=784, B=32):
             t, s[5] - s[0], s[6] - s[5], s[1] - s[6], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[10] - s[4], s[11] - s[10], s[12] - s[11], nxt - s[0]))
 
 
+def stamps3(f16=1, T=784, B=32):
+    """HIPTS_A3_STAMPS builds (csrc/attn3.h): one launch of variant 6, then the stamped wave's cycles per tile:
+    phase A | phase B of the odd half-step, vmcnt wait, barrier, phase A | phase B of the even half-step."""
+    H, TP = 12, (T + 63) // 64 * 64
+    rng = np.random.default_rng(0)
+    q = np.zeros((B * H, TP, 64), np.float32); k = np.zeros_like(q); v = np.zeros_like(q)
+    q[:, :T] = rng.standard_normal((B * H, T, 64)) * 0.18 * 1.4427
+    k[:, :T] = rng.standard_normal((B * H, T, 64)); v[:, :T] = rng.standard_normal((B * H, T, 64))
+    qb, kb, vb = _bits(q, f16), _bits(k, f16), _bits(v, f16)
+    us = ctypes.c_double()
+    _lib.check(fn(_lib.ptr(qb), _lib.ptr(kb), _lib.ptr(vb), None, B, H, T, TP, f16, 6, 5, ctypes.byref(us)))
+    st = np.zeros(4096, np.uint64)
+    g = lib.hiptsdbg_attention2_stamps
+    g.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    _lib.check(g(_lib.ptr(st), 4096))
+    st = st.astype(np.int64)
+    print("attn3 stamps f16=%d (%.1f us per launch): prologue %d cycles" % (f16, us.value, st[1] - st[0]))
+    tot = 0
+    for t in range(TP // 64 - 1):
+        s = st[8 + t * 8: 16 + t * 8]
+        nxt = st[8 + (t + 1) * 8] if t + 2 < TP // 64 else s[7]
+        print("  body %2d: A1 %5d B1 %5d | vmcnt %5d barrier %5d | A0 %5d mask %5d B0 %5d | to next %5d | total %6d" % (
+            t, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[6] - s[5], s[7] - s[6], nxt - s[7], nxt - s[0]))
+    last = st[8 + (TP // 64 - 2) * 8 + 7]
+    print("  tail: last P V + sums %d, stores %d; whole wave %d cycles" % (st[2] - last, st[3] - st[2], st[3] - st[0]))
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "both"
     variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 3]
@@ -113,6 +140,9 @@ if __name__ == "__main__":
         ok = check(variants)
     if mode in ("time", "both") and ok:
         timing(variants)
+    if mode == "stamps3":
+        stamps3(1)
+        stamps3(0)
     if mode == "stamps":
         for vnt in variants:
             stamps(vnt, 0)
