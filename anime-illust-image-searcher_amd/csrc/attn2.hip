@@ -38,7 +38,10 @@ namespace hipts {
 namespace {
 
 #ifndef HIPTS_ATTN2_ASM_ADD
-#define HIPTS_ATTN2_ASM_ADD 0
+#define HIPTS_ATTN2_ASM_ADD 1       // row sums as single v_add_f32 (asm): left alone hipcc pairs them into v_pk_add_f32, which beside MFMAs costs ~24 issue cycles against 2 x 5 (tools/micro/issue_cost.hip): bf16 operands 82-84 -> 78.5 us alone, half operands unchanged (83-85)
+#endif
+#ifndef HIPTS_ATTN2_MFMA_SUM
+#define HIPTS_ATTN2_MFMA_SUM 0      // 1: the row sums as two more MFMAs per 32 keys (ones x P^T) instead of 32 v_add_f32 -- the loop is bound by vector issue, the matrix pipe ~40 % busy.  NOT usable with half operands: the MFMA takes half subnormals (P < 2^-14, with the reference exponent's head room most keys of a row) as zero, so the P V product already drops them; dividing by the sum of what is LEFT (this switch) triples the error (5.9e-3 against 1.9e-3 at 784 tokens), dividing by the exact sum (the v_add path) keeps the result a scaled-down true average
 #endif
 #ifndef HIPTS_ATTN2_SEQ_WAVES
 #define HIPTS_ATTN2_SEQ_WAVES 3          // waves per SIMD the sequential body (MODE 1) is compiled for: 4 -> 128 registers, 3 -> 168
@@ -406,6 +409,14 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
     float l_run = 0.f, m_ref = 0.f;
+#if HIPTS_ATTN2_MFMA_SUM
+    f32x16 lacc;                                     // every row: the sum over the keys of P[key][query r]
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = to_op<F16>(1.0f);
+#endif
     const int tail_keys = tokens - (nkv - 1) * KV;
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -459,7 +470,8 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
             const float p0 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[i] - m_ref : sacc[i]);
             const float p1 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[8 + i] - m_ref : sacc[8 + i]);
 #endif
-#ifndef HIPTS_X_NOSUM
+#if HIPTS_ATTN2_MFMA_SUM
+#elif !defined(HIPTS_X_NOSUM)
 #if HIPTS_ATTN2_ASM_ADD
             asm("v_add_f32 %0, %0, %1" : "+v"(ls0) : "v"(p0));      // single adds: hipcc pairs plain ones into v_pk_add_f32, which costs more issue cycles than two v_add_f32
             asm("v_add_f32 %0, %0, %1" : "+v"(ls1) : "v"(p1));
@@ -481,6 +493,10 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
             o[blk] = mfma_32x32x16<F16>(vf[blk][0], w0, o[blk]);
             o[blk] = mfma_32x32x16<F16>(vf[blk][1], w1, o[blk]);
         }
+#if HIPTS_ATTN2_MFMA_SUM
+        lacc = mfma_32x32x16<F16>(ones, w0, lacc);
+        lacc = mfma_32x32x16<F16>(ones, w1, lacc);
+#endif
     };
     auto step = [&](int t, auto first_c, auto last_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_c)::value;
@@ -545,7 +561,11 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     }
     if (!active) return false;
 
+#if HIPTS_ATTN2_MFMA_SUM
+    const float l_tot = lacc[0];                     // over all keys already (the MFMA sums the two lane halves' keys)
+#else
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+#endif
     bool bad;
     {
         const uint32_t lb = __float_as_uint(l_tot);
@@ -574,7 +594,9 @@ __device__ __forceinline__ void attn2_classic(char* __restrict__ smem, const bf1
                                            int wave_nq = 0) {
     // wave_blk0 >= 0 (attn3_kernel): this wave's blocks are wave_blk0 .. wave_blk0 + wave_nq - 1, one per pass
     constexpr int PCS = 8 / NW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));      // opaque: the lane constants of this rare pass are computed here, not hoisted to the kernel's entry and kept alive
+    const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int b = bh / heads, head = bh - b * heads;
     const int nkv = tokens_pad / KV;
@@ -715,32 +737,66 @@ __global__ __launch_bounds__(NW * 64, MODE == 1 ? HIPTS_ATTN2_SEQ_WAVES : 2) voi
 
 #include "attn3.h"
 
+// The fallback as a function of its own: inlined into the persistent kernel its registers took part in the item loop's allocation and the
+// two hand-placed streams were allocated around them (AGPR spills to scratch in front of each stream).
+template <bool F16>
+__device__ __noinline__ void attn3_classic(char* smem, const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int heads, int tokens, int tokens_pad,
+                                           int bh, int blk0, int nblk, int out_stride, int out_ld, int lo_off, float lo_scale, int wb0, int nq) {
+    attn2_classic<F16, A3_MAXQB, 4>(smem, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale, wb0, nq);
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void attn3_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                       bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int chunks, int out_stride,
-                                                       int classic, int out_ld, int lo_off, float lo_scale) {
+                                                       bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int chunks, int nitems,
+                                                       int out_stride, int classic, int out_ld, int lo_off, float lo_scale) {
+    // Persistent: one workgroup per CU walks the items (an item = one chunk of query blocks of one (image, head)); the K / V ring runs on
+    // across the items -- the last tile steps of an item stage the first tiles of the next.
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     int* redo = reinterpret_cast<int*>(smem3 + A3_LDS);
     if (threadIdx.x == 0) *redo = classic;
-    int wid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, qd = nwg >> 3, rm = nwg & 7, xcd = wid & 7, loc = wid >> 3;
-        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
-    }
-    const int bh = wid / chunks, c = wid - bh * chunks;
-    const int nb = (tokens + 31) / 32;
-    const int blk0 = (c * nb) / chunks, nblk = ((c + 1) * nb) / chunks - blk0;       // <= A3_WG_BLOCKS
+    const unsigned lds0 = (unsigned)(uintptr_t)smem3;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wb0 = blk0 + (wave * nblk) / 4, nq = blk0 + ((wave + 1) * nblk) / 4 - wb0;      // 13 -> 3 3 3 4
-    if (!classic) {
-        const unsigned lds0 = (unsigned)(uintptr_t)smem3;
-        bool bad;
-        if (nq == A3_MAXQB) bad = attn3_body<F16, 4, false>(lds0, q, k, v, out, heads, tokens, tokens_pad, bh, wb0, nq, out_stride, out_ld, lo_off, lo_scale);
-        else bad = attn3_body<F16, 3, F16>(lds0, q, k, v, out, heads, tokens, tokens_pad, bh, wb0, nq, out_stride, out_ld, lo_off, lo_scale);
-        if (bad) *redo = 1;
+    const int nb = (tokens + 31) / 32, nkv = tokens_pad / KV;
+    // XCD-aware item -> work id (attn.hip): the chunks of one (image, head) stream the same K / V -- same XCD, same round.  The chunk roles
+    // rotate with the round, so that the workgroup that had the larger chunk (a wave with four blocks) gets a smaller one next.
+    auto item_bh = [&](int item, int round, int& c) __attribute__((always_inline)) -> int {
+        const int qd = nitems >> 3, rm = nitems & 7, xcd = item & 7, loc = item >> 3;
+        const int wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+        const int bh = wid / chunks;
+        c = (wid - bh * chunks + round) % chunks;
+        return bh;
+    };
+    int gbase = 0;
+    bool fresh = true;
+    int round = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++round) {
+        int c, c2;
+        const int bh = item_bh(item, round, c);
+        const int bh2 = item + (int)gridDim.x < nitems ? item_bh(item + gridDim.x, round + 1, c2) : -1;
+        const int blk0 = (c * nb) / chunks, nblk = ((c + 1) * nb) / chunks - blk0;       // <= A3_WG_BLOCKS
+        const int wb0 = blk0 + (wave * nblk) / 4, nq = blk0 + ((wave + 1) * nblk) / 4 - wb0;      // 13 -> 3 3 3 4
+        if (!classic) {
+            bool bad;
+            if (nq == A3_MAXQB)
+                bad = attn3_body<F16, 4, false>(lds0, q, k, v, out, heads, tokens, tokens_pad, bh, wb0, nq, bh2, gbase, fresh, out_stride, out_ld, lo_off, lo_scale);
+            else
+                bad = attn3_body<F16, 3, F16>(lds0, q, k, v, out, heads, tokens, tokens_pad, bh, wb0, nq, bh2, gbase, fresh, out_stride, out_ld, lo_off, lo_scale);
+            if (bad) *redo = 1;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(*redo) != 0) {             // a wave whose row sum left the window stored nothing; the workgroup repeats the item classically
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staging of the next item may still be in flight: the fallback reuses the ring
+            __syncthreads();
+            attn3_classic<F16>(smem3, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale, wb0, nq);
+            __syncthreads();
+            if (threadIdx.x == 0) *redo = classic;
+            fresh = true;
+        } else {
+            fresh = false;
+        }
+        gbase += nkv;
     }
-    __syncthreads();
-    if (*redo) attn2_classic<F16, A3_MAXQB, 4>(smem3, q, k, v, out, heads, tokens, tokens_pad, bh, blk0, nblk, out_stride, out_ld, lo_off, lo_scale, wb0, nq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <bool F16>
@@ -748,7 +804,7 @@ int launch_attn3(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out,
                  int out_ld, int lo_off, float lo_scale, hipStream_t s) {
     static PerDevice attr;
     int dev = 0;
-    (void)current_device_cus(&dev);
+    const int cus = current_device_cus(&dev);
     {
         std::lock_guard<std::mutex> lk(attr.mu);
         if (!attr.done(dev)) {
@@ -758,7 +814,12 @@ int launch_attn3(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out,
     }
     const int nb = (tokens + 31) / 32;
     const int chunks = (nb + A3_WG_BLOCKS - 1) / A3_WG_BLOCKS;
-    attn3_kernel<F16><<<batch * heads * chunks, 256, A3_LDS + 16, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, ost, classic, out_ld, lo_off, lo_scale);
+    const int nitems = batch * heads * chunks;
+    // a grid of whole rounds: a multiple of 8 * chunks workgroups (the chunks of an (image, head) sit 8 items apart, on one XCD)
+    static const int env_grid = getenv("HIPTS_ATTN3_GRID") ? atoi(getenv("HIPTS_ATTN3_GRID")) : 0;
+    int grid = env_grid > 0 ? env_grid : cus / (8 * chunks) * (8 * chunks);
+    if (grid <= 0 || grid > nitems) grid = nitems;
+    attn3_kernel<F16><<<grid, 256, A3_LDS + 16, s>>>(q, k, v, out, heads, tokens, tokens_pad, chunks, nitems, ost, classic, out_ld, lo_off, lo_scale);
     HIPTS_LAUNCH_CHECK();
     return HIPTS_OK;
 }

@@ -34,7 +34,7 @@ __device__ unsigned long long g_attn3_stamps[4096];
     do {                                                                                    \
         unsigned long long ts_;                                                             \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");         \
-        if (stamp_on && (slot) < 4096) g_attn3_stamps[(slot)] = ts_;                        \
+        if (stamp_on && stamp_base + (slot) < 4096) g_attn3_stamps[stamp_base + (slot)] = ts_; \
     } while (0)
 #else
 #define A3_STAMP(slot) do { } while (0)
@@ -112,7 +112,7 @@ __device__ __forceinline__ void a3_vread(bf16x4& dst, unsigned addr) {
 }
 // LDS-DMA of one 1 KiB piece: M0 = the wave-uniform LDS byte address, per-lane 32-bit byte offset from a scalar base pointer
 #define A3_GLDS(M0ADDR, VOFF, SPTR) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(M0ADDR), "v"(VOFF), "s"(SPTR) : "memory", "m0")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(M0ADDR), "v"(VOFF), "s"(SPTR) : "memory")
 
 template <int QB, bool CI>
 __device__ __forceinline__ void a3_wait_k(A3Regs<QB, CI>& R) {          // the fragments named "+a": no consumer (or copy) moves above the wait
@@ -127,22 +127,30 @@ __device__ __forceinline__ void a3_wait_v(A3Regs<QB, CI>& R) {
 struct A3Dma {
     const char* kb;
     const char* vb;
+    const char* kb2;                 // the workgroup's NEXT (image, head): the tiles past this one's last are its first ones (the ring runs on
+    const char* vb2;                 // across the seam); without a next one they are the last tile again, into a slot nobody reads any more
     unsigned kvo[2], vvo[2];         // per-lane byte offsets inside a tile, pieces wave and wave + 4
     unsigned m0k;                    // lds0 + wave * 1024
     int nkv;
+    int gbase;                       // tiles this workgroup has been through before this item: tile t sits in ring slot (gbase + t) & 3
 };
-// piece `pc` (0 .. 3: K pieces 0, 1, then V pieces 0, 1) of the DMA that follows barrier B_t: K tile t + 3 and V tile t + 2, clamped to
-// the last tile (the copy lands in a slot nobody reads any more)
+// one of the four pieces (K pieces 0, 1, then V pieces 0, 1) of tile tt of this item's numbering (tt >= nkv: the next item's tile tt - nkv)
 template <int PC>
-__device__ __forceinline__ void a3_dma_piece(const A3Dma& d, int t) {
+__device__ __forceinline__ void a3_dma_tile_piece(const A3Dma& d, int tt) {
     constexpr bool ISV = PC >= 2;
     constexpr int pc = PC & 1;
-    int tt = t + (ISV ? 2 : 3);
-    const int slot = tt & (A3_SLOTS - 1);
-    tt = tt < d.nkv ? tt : d.nkv - 1;
-    const char* src = (ISV ? d.vb : d.kb) + (size_t)tt * TILE;
+    const int slot = (d.gbase + tt) & (A3_SLOTS - 1);
+    const bool next = tt >= d.nkv;
+    int tn = next ? tt - d.nkv : tt;
+    tn = tn < d.nkv ? tn : d.nkv - 1;
+    const char* src = (next ? (ISV ? d.vb2 : d.kb2) : (ISV ? d.vb : d.kb)) + (size_t)tn * TILE;
     const unsigned m0 = d.m0k + (ISV ? A3_VBASE : 0) + slot * TILE + pc * 4096;
     A3_GLDS(m0, ISV ? d.vvo[pc] : d.kvo[pc], src);
+}
+// piece PC of the DMA that follows barrier B_t: K tile t + 3 and V tile t + 2
+template <int PC>
+__device__ __forceinline__ void a3_dma_piece(const A3Dma& d, int t) {
+    a3_dma_tile_piece<PC>(d, t + (PC >= 2 ? 2 : 3));
 }
 
 // ---- one MFMA slot of phase A: S(j) chain element, softmax(j - 1) second half, V^T reads of half j - 1, (DMA) ----
@@ -250,14 +258,20 @@ __device__ __forceinline__ void a3_phase_b(A3Regs<QB, CI>& R, const unsigned (&k
     }
 }
 
-// One wave's pass over its nq <= QB query blocks (first block wb0); every wave of the workgroup runs one instance (the barriers).
+// One wave's pass over its nq <= QB query blocks (first block wb0) of one (image, head); every wave of the workgroup runs one instance (the
+// barriers).  bh2: the workgroup's next (image, head), -1 = none; gbase: key tiles the workgroup has been through (the ring position);
+// fresh: the ring holds nothing of this item yet (the workgroup's first item, or the one after a fallback pass).
 // Returns true when a row sum left the fast path's window (nothing stored).
+#define A3_QLOAD(DST, ADDR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(DST) : "v"(ADDR), "i"(OFF) : "memory")
 template <bool F16, int QB, bool CI>
 __device__ __forceinline__ bool attn3_body(unsigned lds0, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                           bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int bh, int wb0, int nq, int out_stride,
-                                           int out_ld, int lo_off, float lo_scale) {
+                                           bf16_t* __restrict__ out, int heads, int tokens, int tokens_pad, int bh, int wb0, int nq, int bh2, int gbase,
+                                           bool fresh, int out_stride, int out_ld, int lo_off, float lo_scale) {
     static_assert(!CI || F16, "CI: the -m_ref accumulator images of the half-operand path");
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));      // opaque per item: the lane constants below are recomputed per item instead of being hoisted out of the
+                                       // workgroup's item loop and kept (spilled) across the OTHER stream's registers
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int b = bh / heads, head = bh - b * heads;
@@ -267,47 +281,56 @@ __device__ __forceinline__ bool attn3_body(unsigned lds0, const bf16_t* __restri
     A3Dma d;
     d.kb = reinterpret_cast<const char*>(k + (size_t)bh * tokens_pad * HD);
     d.vb = reinterpret_cast<const char*>(v + (size_t)bh * tokens_pad * HD);
+    d.kb2 = reinterpret_cast<const char*>(k + (size_t)(bh2 >= 0 ? bh2 : bh) * tokens_pad * HD);      // no next item: this one's first tiles again (never read)
+    d.vb2 = reinterpret_cast<const char*>(v + (size_t)(bh2 >= 0 ? bh2 : bh) * tokens_pad * HD);
     d.m0k = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
     d.nkv = nkv;
+    d.gbase = gbase;
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) {
         const int row = (wave + 4 * pc) * 8 + (lane >> 3);
         d.kvo[pc] = (unsigned)(row * HD + (((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
         d.vvo[pc] = (unsigned)(row * HD + (((lane & 7) ^ (((row >> 1) & 1) << 2)) * 8)) * 2u;
     }
-    // prologue DMA, in the order the counted waits assume: K0 V0 K1 | K2 V1 (what "after B_-1" would have issued) -- then after B_t: K(t+3) V(t+2)
-    {
-        auto piece = [&](bool isv, int tt, int pc) __attribute__((always_inline)) {
-            const int slot = tt & (A3_SLOTS - 1);
-            tt = tt < nkv ? tt : nkv - 1;
-            const char* src = (isv ? d.vb : d.kb) + (size_t)tt * TILE;
-            const unsigned m0 = d.m0k + (isv ? A3_VBASE : 0) + slot * TILE + pc * 4096;
-            A3_GLDS(m0, isv ? d.vvo[pc] : d.kvo[pc], src);
-        };
-        piece(false, 0, 0); piece(false, 0, 1);
-        piece(true, 0, 0); piece(true, 0, 1);
-        piece(false, 1, 0); piece(false, 1, 1);
-        piece(false, 2, 0); piece(false, 2, 1);
-        piece(true, 1, 0); piece(true, 1, 1);
+#ifdef HIPTS_A3_STAMPS
+#ifndef HIPTS_A3_STAMP_WAVE
+#define HIPTS_A3_STAMP_WAVE 0
+#endif
+    const bool stamp_on = blockIdx.x == HIPTS_A3_STAMPS && wave == HIPTS_A3_STAMP_WAVE && lane == 0;
+    const int stamp_base = (gbase / nkv) * 128;          // per item of the workgroup
+#endif
+    A3_STAMP(4);
+    if (fresh) {
+        // in the order the counted waits assume: K0 V0 K1 | K2 V1 (what "after B_-1" would have issued) -- then after B_t: K(t + 3) V(t + 2).
+        // Otherwise the previous item's last tile steps have issued them.
+        a3_dma_tile_piece<0>(d, 0); a3_dma_tile_piece<1>(d, 0);
+        a3_dma_tile_piece<2>(d, 0); a3_dma_tile_piece<3>(d, 0);
+        a3_dma_tile_piece<0>(d, 1); a3_dma_tile_piece<1>(d, 1);
+        a3_dma_tile_piece<0>(d, 2); a3_dma_tile_piece<1>(d, 2);
+        a3_dma_tile_piece<2>(d, 1); a3_dma_tile_piece<3>(d, 1);
     }
     if (nq == 0) {                                   // a wave without query blocks only stages
-        for (int t = 0; t < nkv; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        a3_dma_piece<0>(d, 0); a3_dma_piece<1>(d, 0); a3_dma_piece<2>(d, 0); a3_dma_piece<3>(d, 0);
+        for (int t = 1; t < nkv; ++t) {
             asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             a3_dma_piece<0>(d, t); a3_dma_piece<1>(d, t); a3_dma_piece<2>(d, t); a3_dma_piece<3>(d, t);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return false;
     }
 
     A3Regs<QB, CI> R;
-    // Q^T fragments (B operand): lane (query r, half h), k-step s: d = 16 s + 8 h .. + 7
+    // Q^T fragments (B operand): lane (query r, half h), k-step s: d = 16 s + 8 h .. + 7.  Requested here, straight into the AGPRs; they are
+    // waited for together with the epilogue stores of the previous item in front of B_0 (the compiler knows nothing of these loads)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         int qrow = q0 + 32 * qb + r;
         qrow = qrow < tokens_pad ? qrow : tokens_pad - 1;
         const bf16_t* qp = q + ((size_t)bh * tokens_pad + qrow) * HD + 8 * h;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) R.Q[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        A3_QLOAD(R.Q[qb][0], qp, 0);
+        A3_QLOAD(R.Q[qb][1], qp, 32);
+        A3_QLOAD(R.Q[qb][2], qp, 64);
+        A3_QLOAD(R.Q[qb][3], qp, 96);
         R.l0[qb] = 0.f;
         R.l1[qb] = 0.f;
         R.mref[qb] = 0.f;
@@ -327,12 +350,12 @@ __device__ __forceinline__ bool attn3_body(unsigned lds0, const bf16_t* __restri
         for (int blk = 0; blk < 2; ++blk) va[blk] = lds0 + A3_VBASE + (4 * h + qd) * 128 + (2 * dgrp + (p >> 1) + 4 * (blk ^ x)) * 16 + (p & 1) * 8;
     }
     auto k_addr = [&](int t, unsigned (&kad)[4]) __attribute__((always_inline)) {
-        const unsigned o = (unsigned)((t & (A3_SLOTS - 1)) * TILE);
+        const unsigned o = (unsigned)(((gbase + t) & (A3_SLOTS - 1)) * TILE);
 #pragma unroll
         for (int s = 0; s < 4; ++s) kad[s] = ka[s] + o;
     };
     auto v_addr = [&](int t, unsigned (&vad)[2]) __attribute__((always_inline)) {
-        const unsigned o = (unsigned)((t & (A3_SLOTS - 1)) * TILE);
+        const unsigned o = (unsigned)(((gbase + t) & (A3_SLOTS - 1)) * TILE);
         vad[0] = va[0] + o;
         vad[1] = va[1] + o;
     };
@@ -345,13 +368,13 @@ __device__ __forceinline__ bool attn3_body(unsigned lds0, const bf16_t* __restri
             for (int i = 0; i < 16; ++i) S[qb][i] = (key0 + crow(i, h) >= tokens) ? -INFINITY : S[qb][i];
     };
 
-#ifdef HIPTS_A3_STAMPS
-    const bool stamp_on = blockIdx.x == HIPTS_A3_STAMPS && wave == 0 && lane == 0;
-#endif
     unsigned kad[4], vad[2];
     A3_STAMP(0);
     // ---- half-step 0: B_0, S(0), the reference exponent, the first half of softmax(0), the K fragments of half-step 1
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // (vmcnt(0): Q, and with it everything older -- K0 V0 K1 K2 V1 of this item and the previous item's stores)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) asm volatile("s_waitcnt vmcnt(0)" : "+a"(R.Q[qb][0]), "+a"(R.Q[qb][1]), "+a"(R.Q[qb][2]), "+a"(R.Q[qb][3])::"memory");
+    asm volatile("s_barrier" ::: "memory");
     a3_dma_piece<0>(d, 0); a3_dma_piece<1>(d, 0); a3_dma_piece<2>(d, 0); a3_dma_piece<3>(d, 0);
     k_addr(0, kad);
     v_addr(0, vad);
@@ -426,7 +449,7 @@ __device__ __forceinline__ bool attn3_body(unsigned lds0, const bf16_t* __restri
         a3_phase_a<F16, QB, CI, LC ^ 1, false, true, true, false>(R, vad, d, 0);
         a3_wait_v(R);
         a3_phase_b<F16, QB, CI, LC ^ 1, true, false, false>(R, kad);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // O is read by plain code
         bool bad = false;
         float inv[QB];
 #pragma unroll

@@ -43,7 +43,7 @@ def _from_bits(b, f16=0):
     return (b.astype(np.uint32) << 16).view(np.float32)
 
 
-KERNELS64 = ["attn2", "attn2:3", "attn2:1", "attn"]      # head_dim 64: the round-3 kernel (default geometry and two others) and the round-2 one
+KERNELS64 = ["attn2", "attn2:6", "attn2:3", "attn2:1", "attn"]      # head_dim 64: the round-3 kernel (default geometry and two others) and the round-2 one
 
 
 def _run(q, k, v, tokens, hd, f16=0, kernel="attn"):
@@ -98,6 +98,26 @@ def test_attention_matches_float64_softmax(tokens, hd, f16):
         err = np.abs(got - want).max()
         print("%s %dx%d f16=%d: max |error| %.3e" % (kernel, tokens, hd, f16, err))
         assert err <= TOL[f16], kernel
+
+
+@pytest.mark.parametrize("f16", [0, 1])
+def test_attention_one_wave_per_simd_kernel_walks_several_items(f16):
+    """csrc/attn3.h (variant 6) is persistent: with more (image, head) chunks than compute units a workgroup takes several items in turn, the K / V
+    ring running on across them (the last tile steps of one item stage the first tiles of the next), and a fallback pass in the MIDDLE of a
+    workgroup's items (head 3: a late +300 spike) has to leave the ring usable for the items after it."""
+    rng = np.random.default_rng(11 + f16)
+    BH, tokens, hd = 288, 784, 64                   # 576 items for at most 256 workgroups
+    q = _op(rng.standard_normal((BH, tokens, hd)) * 0.6, f16)
+    k = _op(rng.standard_normal((BH, tokens, hd)), f16)
+    v = _op(rng.standard_normal((BH, tokens, hd)), f16)
+    _spike(q, k, 3, 5, 600, 300.0, f16)
+    got = _run(q, k, v, tokens, hd, f16, "attn2:6")
+    assert np.isfinite(got).all()
+    for b in (0, 1, 2, 3, 4, 127, 128, 129, 200, 255, 256, 257, 287):      # float64 reference of a few heads ...
+        e = np.abs(got[b] - _reference(q[b:b + 1], k[b:b + 1], v[b:b + 1])[0]).max()
+        assert e <= TOL[f16], (b, e)
+    base = _run(q, k, v, tokens, hd, f16, "attn2")                          # ... and all of them against the default kernel
+    assert np.abs(got - base).max() <= 2 * TOL[f16]
 
 
 def _spike(q, k, b, row, key, score, f16):

@@ -121,15 +121,22 @@ def stamps3(f16=1, T=784, B=32):
     g.argtypes = [ctypes.c_void_p, ctypes.c_int]
     _lib.check(g(_lib.ptr(st), 4096))
     st = st.astype(np.int64)
-    print("attn3 stamps f16=%d (%.1f us per launch): prologue %d cycles" % (f16, us.value, st[1] - st[0]))
-    tot = 0
-    for t in range(TP // 64 - 1):
-        s = st[8 + t * 8: 16 + t * 8]
-        nxt = st[8 + (t + 1) * 8] if t + 2 < TP // 64 else s[7]
-        print("  body %2d: A1 %5d B1 %5d | vmcnt %5d barrier %5d | A0 %5d mask %5d B0 %5d | to next %5d | total %6d" % (
-            t, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[6] - s[5], s[7] - s[6], nxt - s[7], nxt - s[0]))
-    last = st[8 + (TP // 64 - 2) * 8 + 7]
-    print("  tail: last P V + sums %d, stores %d; whole wave %d cycles" % (st[2] - last, st[3] - st[2], st[3] - st[0]))
+    print("attn3 stamps f16=%d (%.1f us per launch)" % (f16, us.value))
+    for it in range(4):
+        b = it * 128
+        if st[b + 3] == 0:
+            break
+        print(" item %d: entry -> B_0 wait %d, prologue (B_0 .. first body) %d" % (it, st[b + 0] - st[b + 4], st[b + 1] - st[b + 0]))
+        for t in range(TP // 64 - 1):
+            s = st[b + 8 + t * 8: b + 16 + t * 8]
+            nxt = st[b + 8 + (t + 1) * 8] if t + 2 < TP // 64 else s[7]
+            if t in (0, 1, 5, TP // 64 - 2):
+                print("  body %2d: A1 %5d B1 %5d | vmcnt %5d barrier %5d | A0 %5d mask %5d B0 %5d | to next %5d | total %6d" % (
+                    t, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[6] - s[5], s[7] - s[6], nxt - s[7], nxt - s[0]))
+        last = st[b + 8 + (TP // 64 - 2) * 8 + 7]
+        nxt_item = st[b + 128 + 4]
+        print("  loop %d, last P V + sums %d, stores %d; item %d cycles; to the next item's entry %d" % (
+            last - st[b + 1], st[b + 2] - last, st[b + 3] - st[b + 2], st[b + 3] - st[b + 4], nxt_item - st[b + 3] if nxt_item else -1))
 
 
 if __name__ == "__main__":
