@@ -462,8 +462,11 @@ __global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const bf16_t* __re
             const bool rowok = it < ITEMS && pr < L::PAIRS && iy >= 0 && iy < H;
             const bool ok0 = rowok && ix >= 0 && ix < H, ok1 = rowok && ix + 1 >= 0 && ix + 1 < H;
             const int iyc = min(max(iy, 0), H - 1), ix0 = min(max(ix, 0), H - 1), ix1 = min(max(ix + 1, 0), H - 1);
-            v0[u] = *reinterpret_cast<const uint4*>(img + ((int64_t)iyc * H + ix0) * C + g * 8);
-            v1[u] = *reinterpret_cast<const uint4*>(img + ((int64_t)iyc * H + ix1) * C + g * 8);
+            // 32-bit byte offsets from the image's (scalar) base: an image is far below 4 GB, and the loads take the base from SGPRs
+            // (the review's item 5c: the 64-bit address arithmetic was a fifth of the request phase's instructions)
+            const char* imgb = reinterpret_cast<const char*>(img);
+            v0[u] = *reinterpret_cast<const uint4*>(imgb + (unsigned)(((iyc * H + ix0) * C + g * 8) * 2));
+            v1[u] = *reinterpret_cast<const uint4*>(imgb + (unsigned)(((iyc * H + ix1) * C + g * 8) * 2));
             okmask |= ((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)) << (2 * u);
         }
     };
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_mfma_kernel(const bf16_t* __re
                     const int it = tid + u * 256;
                     const int g = it % G, pixel = it / G;
                     const int oy = y0 + pixel / (16 * XT), ox = x0 + pixel % (16 * XT);
-                    *reinterpret_cast<uint4*>(img + ((int64_t)oy * H + ox) * C + g * 8) = *reinterpret_cast<const uint4*>(smem + pixel * L::OP + g * 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(img) + (unsigned)(((oy * H + ox) * C + g * 8) * 2)) = *reinterpret_cast<const uint4*>(smem + pixel * L::OP + g * 16);
                 }
             } else {
                 for (int it = tid; it < 256 * XT * G; it += 256) {
