@@ -40,6 +40,9 @@ namespace {
 #ifndef HIPTS_ATTN2_ASM_ADD
 #define HIPTS_ATTN2_ASM_ADD 1       // row sums as single v_add_f32 (asm): left alone hipcc pairs them into v_pk_add_f32, which beside MFMAs costs ~24 issue cycles against 2 x 5 (tools/micro/issue_cost.hip): bf16 operands 82-84 -> 78.5 us alone, half operands unchanged (83-85)
 #endif
+#ifndef HIPTS_ATTN2_PV_SNAKE
+#define HIPTS_ATTN2_PV_SNAKE 0
+#endif
 #ifndef HIPTS_ATTN2_MFMA_SUM
 #define HIPTS_ATTN2_MFMA_SUM 0      // 1: the row sums as two more MFMAs per 32 keys (ones x P^T) instead of 32 v_add_f32 -- the loop is bound by vector issue, the matrix pipe ~40 % busy.  NOT usable with half operands: the MFMA takes half subnormals (P < 2^-14, with the reference exponent's head room most keys of a row) as zero, so the P V product already drops them; dividing by the sum of what is LEFT (this switch) triples the error (5.9e-3 against 1.9e-3 at 784 tokens), dividing by the exact sum (the v_add path) keeps the result a scaled-down true average
 #endif
@@ -488,11 +491,18 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
         l_run += ls0 + ls1;
     };
     auto pv = [&](const bf16x8 (&vf)[2][2], const bf16x8& w0, const bf16x8& w1) __attribute__((always_inline)) {
+#if HIPTS_ATTN2_PV_SNAKE      // every MFMA shares an operand with its predecessor (gemm.hip: HIPTS_MFMA_ORDER); same chain per accumulator, same bits
+        o[0] = mfma_32x32x16<F16>(vf[0][0], w0, o[0]);
+        o[1] = mfma_32x32x16<F16>(vf[1][0], w0, o[1]);
+        o[1] = mfma_32x32x16<F16>(vf[1][1], w1, o[1]);
+        o[0] = mfma_32x32x16<F16>(vf[0][1], w1, o[0]);
+#else
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             o[blk] = mfma_32x32x16<F16>(vf[blk][0], w0, o[blk]);
             o[blk] = mfma_32x32x16<F16>(vf[blk][1], w1, o[blk]);
         }
+#endif
 #if HIPTS_ATTN2_MFMA_SUM
         lacc = mfma_32x32x16<F16>(ones, w0, lacc);
         lacc = mfma_32x32x16<F16>(ones, w1, lacc);

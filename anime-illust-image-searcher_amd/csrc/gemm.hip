@@ -33,6 +33,9 @@
 namespace hipts {
 namespace {
 
+#ifndef HIPTS_MFMA_ORDER
+#define HIPTS_MFMA_ORDER 1      // order of a phase's 16 MFMAs (below): 1 = snake, every MFMA shares an operand with its predecessor: forward +0.5 % (5461 / 5460 against 5426 / 5435 images/s, the chip is power-bound), same bits
+#endif
 #include "gemm_epi.h"
 
 
@@ -436,15 +439,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(HIPTS_INT_DEPTH
                         }
                 } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (mh * 4 + i >= MR) continue;
-                        if constexpr (EPI == EPI_VT)
-                            acc[mh * 4 + i][j] = mfma_16x16x32<F16>(af[i], wf[kk][j], acc[mh * 4 + i][j]);
-                        else
-                            acc[mh * 4 + i][j] = mfma_16x16x32<F16>(wf[kk][j], af[i], acc[mh * 4 + i][j]);
-                    }
+                for (int ij = 0; ij < 16; ++ij) {
+                    // HIPTS_MFMA_ORDER (measurement): 0 = rows outer (the A fragment stays for four MFMAs), 1 = snake (every MFMA shares one
+                    // operand with its predecessor), 2 = columns outer (the W fragment stays)
+#if HIPTS_MFMA_ORDER == 2
+                    const int j = ij >> 2, i = ij & 3;
+#elif HIPTS_MFMA_ORDER == 1
+                    const int i = ij >> 2, j = (i & 1) ? 3 - (ij & 3) : (ij & 3);
+#else
+                    const int i = ij >> 2, j = ij & 3;
+#endif
+                    if (mh * 4 + i >= MR) continue;
+                    if constexpr (EPI == EPI_VT)
+                        acc[mh * 4 + i][j] = mfma_16x16x32<F16>(af[i], wf[kk][j], acc[mh * 4 + i][j]);
+                    else
+                        acc[mh * 4 + i][j] = mfma_16x16x32<F16>(wf[kk][j], af[i], acc[mh * 4 + i][j]);
+                }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);

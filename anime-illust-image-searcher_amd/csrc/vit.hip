@@ -1127,6 +1127,10 @@ extern "C" int hiptsdbg_gemm_time(int M, int N, int K, int epi, int iters, float
     const bool dbg_f16 = getenv("HIPTS_DBG_GEMM_F16") != nullptr;      // IEEE-half operands (the product's default)
     for (auto& v : ha) v = dbg_f16 ? f32_to_f16_rne(rnd()) : f32_to_bf16_rne(rnd());
     for (auto& v : hw) v = dbg_f16 ? f32_to_f16_rne(rnd() * 0.05f) : f32_to_bf16_rne(rnd() * 0.05f);
+    if (getenv("HIPTS_DBG_GEMM_ZERO")) {      // all-zero operands: no switching in the matrix pipe, the clock stays up -- the loop's issue rate without the power limit
+        for (auto& v : ha) v = 0;
+        for (auto& v : hw) v = 0;
+    }
     const bool op8 = getenv("HIPTS_GEMM_OP8") != nullptr;      // e4m3 operands: the same bytes, two finite codes per element
     if (op8) {
         for (auto& v : ha) v &= 0xbfbf;
