@@ -33,6 +33,14 @@
 namespace hipts {
 namespace {
 
+#ifndef HIPTS_DW_SNAKE
+#define HIPTS_DW_SNAKE 1       // the same snake order in gemm_dw_kernel's two 4 x 4 product blocks per step
+#endif
+#if HIPTS_DW_SNAKE
+#define HIPTS_SNAKE_J(i, j) (((i) & 1) ? 3 - (j) : (j))
+#else
+#define HIPTS_SNAKE_J(i, j) (j)
+#endif
 #ifndef HIPTS_MFMA_ORDER
 #define HIPTS_MFMA_ORDER 1      // order of a phase's 16 MFMAs (below): 1 = snake, every MFMA shares an operand with its predecessor: forward +0.5 % (5461 / 5460 against 5426 / 5435 images/s, the chip is power-bound), same bits
 #endif
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmArgs a, int t
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                mm(acc[i][j], alo[u][i], wfr[u][j]);
+                mm(acc[i][HIPTS_SNAKE_J(i, j)], alo[u][i], wfr[u][HIPTS_SNAKE_J(i, j)]);
                 if (i == 0) ahi[j] = frag(cur, wave_m * 8 + 4 + j);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -988,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_kernel(const GemmArgs a, int t
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                mm(acc[4 + i][j], ahi[i], wfr[u][j]);
+                mm(acc[4 + i][HIPTS_SNAKE_J(i, j)], ahi[i], wfr[u][HIPTS_SNAKE_J(i, j)]);
                 const int idx = i * 4 + j;
                 if constexpr (has1) {
                     if (idx < 4) wfr[u ^ 1][idx] = frag(nx + DW_A_BYTES, wave_n * 4 + idx);
