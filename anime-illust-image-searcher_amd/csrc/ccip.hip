@@ -69,8 +69,9 @@ struct hipts_ccip {
     size_t pstat = 0;              // float2 per image of stat_part (largest wide stage)
     bool fold_dirty = true;        // a norm / qkv / fc1 tensor changed since the fold vectors were computed
     size_t px = 0, p2c = 0, p4c = 0, pcol = 0, pqk = 0;   // per-image element strides of the workspace buffers (largest stage)
-    hipStream_t sub[2] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {};
+    static constexpr int MAX_SUB = 4;
+    hipStream_t sub[MAX_SUB] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SUB] = {};
     double flops_per_image = 0.0;
 };
 
@@ -986,20 +987,21 @@ int ccip_forward_impl(hipts_ccip* h, const void* input, int in_memspace, bool is
     // (measured, B36 @384: batch 64 2567 -> 2809 images/s; at the reference's batch of 20 the halves are too small
     // to gain and the doubled launch count costs, so small batches stay on the caller's stream)
     static const int min_sub = getenv("HIPTS_CCIP_MINSUB") && atoi(getenv("HIPTS_CCIP_MINSUB")) > 0 ? atoi(getenv("HIPTS_CCIP_MINSUB")) : 16;      // images per sub-batch needed to split
-    const int ns = std::min({want_streams, 2, batch / min_sub});
+    const int ns = std::min({want_streams, (int)hipts_ccip::MAX_SUB, batch / min_sub});      // (round 5, HIPTS_CCIP_STREAMS = 2 / 3 / 4 at batch 64: 3608 / 3458 / 2844 images/s -- two it stays)
     if (ns >= 2) {
         if (!h->ev_fork) {
             HIPTS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < hipts_ccip::MAX_SUB; ++i) {
                 HIPTS_HIP(hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking));
                 HIPTS_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
             }
         }
         HIPTS_HIP(hipEventRecord(h->ev_fork, s));
-        const int nb0 = (batch + 1) / 2;
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < ns; ++i) {
+            const int i0 = (int)((int64_t)batch * i / ns), i1 = (int)((int64_t)batch * (i + 1) / ns);      // (two streams: the halves as before, the larger one first)
+            const int a0 = ns == 2 ? (i ? (batch + 1) / 2 : 0) : i0, a1 = ns == 2 ? (i ? batch : (batch + 1) / 2) : i1;
             HIPTS_HIP(hipStreamWaitEvent(h->sub[i], h->ev_fork, 0));
-            HIPTS_TRY(ccip_run_images(h, in_dev, is_u8, i ? nb0 : 0, i ? batch - nb0 : nb0, f_dev, h->sub[i], true));
+            HIPTS_TRY(ccip_run_images(h, in_dev, is_u8, a0, a1 - a0, f_dev, h->sub[i], true));
             HIPTS_HIP(hipEventRecord(h->ev_join[i], h->sub[i]));
             HIPTS_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
         }
@@ -1125,7 +1127,7 @@ int hipts_ccip_destroy(hipts_ccip_t* h) {
     if (h) {
         (void)hipSetDevice(h->device);
         (void)hipDeviceSynchronize();
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < hipts_ccip::MAX_SUB; ++i) {
             if (h->sub[i]) (void)hipStreamDestroy(h->sub[i]);
             if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
         }
