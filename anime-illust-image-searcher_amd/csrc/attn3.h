@@ -10,13 +10,20 @@
 //   * the 32-key half tiles form a software pipeline written out by hand: half-step j is two phases of 4 QB MFMAs --
 //         phase A:  S(j) = K Q^T              ||  second half of softmax(j - 1)  ||  V^T fragment reads of half j - 1
 //         phase B:  O^T += V^T P^T (j - 1)    ||  first half of softmax(j)       ||  K fragment reads of half j + 1, LDS-DMA of later tiles
-//     every MFMA is followed by its share of the vector work (2 v_exp, 2 v_add, 1 v_cvt_pk: 28 issue cycles in a 32-cycle gap) and at
+//     every MFMA is followed by its share of the vector work (2 v_exp, 2 v_add, 1 v_cvt_pk: 34 issue cycles measured, beside the 8 of the MFMA itself) and at
 //     most one LDS / DMA instruction.  All of it is `asm volatile` statements in program order (hipcc keeps their order and allocates the
 //     registers); waits are counted by hand.
-//   * K / V tiles of 64 keys by LDS-DMA into rings of four slots, two tiles ahead; one vmcnt + one s_barrier per tile.  The DMA of the
-//     tiles past the last one re-reads the last tile into a dead slot: no branch in the stream, a constant vmcnt.
-//   * the 25 query blocks of ViT-B/16@448 go to two workgroups per (image, head): 13 = 3 + 3 + 3 + 4 and 12 = 3 + 3 + 3 + 3; a wave with
-//     four blocks runs the QB = 4 stream (no register room for the -m_ref accumulator images: it subtracts explicitly).
+//   * K / V tiles of 64 keys by LDS-DMA into rings of four slots, two tiles ahead; one vmcnt + one s_barrier per tile.  The kernel is
+//     persistent (one workgroup per CU walks several items = chunks of query blocks of (image, head) pairs) and the ring runs on across
+//     the items: the DMA of the tiles past an item's last one stages the workgroup's NEXT item (without one: this item's first tiles again,
+//     into slots nobody reads) -- no branch in the stream, a constant vmcnt.
+//   * the 25 query blocks of ViT-B/16@448 go to two workgroups per (image, head): 13 = 3 + 3 + 3 + 4 and 12 = 3 + 3 + 3 + 3, the roles
+//     rotating per round; a wave with four blocks runs the QB = 4 stream (no register room for the -m_ref accumulator images: it
+//     subtracts explicitly).
+//   * the V^T fragments live in FIXED registers a[240:255] (see A3_VREAD_P), and the rare fallback pass is a __noinline__ function
+//     (attn2.hip::attn3_classic): both keep hipcc from copying or spilling registers that an asynchronous LDS read is still filling.
+// Measured (LABNOTES.md, round 5): correct, 90 / 96 us alone against 82-85 for attn2_seq_body, slower still inside the forward: the
+// loop is bound by vector issue (42 cycles per MFMA slot at best at head_dim 64) and half of an item is outside the loop.  A/B variant.
 // Arithmetic per element as attn2_seq_body (same MFMA chains, same conversions); only the order of the row sums' additions differs.
 // Requires tokens_pad >= 128 (two key tiles); launch_attention2 keeps shorter sequences on attn2_seq_body.
 
