@@ -49,6 +49,7 @@ struct ProfRec {
 struct hipts_vit {
     bool prof = false;          // events are recorded during THIS forward call
     int prof_every = 0;         // 0 = off, n = record every n-th forward call (sampling keeps event overhead out of the step time)
+    uint32_t prof_mask = 0xffffffffu;      // categories recorded (hipts_vit_profile_select)
     long prof_calls = 0;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;      // recycled events
@@ -615,7 +616,7 @@ struct ProfScope {
     hipStream_t s;
     ProfRec r{};
     bool on;
-    ProfScope(hipts_vit* h_, hipStream_t s_, int cat, double flops, double bytes) : h(h_), s(s_), on(h_->prof) {
+    ProfScope(hipts_vit* h_, hipStream_t s_, int cat, double flops, double bytes) : h(h_), s(s_), on(h_->prof && ((h_->prof_mask >> cat) & 1u)) {
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -1060,6 +1061,12 @@ int hipts_vit_profile_enable(hipts_vit_t* h, int enable) {
     h->prof_every = enable > 0 ? enable : 0;
     h->prof_calls = 0;
     h->prof = false;
+    return HIPTS_OK;
+}
+
+int hipts_vit_profile_select(hipts_vit_t* h, uint32_t category_mask) {
+    HIPTS_REQUIRE(h, "null handle");
+    h->prof_mask = category_mask;
     return HIPTS_OK;
 }
 

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "hipts_vit_set_deferred_join": [c_void_p, c_int],
     "hipts_vit_join": [c_void_p, c_void_p],
     "hipts_vit_profile_enable": [c_void_p, c_int],
+    "hipts_vit_profile_select": [c_void_p, ctypes.c_uint32],
     "hipts_vit_profile_read": [c_void_p, c_int, POINTER(c_double), POINTER(c_int64), POINTER(c_double), POINTER(c_double)],
     "hipts_vit_profile_name": [c_int, c_char_p, c_size_t],
     "hipts_eva_create": [POINTER(EvaConfig), c_int, POINTER(c_void_p)],

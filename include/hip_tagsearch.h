@@ -106,6 +106,10 @@ int hipts_vit_forward_f32(hipts_vit_t* h, const float* x, int x_memspace, int ba
  * Categories are numbered 0 .. HIPTS_VIT_PROF_CATEGORIES-1; name() gives the kernel's name. */
 #define HIPTS_VIT_PROF_CATEGORIES 11
 int hipts_vit_profile_enable(hipts_vit_t* h, int enable);
+/* Which categories are recorded while profiling is enabled (bit c = category c; default: all).  bench.py records only the dominant
+ * kernel's launches inside its timed region -- the events of all ~130 launches of a step cost 0.7 % of the step -- and the full
+ * breakdown in extra steps after it. */
+int hipts_vit_profile_select(hipts_vit_t* h, uint32_t category_mask);
 int hipts_vit_profile_read(hipts_vit_t* h, int category, double* total_ms, int64_t* launches,
                            double* total_flops, double* total_bytes);
 int hipts_vit_profile_name(int category, char* buf, size_t n);
