@@ -44,7 +44,7 @@ namespace {
 #define HIPTS_ATTN2_PV_SNAKE 0
 #endif
 #ifndef HIPTS_ATTN2_MFMA_SUM
-#define HIPTS_ATTN2_MFMA_SUM 0      // 1: the row sums as two more MFMAs per 32 keys (ones x P^T) instead of 32 v_add_f32 -- the loop is bound by vector issue, the matrix pipe ~40 % busy.  NOT usable with half operands: the MFMA takes half subnormals (P < 2^-14, with the reference exponent's head room most keys of a row) as zero, so the P V product already drops them; dividing by the sum of what is LEFT (this switch) triples the error (5.9e-3 against 1.9e-3 at 784 tokens), dividing by the exact sum (the v_add path) keeps the result a scaled-down true average.  (P once more as bf16 for the sum MFMAs alone -- no subnormals there -- fails too: 9e-3, a peaked row's sum is only as good as its largest term's 8 mantissa bits.)
+#define HIPTS_ATTN2_MFMA_SUM 0      // 1: the row sums as two more MFMAs per 32 keys (ones x P^T) instead of 32 v_add_f32 -- the loop is bound by vector issue, the matrix pipe ~40 % busy.  Measured and NOT usable: with half operands the checks fail (5.9e-3 against 1.9e-3 at 784 tokens; bf16 operands pass); P once more as bf16 for the sum MFMAs alone fails too (9e-3: a peaked row's sum is only as good as its largest term's 8 mantissa bits).  Not explained: the error of the default path does not depend on the reference exponent's head room (0 .. 10 bits give the same 1.902e-3, profiles/r05_attn_margin_error.txt), so no subnormal P is lost in the P V product, and the sum of the rounded P should be as good as the exact one
 #endif
 #ifndef HIPTS_ATTN2_SEQ_WAVES
 #define HIPTS_ATTN2_SEQ_WAVES 3          // waves per SIMD the sequential body (MODE 1) is compiled for: 4 -> 128 registers, 3 -> 168
