@@ -44,7 +44,7 @@ namespace {
 #define HIPTS_ATTN2_PV_SNAKE 0
 #endif
 #ifndef HIPTS_ATTN2_MFMA_SUM
-#define HIPTS_ATTN2_MFMA_SUM 0      // 1: the row sums as two more MFMAs per 32 keys (ones x P^T) instead of 32 v_add_f32 -- the loop is bound by vector issue, the matrix pipe ~40 % busy.  Measured and NOT usable: with half operands the checks fail (5.9e-3 against 1.9e-3 at 784 tokens; bf16 operands pass); P once more as bf16 for the sum MFMAs alone fails too (9e-3: a peaked row's sum is only as good as its largest term's 8 mantissa bits).  Not explained: the error of the default path does not depend on the reference exponent's head room (0 .. 10 bits give the same 1.902e-3, profiles/r05_attn_margin_error.txt), so no subnormal P is lost in the P V product, and the sum of the rounded P should be as good as the exact one
+#define HIPTS_ATTN2_MFMA_SUM 0      // 1: the row sums as two more MFMAs per 32 keys (ones x P^T) instead of 32 v_add_f32 -- the loop is bound by vector issue, the matrix pipe ~40 % busy.  Measured and NOT usable with half operands: the MFMA reads half subnormals as zero.  In the P V product that loss is invisible (0.1-0.2 % of a peaked row's mass times the averaged V of its small keys; the default path's error is the same 1.902e-3 for 0 .. 10 bits of head room, profiles/r05_attn_margin_error.txt), but in the SUM it is a pure scale error of the row's output: a few rows of 784 come out 1.0013-1.0017 x too large = 5.9e-3 (profiles/r05_attn_mfma_sum_debug.txt; 3 = both sums side by side, they agree to 4e-5 elsewhere).  P once more as bf16 for the sum MFMAs alone fails too (9e-3: a peaked row's sum is only as good as its largest term's 8 mantissa bits)
 #endif
 #ifndef HIPTS_ATTN2_SEQ_WAVES
 #define HIPTS_ATTN2_SEQ_WAVES 3          // waves per SIMD the sequential body (MODE 1) is compiled for: 4 -> 128 registers, 3 -> 168
@@ -473,7 +473,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
             const float p0 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[i] - m_ref : sacc[i]);
             const float p1 = __builtin_amdgcn_exp2f((F16 && !PRESUB) ? sacc[8 + i] - m_ref : sacc[8 + i]);
 #endif
-#if HIPTS_ATTN2_MFMA_SUM
+#if HIPTS_ATTN2_MFMA_SUM == 1
 #elif !defined(HIPTS_X_NOSUM)
 #if HIPTS_ATTN2_ASM_ADD
             asm("v_add_f32 %0, %0, %1" : "+v"(ls0) : "v"(p0));      // single adds: hipcc pairs plain ones into v_pk_add_f32, which costs more issue cycles than two v_add_f32
@@ -571,7 +571,10 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     }
     if (!active) return false;
 
-#if HIPTS_ATTN2_MFMA_SUM
+#if HIPTS_ATTN2_MFMA_SUM == 3
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (blockIdx.x < 2 && wave == 0 && (lane == 0 || lane == 1 || lane == 33)) printf("blk %d lane %d: adds %.9g  mfma %.9g %.9g %.9g\n", (int)blockIdx.x, lane, l_tot, lacc[0], lacc[5], lacc[15]);
+#elif HIPTS_ATTN2_MFMA_SUM
     const float l_tot = lacc[0];                     // over all keys already (the MFMA sums the two lane halves' keys)
 #else
     const float l_tot = l_run + __shfl_xor(l_run, 32);

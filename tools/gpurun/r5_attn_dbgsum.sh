@@ -1,0 +1,29 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+cd $R/anime-illust-image-searcher_amd/csrc
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function -fno-honor-nans"
+cp attn2.o /tmp/attn2.o.keep; cp ../libhip_tagsearch.so /tmp/lib.keep
+/opt/rocm/bin/hipcc $FLAGS -DHIPTS_ATTN2_MFMA_SUM=${MODE:-3} -c attn2.hip -o attn2.o 2> $R/gpurun_out/r5_dbgsum_build.log && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhip_tagsearch.so *.o || { tail -20 $R/gpurun_out/r5_dbgsum_build.log; exit 1; }
+(cd $R && timeout -k 10 100 python3 - <<'PY'
+import sys, os, ctypes
+sys.path.insert(0, "tools"); sys.path.insert(0, "tests"); sys.path.insert(0, "anime-illust-image-searcher_amd")
+import numpy as np
+from attn2_check import run2, _op, _reference
+rng = np.random.default_rng(848)
+BH, tokens = 2, 784
+q = _op(rng.standard_normal((BH, tokens, 64)) * 0.6, 1); k = _op(rng.standard_normal((BH, tokens, 64)), 1); v = _op(rng.standard_normal((BH, tokens, 64)), 1)
+got = run2(q, k, v, tokens, 1, 5)
+ref = _reference(q, k, v)
+e = np.abs(got - ref)
+print("err", e.max(), "at", np.unravel_index(e.argmax(), e.shape))
+rows = e.max(axis=2)
+for b in range(BH):
+    bad = np.where(rows[b] > 3e-3)[0]
+    print("head", b, "rows over 3e-3:", bad[:40], len(bad))
+    if len(bad):
+        r = bad[0]
+        print(" got", got[b, r, :6], "ref", ref[b, r, :6], "ratio", (got[b, r] / ref[b, r])[:6])
+PY
+) > $R/gpurun_out/r5_dbgsum.txt 2>&1
+cp /tmp/attn2.o.keep attn2.o; cp /tmp/lib.keep ../libhip_tagsearch.so
+tail -12 $R/gpurun_out/r5_dbgsum.txt
