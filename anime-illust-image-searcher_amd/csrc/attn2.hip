@@ -38,7 +38,10 @@ namespace hipts {
 namespace {
 
 #ifndef HIPTS_ATTN2_ASM_ADD
-#define HIPTS_ATTN2_ASM_ADD 1       // row sums as single v_add_f32 (asm): left alone hipcc pairs them into v_pk_add_f32, which beside MFMAs costs ~24 issue cycles against 2 x 5 (tools/micro/issue_cost.hip): bf16 operands 82-84 -> 78.5 us alone, half operands unchanged (83-85)
+#define HIPTS_ATTN2_ASM_ADD 0       // 1: the row sums as single v_add_f32 in (non-volatile) inline asm -- what first kept hipcc from pairing them into v_pk_add_f32; the Makefile's -fno-slp-vectorize does the same without asm (with the sampled reference below the asm form came out WRONG: negative row sums, every workgroup on the fallback pass)
+#endif
+#ifndef HIPTS_ATTN_SAMPLED_REF
+#define HIPTS_ATTN_SAMPLED_REF 0     // attn2_seq_body, half operands: the reference exponent from 32 keys sampled across the sequence instead of the first 32 (then 4 bits of head room do: -DHIPTS_ATTN_REF_MARGIN=4).  Correct; alone the same 84-88 us; forward 5369 against 5400-5407 images/s on noise, 5367-5372 against 5333-5338 on the padded test picture: costs what it gains, off
 #endif
 #ifndef HIPTS_ATTN2_PV_SNAKE
 #define HIPTS_ATTN2_PV_SNAKE 0
@@ -412,6 +415,27 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
     float l_run = 0.f, m_ref = 0.f;
+#if HIPTS_ATTN_SAMPLED_REF
+    if constexpr (F16) {
+        // The reference exponent of the half-operand fast path: this row's maximum over 32 keys SAMPLED across the sequence (one extra
+        // 32 x 32 score block, the K rows straight from memory in the A-operand layout) + the head room.  The first keys' maximum was
+        // the bar of a padded picture; a sample sees what the row will meet, so the head room can be smaller and fewer P fall below
+        // half's normal range (the MFMA reads half subnormals as zero).
+        const int stride = tokens >= 32 ? tokens / 32 : 1;
+        int krow = r * stride + (stride >> 1);
+        krow = krow < tokens ? krow : tokens - 1;
+        const bf16_t* kp = kb + (size_t)krow * HD + 8 * h;
+        f32x16 sref;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sref[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sref = mfma_32x32x16<F16>(*reinterpret_cast<const bf16x8*>(kp + 16 * s), qf[s], sref);
+        float mx = sref[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sref[i]);
+        m_ref = fmaxf(mx, __shfl_xor(mx, 32)) + (float)HIPTS_ATTN_REF_MARGIN;
+    }
+#endif
 #if HIPTS_ATTN2_MFMA_SUM
     f32x16 lacc;                                     // every row: the sum over the keys of P[key][query r]
     bf16x8 ones;
@@ -445,7 +469,7 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     // loop; 32 v_sub per tile otherwise).  The very first half (FIRST) defines m_ref and subtracts explicitly.
     auto s_mfma = [&](const bf16x8 (&kf)[4], int t, int g, f32x16& sacc, auto first_c, auto last_c) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
-        constexpr bool PRESUB = F16 && !FIRST;
+        constexpr bool PRESUB = F16 && (!FIRST || HIPTS_ATTN_SAMPLED_REF);
         const float c0 = PRESUB ? -m_ref : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -457,8 +481,8 @@ __device__ __forceinline__ bool attn2_seq_body(char* __restrict__ smem, const bf
     };
     auto soft = [&](const f32x16& sacc, bf16x8& w0, bf16x8& w1, auto first_c) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value;
-        constexpr bool PRESUB = F16 && !FIRST;
-        if constexpr (F16 && FIRST) {                // the reference: this row's maximum over the first 32 keys
+        constexpr bool PRESUB = F16 && (!FIRST || HIPTS_ATTN_SAMPLED_REF);
+        if constexpr (F16 && FIRST && !HIPTS_ATTN_SAMPLED_REF) {                // the reference: this row's maximum over the first 32 keys
             float mx = sacc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sacc[i]);

@@ -1,9 +1,9 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd $R/anime-illust-image-searcher_amd/csrc
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function -fno-honor-nans"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function -fno-honor-nans -fno-slp-vectorize"
 cp attn2.o /tmp/attn2.o.keep; cp ../libhip_tagsearch.so /tmp/lib.keep
-/opt/rocm/bin/hipcc $FLAGS -DHIPTS_ATTN2_MFMA_SUM=${MODE:-3} -c attn2.hip -o attn2.o 2> $R/gpurun_out/r5_dbgsum_build.log && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhip_tagsearch.so *.o || { tail -20 $R/gpurun_out/r5_dbgsum_build.log; exit 1; }
+/opt/rocm/bin/hipcc $FLAGS ${DEFS:--DHIPTS_ATTN2_MFMA_SUM=3} -c attn2.hip -o attn2.o 2> $R/gpurun_out/r5_dbgsum_build.log && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhip_tagsearch.so *.o || { tail -20 $R/gpurun_out/r5_dbgsum_build.log; exit 1; }
 (cd $R && timeout -k 10 100 python3 - <<'PY'
 import sys, os, ctypes
 sys.path.insert(0, "tools"); sys.path.insert(0, "tests"); sys.path.insert(0, "anime-illust-image-searcher_amd")
